@@ -1,0 +1,140 @@
+"""ctypes binding of libdgs_hip.so (include/dgs_hip.h).
+
+This is the ONLY way the package reaches device code.  There is no CPU or eager-PyTorch fallback: if the
+library is missing or a call fails, a RuntimeError is raised (the CPU oracle under /oracle is test
+infrastructure and is never imported from here).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdgs_hip.so")
+
+DGS_MAX_K = 128
+STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "composite_fwd", "composite_bwd", "geometry_bwd"]
+
+_c_f32p = ctypes.c_void_p  # device pointers are passed as integers
+
+
+class DgsProblem(ctypes.Structure):
+    _fields_ = [
+        ("P", ctypes.c_int32), ("D", ctypes.c_int32), ("M", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("H", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
+        ("z_near", ctypes.c_float), ("z_far", ctypes.c_float),
+        ("use_sigmoid", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
+        ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p), ("colors_precomp", ctypes.c_void_p),
+        ("opacities", ctypes.c_void_p), ("scales", ctypes.c_void_p), ("rotations", ctypes.c_void_p),
+        ("cov3D_precomp", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p), ("projmatrix", ctypes.c_void_p),
+        ("campos", ctypes.c_void_p), ("bg", ctypes.c_void_p),
+        ("geom_state", ctypes.c_void_p), ("geom_bytes", ctypes.c_size_t),
+        ("image_state", ctypes.c_void_p), ("image_bytes", ctypes.c_size_t),
+        ("binning_state", ctypes.c_void_p), ("binning_bytes", ctypes.c_size_t),
+    ]
+
+
+class DgsForwardOut(ctypes.Structure):
+    _fields_ = [("out_color", ctypes.c_void_p), ("out_depth", ctypes.c_void_p), ("radii", ctypes.c_void_p),
+                ("num_rendered_host", ctypes.c_void_p)]
+
+
+class DgsBackwardIO(ctypes.Structure):
+    _fields_ = [
+        ("num_rendered", ctypes.c_uint32), ("radii", ctypes.c_void_p), ("dL_dout_color", ctypes.c_void_p),
+        ("dL_dout_depth", ctypes.c_void_p), ("scratch", ctypes.c_void_p), ("scratch_bytes", ctypes.c_size_t),
+        ("dL_dmeans3D", ctypes.c_void_p), ("dL_dmeans2D", ctypes.c_void_p), ("dL_dsh", ctypes.c_void_p),
+        ("dL_dcolors", ctypes.c_void_p), ("dL_dopacity", ctypes.c_void_p), ("dL_dscales", ctypes.c_void_p),
+        ("dL_drotations", ctypes.c_void_p), ("dL_dcov3D", ctypes.c_void_p), ("dL_dviewmatrix", ctypes.c_void_p),
+        ("dL_dprojmatrix", ctypes.c_void_p),
+    ]
+
+
+class DgsLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_size_t) for n in (
+        "geom_rows", "cov3D", "pre_sigmoid", "tiles_touched", "point_offsets", "scan_tmp", "num_rendered",
+        "geom_total", "final_T", "n_contrib", "ranges", "image_total", "keys_sorted", "point_list",
+        "keys_unsorted", "vals_unsorted", "sort_tmp", "binning_total")] + [
+        ("sort_bits", ctypes.c_int32), ("sort_passes", ctypes.c_int32)]
+
+
+# every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
+EXPORTS = {
+    "dgs_abi_version": (ctypes.c_int, []),
+    "dgs_last_error": (ctypes.c_char_p, []),
+    "dgs_geom_state_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "dgs_image_state_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dgs_binning_state_bytes": (ctypes.c_size_t, [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dgs_backward_scratch_bytes": (ctypes.c_size_t, [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32]),
+    "dgs_layout": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64,
+                                  ctypes.POINTER(DgsLayout)]),
+    "dgs_forward_geometry": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsForwardOut),
+                                            ctypes.c_void_p]),
+    "dgs_forward_render": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsForwardOut),
+                                          ctypes.c_uint32, ctypes.c_void_p]),
+    "dgs_backward": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsBackwardIO), ctypes.c_void_p]),
+    "dgs_mark_visible": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "dgs_scan_tmp_bytes": (ctypes.c_size_t, [ctypes.c_uint64]),
+    "dgs_exclusive_scan_u32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_void_p]),
+    "dgs_sort_tmp_bytes": (ctypes.c_size_t, [ctypes.c_uint64]),
+    "dgs_sort_pairs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p]),
+    "dgs_blur_loss_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p]),
+    "dgs_profile_enable": (ctypes.c_int, [ctypes.c_int32]),
+    "dgs_profile_reset": (ctypes.c_int, []),
+    "dgs_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32),
+                                        ctypes.c_int32]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libdgs_hip.so (fails loudly: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m deblurgs_amd.build` (hipcc, gfx950). "
+                "deblurgs_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.dgs_abi_version() != 1:
+            raise RuntimeError("libdgs_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().dgs_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libdgs_hip {what} failed (code {rc}): {msg}")
+
+
+def layout(P, W, H, K, R):
+    L = DgsLayout()
+    check(lib().dgs_layout(P, W, H, K, R, ctypes.byref(L)), "dgs_layout")
+    return L
+
+
+def profile_enable(on=True):
+    check(lib().dgs_profile_enable(1 if on else 0), "profile_enable")
+
+
+def profile_reset():
+    check(lib().dgs_profile_reset(), "profile_reset")
+
+
+def profile_read():
+    n = len(STAGES)
+    ms = (ctypes.c_float * n)()
+    calls = (ctypes.c_int32 * n)()
+    check(lib().dgs_profile_read(ms, calls, n), "profile_read")
+    return {STAGES[i]: (float(ms[i]), int(calls[i])) for i in range(n)}

@@ -1,0 +1,438 @@
+// api.hip -- the extern "C" surface of libdgs_hip.so (include/dgs_hip.h): argument checks, blob carving,
+// stage sequencing (replaces Rasterizer::forward / ::backward, rasterizer_impl.cu:198-463, and the torch glue
+// in rasterize_points.cu:35-239), stage timing and the fused loss-gradient image kernel.
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "dgs_common.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a = "") {
+  snprintf(g_err, sizeof(g_err), fmt, a);
+  return code;
+}
+int fail_hip(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+  return DGS_E_HIP;
+}
+
+constexpr size_t ALIGN = 256;
+size_t up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
+
+int sort_bits_for(int W, int H, int K) {
+  const uint32_t T = (uint32_t)((W + DGS_TILE - 1) / DGS_TILE) * (uint32_t)((H + DGS_TILE - 1) / DGS_TILE);
+  return 32 + (int)dgs_higher_msb(T * (uint32_t)K);  // rasterizer_impl.cu:306, with K*T tiles
+}
+
+void make_layout(int P, int W, int H, int K, uint64_t R, DgsLayout* L) {
+  const size_t KP = (size_t)K * (size_t)P;
+  const size_t N = (size_t)W * (size_t)H;
+  const size_t T = (size_t)((W + DGS_TILE - 1) / DGS_TILE) * (size_t)((H + DGS_TILE - 1) / DGS_TILE);
+  size_t o = 0;
+  L->geom_rows = o;      o += up(KP * sizeof(DgsRow));
+  L->cov3D = o;          o += up((size_t)P * 6 * 4);
+  L->pre_sigmoid = o;    o += up(KP * 3 * 4);
+  L->tiles_touched = o;  o += up(KP * 4);
+  L->point_offsets = o;  o += up(KP * 4);
+  L->scan_tmp = o;       o += up(dgs_scan_tmp_words(KP) * 4);
+  L->num_rendered = o;   o += up(16);
+  L->geom_total = o;
+  o = 0;
+  L->final_T = o;        o += up((size_t)K * N * 4);
+  L->n_contrib = o;      o += up((size_t)K * N * 4);
+  L->ranges = o;         o += up((size_t)K * T * 8);
+  L->image_total = o;
+  o = 0;
+  L->keys_sorted = o;    o += up(R * 8);
+  L->point_list = o;     o += up(R * 4);
+  L->keys_unsorted = o;  o += up(R * 8);
+  L->vals_unsorted = o;  o += up(R * 4);
+  L->sort_tmp = o;       o += up(dgs_sort_tmp_words(R) * 4);
+  L->binning_total = o;
+  L->sort_bits = sort_bits_for(W, H, K);
+  L->sort_passes = dgs_sort_num_passes(L->sort_bits);
+}
+
+int check_problem(const DgsProblem* p) {
+  if (p == nullptr) return fail(DGS_E_ARG, "null DgsProblem");
+  if (p->P < 0 || p->W <= 0 || p->H <= 0) return fail(DGS_E_ARG, "bad P/W/H");
+  if (p->K < 1 || p->K > DGS_MAX_K) return fail(DGS_E_ARG, "K must be in [1, DGS_MAX_K]");
+  if (p->D < 0 || p->D > 3) return fail(DGS_E_ARG, "SH degree must be 0..3");
+  if (p->P == 0) return DGS_OK;
+  if (p->means3D == nullptr || p->opacities == nullptr) return fail(DGS_E_ARG, "means3D / opacities are null");
+  if ((p->shs == nullptr) == (p->colors_precomp == nullptr))
+    return fail(DGS_E_ARG, "Please provide excatly one of either SHs or precomputed colors!");
+  const bool sr = (p->scales != nullptr) && (p->rotations != nullptr);
+  if (((p->scales == nullptr || p->rotations == nullptr) && p->cov3D_precomp == nullptr) ||
+      ((p->scales != nullptr || p->rotations != nullptr) && p->cov3D_precomp != nullptr))
+    return fail(DGS_E_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+  (void)sr;
+  if (p->shs != nullptr && p->M < (p->D + 1) * (p->D + 1)) return fail(DGS_E_ARG, "M < (D+1)^2");
+  if (p->viewmatrix == nullptr || p->projmatrix == nullptr || p->campos == nullptr || p->bg == nullptr)
+    return fail(DGS_E_ARG, "viewmatrix / projmatrix / campos / bg are null");
+  if ((uint64_t)p->K * (uint64_t)p->P >= (1ull << 32)) return fail(DGS_E_ARG, "K*P must be < 2^32");
+  return DGS_OK;
+}
+
+DgsView make_view(const DgsProblem* p) {
+  DgsView v;
+  v.P = p->P; v.D = p->D; v.M = p->M; v.W = p->W; v.H = p->H; v.K = p->K;
+  v.gx = (p->W + DGS_TILE - 1) / DGS_TILE;
+  v.gy = (p->H + DGS_TILE - 1) / DGS_TILE;
+  v.T = v.gx * v.gy;
+  v.tanfovx = p->tanfovx; v.tanfovy = p->tanfovy;
+  v.focal_y = p->H / (2.0f * p->tanfovy);  // rasterizer_impl.cu:227-228
+  v.focal_x = p->W / (2.0f * p->tanfovx);
+  v.scale_modifier = p->scale_modifier;
+  v.z_far = p->z_far;
+  v.use_sigmoid = p->use_sigmoid; v.prefiltered = p->prefiltered;
+  return v;
+}
+
+void carve(const DgsProblem* p, const DgsLayout& L, DgsCarve* c) {
+  char* g = reinterpret_cast<char*>(p->geom_state);
+  char* im = reinterpret_cast<char*>(p->image_state);
+  char* b = reinterpret_cast<char*>(p->binning_state);
+  c->rows = reinterpret_cast<DgsRow*>(g + L.geom_rows);
+  c->cov3D = reinterpret_cast<float*>(g + L.cov3D);
+  c->pre_sigmoid = reinterpret_cast<float*>(g + L.pre_sigmoid);
+  c->tiles_touched = reinterpret_cast<uint32_t*>(g + L.tiles_touched);
+  c->point_offsets = reinterpret_cast<uint32_t*>(g + L.point_offsets);
+  c->scan_tmp = reinterpret_cast<uint32_t*>(g + L.scan_tmp);
+  c->num_rendered = reinterpret_cast<uint32_t*>(g + L.num_rendered);
+  c->final_T = reinterpret_cast<float*>(im + L.final_T);
+  c->n_contrib = reinterpret_cast<uint32_t*>(im + L.n_contrib);
+  c->ranges = reinterpret_cast<uint2*>(im + L.ranges);
+  c->keys_sorted = b ? reinterpret_cast<uint64_t*>(b + L.keys_sorted) : nullptr;
+  c->point_list = b ? reinterpret_cast<uint32_t*>(b + L.point_list) : nullptr;
+  c->keys_unsorted = b ? reinterpret_cast<uint64_t*>(b + L.keys_unsorted) : nullptr;
+  c->vals_unsorted = b ? reinterpret_cast<uint32_t*>(b + L.vals_unsorted) : nullptr;
+  c->sort_tmp = b ? reinterpret_cast<uint32_t*>(b + L.sort_tmp) : nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------- profiling
+constexpr int PROF_MAX = 16384;
+struct Prof {
+  std::mutex mu;
+  bool on = false;
+  int n = 0;
+  hipEvent_t beg[PROF_MAX], end[PROF_MAX];
+  int stage[PROF_MAX];
+  int created = 0;
+} g_prof;
+
+int prof_begin(int stage, hipStream_t s) {
+  if (!g_prof.on) return -1;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  if (g_prof.n >= PROF_MAX) return -1;
+  const int i = g_prof.n++;
+  if (i >= g_prof.created) {
+    hipEventCreate(&g_prof.beg[i]);
+    hipEventCreate(&g_prof.end[i]);
+    g_prof.created = i + 1;
+  }
+  g_prof.stage[i] = stage;
+  hipEventRecord(g_prof.beg[i], s);
+  return i;
+}
+void prof_end(int i, hipStream_t s) {
+  if (i >= 0) hipEventRecord(g_prof.end[i], s);
+}
+
+struct StageTimer {
+  int id;
+  hipStream_t s;
+  StageTimer(int stage, hipStream_t st) : id(prof_begin(stage, st)), s(st) {}
+  ~StageTimer() { prof_end(id, s); }
+};
+
+#define DGS_STAGE(stage_id, where, expr)                                   \
+  do {                                                                      \
+    hipError_t e__;                                                         \
+    {                                                                       \
+      StageTimer tm__(stage_id, s);                                         \
+      e__ = (expr);                                                         \
+    }                                                                       \
+    if (e__ != hipSuccess) return fail_hip(e__, where);                     \
+    if (p->debug) {                                                         \
+      e__ = hipStreamSynchronize(s);                                        \
+      if (e__ != hipSuccess) return fail_hip(e__, where " (debug sync)");   \
+    }                                                                       \
+  } while (0)
+
+// --------------------------------------------------------------------------- fused loss-gradient image (f1)
+// train.py:143-165 with utils/loss_utils.py:17-18 (l1_loss) and :80-93 (batchwise_smoothness_loss):
+//   blur = mean_k sub_k;  L = mean|blur - gt| + lambda_t * mean|sub_{k+1} - sub_k|
+//   dL/dsub_k = sign(blur-gt)/(E*K) + lambda_t * [sign(sub_k - sub_{k-1}) - sign(sub_{k+1} - sub_k)] / (E*(K-1))
+// with E = C*H*W.  One thread per (channel, pixel) element; replaces ~20 elementwise launches and ~1.5 GB of
+// traffic between the fused forward and backward.
+__device__ __forceinline__ float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+__global__ void __launch_bounds__(256)
+blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, int K, size_t E, float lambda_t,
+                 float* __restrict__ blur, float* __restrict__ dsub, float* __restrict__ losses) {
+  __shared__ float red[2][4];
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  float l1 = 0.0f, sm = 0.0f;
+  if (e < E) {
+    float acc = 0.0f;
+    for (int k = 0; k < K; k++) acc += sub[(size_t)k * E + e];
+    const float b = acc / (float)K;
+    blur[e] = b;
+    const float d = b - gt[e];
+    l1 = fabsf(d);
+    const float g_l1 = sgn(d) / ((float)E * (float)K);
+    const float ws = (K > 1) ? lambda_t / ((float)E * (float)(K - 1)) : 0.0f;
+    float prev = sub[e];
+    float s_prev = 0.0f;  // sign(x_k - x_{k-1})
+    for (int k = 0; k < K; k++) {
+      float s_next = 0.0f;
+      float nxt = prev;
+      if (k + 1 < K) {
+        nxt = sub[(size_t)(k + 1) * E + e];
+        const float dd = nxt - prev;
+        sm += fabsf(dd);
+        s_next = sgn(dd);
+      }
+      dsub[(size_t)k * E + e] = g_l1 + ws * (s_prev - s_next);
+      s_prev = s_next;
+      prev = nxt;
+    }
+  }
+  l1 = dgs_wave_sum63(l1);
+  sm = dgs_wave_sum63(sm);
+  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  if (lane == 63) {
+    red[0][w] = l1;
+    red[1][w] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const float c = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    atomicAdd(&losses[0], a / (float)E);
+    if (K > 1) atomicAdd(&losses[1], c / ((float)E * (float)(K - 1)));
+  }
+}
+
+}  // namespace
+
+hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t, float* blur,
+                                float* dsub, float* losses, hipStream_t s) {
+  const size_t E = (size_t)C * HW;
+  hipError_t e = hipMemsetAsync(losses, 0, 2 * sizeof(float), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(blur_loss_kernel, dim3((uint32_t)((E + 255) / 256)), dim3(256), 0, s, sub, gt, K, E, lambda_t,
+                     blur, dsub, losses);
+  return hipGetLastError();
+}
+
+extern "C" {
+
+int dgs_abi_version(void) { return DGS_ABI_VERSION; }
+const char* dgs_last_error(void) { return g_err; }
+
+size_t dgs_geom_state_bytes(int32_t P, int32_t K) {
+  DgsLayout L;
+  make_layout(P, 16, 16, K, 0, &L);
+  return L.geom_total;
+}
+size_t dgs_image_state_bytes(int32_t W, int32_t H, int32_t K) {
+  DgsLayout L;
+  make_layout(0, W, H, K, 0, &L);
+  return L.image_total;
+}
+size_t dgs_binning_state_bytes(uint64_t R, int32_t W, int32_t H, int32_t K) {
+  DgsLayout L;
+  make_layout(0, W, H, K, R, &L);
+  return L.binning_total;
+}
+size_t dgs_backward_scratch_bytes(uint64_t R, int32_t P, int32_t K) {
+  return up((size_t)R * DGS_CONTRIB_F * 4) + up((size_t)dgs_geometry_bwd_blocks(P) * (size_t)K * 24 * 4) + ALIGN;
+}
+int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, DgsLayout* out) {
+  if (out == nullptr) return fail(DGS_E_ARG, "null DgsLayout");
+  make_layout(P, W, H, K, R, out);
+  return DGS_OK;
+}
+
+int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = check_problem(p);
+  if (rc != DGS_OK) return rc;
+  if (out == nullptr || out->radii == nullptr || out->num_rendered_host == nullptr)
+    return fail(DGS_E_ARG, "DgsForwardOut: radii / num_rendered_host are null");
+  if (p->P == 0) {  // rasterize_points.cu:85 -- nothing to launch
+    *out->num_rendered_host = 0;
+    return DGS_OK;
+  }
+  DgsLayout L;
+  make_layout(p->P, p->W, p->H, p->K, 0, &L);
+  if (p->geom_state == nullptr || p->geom_bytes < L.geom_total) return fail(DGS_E_CAPACITY, "geom_state too small");
+  DgsCarve c;
+  carve(p, L, &c);
+  const DgsView v = make_view(p);
+  DGS_STAGE(DGS_STAGE_PREPROCESS, "preprocess", dgs_launch_preprocess(*p, v, c, out->radii, s));
+  DGS_STAGE(DGS_STAGE_SCAN, "scan",
+            dgs_launch_scan(c.tiles_touched, c.point_offsets, (uint64_t)p->K * p->P, c.scan_tmp, c.num_rendered, s));
+  hipError_t e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return fail_hip(e, "copy num_rendered");
+  return DGS_OK;
+}
+
+int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t R, dgs_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = check_problem(p);
+  if (rc != DGS_OK) return rc;
+  if (out == nullptr || out->out_color == nullptr || out->out_depth == nullptr)
+    return fail(DGS_E_ARG, "DgsForwardOut: out_color / out_depth are null");
+  const size_t N = (size_t)p->W * p->H;
+  if (p->P == 0) {  // the reference returns zero-filled images when P == 0 (rasterize_points.cu:70-71,85)
+    hipError_t e = hipMemsetAsync(out->out_color, 0, (size_t)p->K * 3 * N * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(out->out_depth, 0, (size_t)p->K * N * 4, s);
+    return e == hipSuccess ? DGS_OK : fail_hip(e, "memset outputs");
+  }
+  DgsLayout L;
+  make_layout(p->P, p->W, p->H, p->K, R, &L);
+  if (p->geom_state == nullptr || p->geom_bytes < L.geom_total) return fail(DGS_E_CAPACITY, "geom_state too small");
+  if (p->image_state == nullptr || p->image_bytes < L.image_total) return fail(DGS_E_CAPACITY, "image_state too small");
+  if (R > 0 && (p->binning_state == nullptr || p->binning_bytes < L.binning_total))
+    return fail(DGS_E_CAPACITY, "binning_state too small");
+  DgsCarve c;
+  carve(p, L, &c);
+  const DgsView v = make_view(p);
+  if (R > 0) {
+    // choose the sort's input pair so that the result always lands in keys_sorted / point_list
+    DgsCarve cd = c;
+    const bool even = (L.sort_passes % 2) == 0;
+    if (even) {
+      cd.keys_unsorted = c.keys_sorted;
+      cd.vals_unsorted = c.point_list;
+    }
+    DGS_STAGE(DGS_STAGE_DUPLICATE, "duplicateWithKeys", dgs_launch_duplicate(v, cd, s));
+    int in_alt = 0;
+    uint64_t* kalt = even ? c.keys_unsorted : c.keys_sorted;
+    uint32_t* valt = even ? c.vals_unsorted : c.point_list;
+    DGS_STAGE(DGS_STAGE_SORT, "radix sort",
+              dgs_launch_sort(cd.keys_unsorted, cd.vals_unsorted, kalt, valt, R, L.sort_bits, c.sort_tmp, &in_alt, s));
+  }
+  DGS_STAGE(DGS_STAGE_RANGES, "identifyTileRanges", dgs_launch_ranges(v, c, R, s));
+  DGS_STAGE(DGS_STAGE_COMPOSITE_FWD, "composite forward",
+            dgs_launch_composite_fwd(v, c, p->bg, out->out_color, out->out_depth, s));
+  return DGS_OK;
+}
+
+int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = check_problem(p);
+  if (rc != DGS_OK) return rc;
+  if (io == nullptr) return fail(DGS_E_ARG, "null DgsBackwardIO");
+  if (io->dL_dviewmatrix == nullptr || io->dL_dprojmatrix == nullptr)
+    return fail(DGS_E_ARG, "dL_dviewmatrix / dL_dprojmatrix are null");
+  if (p->P == 0) {
+    hipError_t e = hipMemsetAsync(io->dL_dviewmatrix, 0, (size_t)p->K * 64, s);
+    if (e == hipSuccess) e = hipMemsetAsync(io->dL_dprojmatrix, 0, (size_t)p->K * 64, s);
+    return e == hipSuccess ? DGS_OK : fail_hip(e, "memset grads");
+  }
+  if (io->dL_dout_color == nullptr || io->radii == nullptr || io->dL_dmeans3D == nullptr ||
+      io->dL_dmeans2D == nullptr || io->dL_dcolors == nullptr || io->dL_dopacity == nullptr ||
+      io->dL_dcov3D == nullptr)
+    return fail(DGS_E_ARG, "DgsBackwardIO: a required pointer is null");
+  if (p->shs != nullptr && io->dL_dsh == nullptr) return fail(DGS_E_ARG, "dL_dsh is null");
+  if (p->scales != nullptr && (io->dL_dscales == nullptr || io->dL_drotations == nullptr))
+    return fail(DGS_E_ARG, "dL_dscales / dL_drotations are null");
+  const uint64_t R = io->num_rendered;
+  DgsLayout L;
+  make_layout(p->P, p->W, p->H, p->K, R, &L);
+  if (p->geom_state == nullptr || p->geom_bytes < L.geom_total) return fail(DGS_E_CAPACITY, "geom_state too small");
+  if (p->image_state == nullptr || p->image_bytes < L.image_total) return fail(DGS_E_CAPACITY, "image_state too small");
+  if (R > 0 && (p->binning_state == nullptr || p->binning_bytes < L.binning_total))
+    return fail(DGS_E_CAPACITY, "binning_state too small");
+  if (io->scratch == nullptr || io->scratch_bytes < dgs_backward_scratch_bytes(R, p->P, p->K))
+    return fail(DGS_E_CAPACITY, "backward scratch too small");
+  DgsCarve c;
+  carve(p, L, &c);
+  const DgsView v = make_view(p);
+  float* contrib = reinterpret_cast<float*>(io->scratch);
+  float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(io->scratch) + up((size_t)R * DGS_CONTRIB_F * 4));
+  DGS_STAGE(DGS_STAGE_COMPOSITE_BWD, "composite backward",
+            dgs_launch_composite_bwd(v, c, p->bg, io->dL_dout_color, io->dL_dout_depth, contrib, s));
+  DGS_STAGE(DGS_STAGE_GEOMETRY_BWD, "geometry backward", dgs_launch_geometry_bwd(*p, v, c, *io, contrib, partials, s));
+  return DGS_OK;
+}
+
+int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, dgs_stream_t stream) {
+  (void)projmatrix;  // in_frustum only uses the view depth (auxiliary.h:159)
+  if (P < 0 || (P > 0 && (means3D == nullptr || viewmatrix == nullptr || present == nullptr)))
+    return fail(DGS_E_ARG, "mark_visible: null pointer");
+  if (P == 0) return DGS_OK;
+  hipError_t e = dgs_launch_mark_visible(P, means3D, viewmatrix, present, reinterpret_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DGS_OK : fail_hip(e, "mark_visible");
+}
+
+size_t dgs_scan_tmp_bytes(uint64_t n) { return dgs_scan_tmp_words(n) * 4; }
+int dgs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, void* tmp, uint32_t* total_out,
+                           dgs_stream_t stream) {
+  hipError_t e = dgs_launch_scan(in, out, n, reinterpret_cast<uint32_t*>(tmp), total_out,
+                                 reinterpret_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DGS_OK : fail_hip(e, "scan");
+}
+size_t dgs_sort_tmp_bytes(uint64_t n) { return dgs_sort_tmp_words(n) * 4; }
+int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
+                   int32_t end_bit, void* tmp, int32_t* result_in_alt, dgs_stream_t stream) {
+  if (n >= (1ull << 32)) return fail(DGS_E_ARG, "sort: n must be < 2^32");
+  int alt = 0;
+  hipError_t e = dgs_launch_sort(keys, vals, keys_alt, vals_alt, n, end_bit, reinterpret_cast<uint32_t*>(tmp), &alt,
+                                 reinterpret_cast<hipStream_t>(stream));
+  if (result_in_alt) *result_in_alt = alt;
+  return e == hipSuccess ? DGS_OK : fail_hip(e, "sort");
+}
+
+int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW, float lambda_t,
+                       float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream) {
+  if (subframes == nullptr || gt == nullptr || blur == nullptr || dL_dsubframes == nullptr || losses == nullptr ||
+      K < 1 || C < 1 || HW < 1)
+    return fail(DGS_E_ARG, "blur_loss_grad: bad argument");
+  hipError_t e = dgs_launch_blur_loss(subframes, gt, K, C, HW, lambda_t, blur, dL_dsubframes, losses,
+                                      reinterpret_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DGS_OK : fail_hip(e, "blur_loss_grad");
+}
+
+int dgs_profile_enable(int32_t on) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.on = on != 0;
+  return DGS_OK;
+}
+int dgs_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.n = 0;
+  return DGS_OK;
+}
+int dgs_profile_read(float* ms, int32_t* calls, int32_t n) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  for (int i = 0; i < n; i++) {
+    if (ms) ms[i] = 0.0f;
+    if (calls) calls[i] = 0;
+  }
+  for (int i = 0; i < g_prof.n; i++) {
+    hipError_t e = hipEventSynchronize(g_prof.end[i]);
+    if (e != hipSuccess) return fail_hip(e, "profile_read");
+    float t = 0.0f;
+    e = hipEventElapsedTime(&t, g_prof.beg[i], g_prof.end[i]);
+    if (e != hipSuccess) return fail_hip(e, "profile_read");
+    const int st = g_prof.stage[i];
+    if (st >= 0 && st < n) {
+      if (ms) ms[st] += t;
+      if (calls) calls[st] += 1;
+    }
+  }
+  return DGS_OK;
+}
+
+}  // extern "C"

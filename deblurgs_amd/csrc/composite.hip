@@ -1,0 +1,404 @@
+// composite.hip -- per-tile alpha compositing, forward and backward, for all K subframes in one launch
+// (replaces renderCUDA<3> forward, forward.cu:273-392, and backward, backward.cu:463-640).
+//
+// CDNA4 design (not the reference's 256-thread / one-pixel-per-thread block):
+//   * ONE wave64 owns one 16x16 tile; each lane carries 4 pixels, one in each 8x8 quadrant.  No block
+//     barriers, no __syncthreads_count: termination votes and culling masks are 64-bit ballots in SGPRs.
+//   * The tile's sorted duplicate list is consumed in batches of 64: lane j gathers Gaussian j's 48-byte
+//     geometry row with three 16-byte loads, tests its alpha>=1/255 ellipse against the four quadrants
+//     (conservative bounding box) and publishes the row to LDS.  The per-Gaussian loop then walks only the
+//     set bits of the ballot masks, so a (Gaussian, quadrant) pair that cannot contribute costs nothing.
+//     Culling is conservative, hence the per-pixel tests below are exactly the reference's.
+//   * Backward: no global atomics.  The 10 per-Gaussian partial gradients are summed over a lane's pixels
+//     in registers, over the wave with DPP (dgs_wave_sum63), staged per batch in LDS, and stored as ONE
+//     48-byte contribution row per (tile, Gaussian) duplicate.  geometry_bwd.hip sums a Gaussian's rows in
+//     duplicate order, so the whole backward is bitwise reproducible (the reference issues 10 float
+//     atomicAdds per (pixel, Gaussian), backward.cu:599-637).
+#include "dgs_common.h"
+
+namespace {
+
+constexpr int CW = 4;  // waves (= tiles) per 256-thread block; the waves never synchronise with each other
+
+struct TileCtx {
+  int k, tx, ty;
+  uint32_t r0, r1;
+};
+
+// XCD-aware block -> tile-group map: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+// run of tiles so that neighbouring tiles, which share Gaussians, hit the same L2.  Speed only.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t per_xcd) { return (b & 7u) * per_xcd + (b >> 3); }
+
+__device__ __forceinline__ bool load_tile_ctx(const DgsView& v, const uint2* __restrict__ ranges, uint32_t per_xcd,
+                                              TileCtx& t) {
+  const uint32_t logical = xcd_remap(blockIdx.x, per_xcd);
+  const uint32_t gw = logical * CW + (threadIdx.x >> 6);
+  const uint32_t KT = (uint32_t)v.K * (uint32_t)v.T;
+  if (gw >= KT) return false;
+  t.k = (int)(gw / (uint32_t)v.T);
+  const uint32_t tile = gw - (uint32_t)t.k * (uint32_t)v.T;
+  t.ty = (int)(tile / (uint32_t)v.gx);
+  t.tx = (int)(tile - (uint32_t)t.ty * (uint32_t)v.gx);
+  const uint2 r = ranges[gw];
+  t.r0 = r.x;
+  t.r1 = r.y;
+  return true;
+}
+
+// Conservative test: can Gaussian (x, y, conic cx/cy/cz, opacity op) reach alpha >= 1/255 anywhere in the
+// pixel square [qx0, qx0+7] x [qy0, qy0+7]?  alpha = op*exp(power) >= 1/255  <=>  q(d) <= 2 ln(255 op), and
+// the bounding box of that ellipse has half extents sqrt(r2*cz/det), sqrt(r2*cx/det).
+struct CullBox {
+  float x0, x1, y0, y1;  // inclusive pixel bounds the ellipse can touch
+  bool any;
+};
+__device__ __forceinline__ CullBox make_cullbox(float x, float y, float cx, float cy, float cz, float op) {
+  CullBox c;
+  const float det = cx * cz - cy * cy;
+  const float r2 = 2.0f * __logf(255.0f * op) + 0.02f;  // slack >> fp32 error of `power`
+  c.any = !(r2 < 0.0f);                                  // NaN -> keep
+  float hx = 3.0e38f, hy = 3.0e38f;
+  if (det > 0.0f && r2 >= 0.0f) {
+    const float inv = 1.0f / det;
+    hx = sqrtf(r2 * cz * inv) * 1.001f + 0.01f;
+    hy = sqrtf(r2 * cx * inv) * 1.001f + 0.01f;
+    if (!(hx == hx)) hx = 3.0e38f;
+    if (!(hy == hy)) hy = 3.0e38f;
+  }
+  c.x0 = x - hx;
+  c.x1 = x + hx;
+  c.y0 = y - hy;
+  c.y1 = y + hy;
+  return c;
+}
+__device__ __forceinline__ bool cull_hit(const CullBox& c, float qx0, float qy0) {
+  return c.any && (c.x1 >= qx0) && (c.x0 <= qx0 + 7.0f) && (c.y1 >= qy0) && (c.y0 <= qy0 + 7.0f);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ void __launch_bounds__(64 * CW)
+composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
+                     const uint32_t* __restrict__ point_list, const DgsRow* __restrict__ rows,
+                     const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                     float* __restrict__ out_color, float* __restrict__ out_depth) {
+  __shared__ float4 s_a[CW][64];  // x, y, cx, cy
+  __shared__ float4 s_b[CW][64];  // cz, op, r, g
+  __shared__ float2 s_c[CW][64];  // b, depth
+  TileCtx t;
+  if (!load_tile_ctx(v, ranges, per_xcd, t)) return;
+  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  const int lx = lane & 7, ly = lane >> 3;
+  const int px0 = t.tx * DGS_TILE + lx, py0 = t.ty * DGS_TILE + ly;  // quadrant 0 pixel; +8 for the others
+  const float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
+  const float qx0 = (float)(t.tx * DGS_TILE), qy0 = (float)(t.ty * DGS_TILE);
+
+  float T[4], C0[4], C1[4], C2[4], Dd[4];
+  uint32_t last[4];
+  bool done[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    T[q] = 1.0f;
+    C0[q] = C1[q] = C2[q] = Dd[q] = 0.0f;
+    last[q] = 0;
+    const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
+    done[q] = !(px < v.W && py < v.H);
+  }
+  const DgsRow* krows = rows + (size_t)t.k * v.P;
+  const uint32_t n = t.r1 - t.r0;
+  uint64_t alive[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) alive[q] = __ballot(!done[q]);
+
+  for (uint32_t base = 0; base < n; base += 64) {
+    if ((alive[0] | alive[1] | alive[2] | alive[3]) == 0) break;  // whole tile terminated (forward.cu:325)
+    const bool has = base + lane < n;
+    float4 A = make_float4(0, 0, 0, 0), B = A, Cc = A;
+    if (has) {
+      const uint32_t g = point_list[t.r0 + base + lane];
+      const float4* rp = reinterpret_cast<const float4*>(krows + g);
+      A = rp[0];
+      B = rp[1];
+      Cc = rp[2];
+    }
+    const CullBox cb = make_cullbox(A.x, A.y, A.z, A.w, B.x, B.y);
+    uint64_t m[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const bool hit = has && cull_hit(cb, qx0 + (float)((q & 1) * 8), qy0 + (float)((q >> 1) * 8));
+      const uint64_t bh = __ballot(hit);
+      m[q] = alive[q] ? bh : 0ull;
+    }
+    s_a[w][lane] = A;
+    s_b[w][lane] = B;
+    s_c[w][lane] = make_float2(Cc.x, Cc.y);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    uint64_t mu = m[0] | m[1] | m[2] | m[3];
+    while (mu) {
+      const int j = __builtin_ctzll(mu);
+      mu &= mu - 1;
+      const float4 a = s_a[w][j];
+      const float4 b = s_b[w][j];
+      const float2 c = s_c[w][j];
+      const float dx0 = a.x - pxf0, dx1 = a.x - pxf1, dy0 = a.y - pyf0, dy1 = a.y - pyf1;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if ((m[q] >> j) & 1ull) {
+          if (!done[q]) {
+            const float dx = (q & 1) ? dx1 : dx0;
+            const float dy = (q >> 1) ? dy1 : dy0;
+            // forward.cu:348-368
+            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+            if (power <= 0.0f) {
+              const float alpha = fminf(0.99f, b.y * __expf(power));
+              if (alpha >= 1.0f / 255.0f) {
+                const float test_T = T[q] * (1.0f - alpha);
+                if (test_T < 0.0001f) {
+                  done[q] = true;
+                } else {
+                  const float wgt = alpha * T[q];
+                  C0[q] += b.z * wgt;
+                  C1[q] += b.w * wgt;
+                  C2[q] += c.x * wgt;
+                  Dd[q] += c.y * wgt;
+                  T[q] = test_T;
+                  last[q] = base + (uint32_t)j + 1u;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) alive[q] = __ballot(!done[q]);
+    __builtin_amdgcn_wave_barrier();  // LDS rows are rewritten by the next batch
+  }
+
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const size_t N = (size_t)v.W * v.H;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
+    if (px < v.W && py < v.H) {
+      const size_t pix = (size_t)py * v.W + px;
+      final_T[(size_t)t.k * N + pix] = T[q];
+      n_contrib[(size_t)t.k * N + pix] = last[q];
+      float* oc = out_color + (size_t)t.k * 3 * N;
+      oc[pix] = C0[q] + T[q] * bg0;
+      oc[N + pix] = C1[q] + T[q] * bg1;
+      oc[2 * N + pix] = C2[q] + T[q] * bg2;
+      out_depth[(size_t)t.k * N + pix] = Dd[q] + T[q] * v.z_far;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- backward
+__global__ void __launch_bounds__(64 * CW)
+composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
+                     const uint32_t* __restrict__ point_list, const DgsRow* __restrict__ rows,
+                     const float* __restrict__ bg, const float* __restrict__ final_T,
+                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                     const float* __restrict__ dL_ddepth, float* __restrict__ contrib) {
+  __shared__ float4 s_a[CW][64];       // x, y, cx, cy
+  __shared__ float4 s_b[CW][64];       // cz, op, r, g
+  __shared__ float2 s_c[CW][64];       // b, depth
+  __shared__ float4 s_acc[CW][64][3];  // per-duplicate gradient rows of the current batch
+  TileCtx t;
+  if (!load_tile_ctx(v, ranges, per_xcd, t)) return;
+  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  const int lx = lane & 7, ly = lane >> 3;
+  const int px0 = t.tx * DGS_TILE + lx, py0 = t.ty * DGS_TILE + ly;
+  const float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
+  const float qx0 = (float)(t.tx * DGS_TILE), qy0 = (float)(t.ty * DGS_TILE);
+  const size_t N = (size_t)v.W * v.H;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const float ddelx_dx = 0.5f * (float)v.W, ddely_dy = 0.5f * (float)v.H;  // backward.cu:535-536
+
+  float T[4], Tfin[4], acc0[4], acc1[4], acc2[4], accd[4], lalpha[4], lc0[4], lc1[4], lc2[4], ldep[4];
+  float g0[4], g1[4], g2[4], gd[4], bgdot[4];
+  uint32_t last[4];
+  uint32_t maxc = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
+    const bool inside = (px < v.W && py < v.H);
+    const size_t pix = (size_t)py * v.W + px;
+    Tfin[q] = inside ? final_T[(size_t)t.k * N + pix] : 0.0f;
+    T[q] = Tfin[q];
+    last[q] = inside ? n_contrib[(size_t)t.k * N + pix] : 0u;
+    const float* gp = dL_dpix + (size_t)t.k * 3 * N;
+    g0[q] = inside ? gp[pix] : 0.0f;
+    g1[q] = inside ? gp[N + pix] : 0.0f;
+    g2[q] = inside ? gp[2 * N + pix] : 0.0f;
+    gd[q] = (inside && dL_ddepth != nullptr) ? dL_ddepth[(size_t)t.k * N + pix] : 0.0f;
+    bgdot[q] = bg0 * g0[q] + bg1 * g1[q] + bg2 * g2[q] + v.z_far * gd[q];  // backward.cu:613-617
+    acc0[q] = acc1[q] = acc2[q] = accd[q] = 0.0f;
+    lalpha[q] = lc0[q] = lc1[q] = lc2[q] = ldep[q] = 0.0f;
+    maxc = max(maxc, last[q]);
+  }
+  // wave-wide max of n_contrib: entries at or beyond it are skipped by every pixel (backward.cu:566-568)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, d, 64));
+  maxc = __builtin_amdgcn_readfirstlane(maxc);
+
+  const DgsRow* krows = rows + (size_t)t.k * v.P;
+  const uint32_t n = t.r1 - t.r0;
+  const uint32_t nbatch = (n + 63) / 64;
+  for (uint32_t bi = nbatch; bi-- > 0;) {
+    const uint32_t base = bi * 64;
+    const bool has = base + lane < n;
+    float4 A = make_float4(0, 0, 0, 0), B = A, Cc = A;
+    uint32_t u = 0;
+    if (has) {
+      const uint32_t g = point_list[t.r0 + base + lane];
+      const float4* rp = reinterpret_cast<const float4*>(krows + g);
+      A = rp[0];
+      B = rp[1];
+      Cc = rp[2];
+      // index of this (tile, Gaussian) duplicate in duplicate order: row-major inside the Gaussian's tile rect
+      int minx, miny, maxx, maxy;
+      dgs_get_rect(A.x, A.y, __float_as_int(Cc.w), v.gx, v.gy, minx, miny, maxx, maxy);
+      u = __float_as_uint(Cc.z) + (uint32_t)((t.ty - miny) * (maxx - minx) + (t.tx - minx));
+    }
+    uint64_t m[4] = {0, 0, 0, 0};
+    if (base < maxc) {
+      const CullBox cb = make_cullbox(A.x, A.y, A.z, A.w, B.x, B.y);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const bool hit = has && (base + lane < maxc) &&
+                         cull_hit(cb, qx0 + (float)((q & 1) * 8), qy0 + (float)((q >> 1) * 8));
+        m[q] = __ballot(hit);
+      }
+      s_a[w][lane] = A;
+      s_b[w][lane] = B;
+      s_c[w][lane] = make_float2(Cc.x, Cc.y);
+    }
+    const float4 z4 = make_float4(0, 0, 0, 0);
+    s_acc[w][lane][0] = z4;
+    s_acc[w][lane][1] = z4;
+    s_acc[w][lane][2] = z4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    uint64_t mu = m[0] | m[1] | m[2] | m[3];
+    while (mu) {
+      const int j = 63 - __builtin_clzll(mu);  // back to front
+      mu &= ~(1ull << j);
+      const float4 a = s_a[w][j];
+      const float4 b = s_b[w][j];
+      const float2 c = s_c[w][j];
+      const uint32_t pos = base + (uint32_t)j;  // 0-based position in the tile list
+      const float dx0 = a.x - pxf0, dx1 = a.x - pxf1, dy0 = a.y - pyf0, dy1 = a.y - pyf1;
+      float s_mx = 0, s_my = 0, s_ca = 0, s_cb = 0, s_cc = 0, s_op = 0, s_r = 0, s_g = 0, s_b_ = 0, s_d = 0;
+      bool touched = false;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if ((m[q] >> j) & 1ull) {
+          if (pos < last[q]) {
+            const float dx = (q & 1) ? dx1 : dx0;
+            const float dy = (q >> 1) ? dy1 : dy0;
+            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+            if (power <= 0.0f) {
+              const float G = __expf(power);
+              const float alpha = fminf(0.99f, b.y * G);
+              if (alpha >= 1.0f / 255.0f) {  // backward.cu:571-637
+                touched = true;
+                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+                T[q] = T[q] * inv1ma;
+                const float dchannel_dcolor = alpha * T[q];
+                float dL_dalpha;
+                acc0[q] = lalpha[q] * lc0[q] + (1.f - lalpha[q]) * acc0[q];
+                lc0[q] = b.z;
+                dL_dalpha = (b.z - acc0[q]) * g0[q];
+                s_r += dchannel_dcolor * g0[q];
+                acc1[q] = lalpha[q] * lc1[q] + (1.f - lalpha[q]) * acc1[q];
+                lc1[q] = b.w;
+                dL_dalpha += (b.w - acc1[q]) * g1[q];
+                s_g += dchannel_dcolor * g1[q];
+                acc2[q] = lalpha[q] * lc2[q] + (1.f - lalpha[q]) * acc2[q];
+                lc2[q] = c.x;
+                dL_dalpha += (c.x - acc2[q]) * g2[q];
+                s_b_ += dchannel_dcolor * g2[q];
+                accd[q] = lalpha[q] * ldep[q] + (1.f - lalpha[q]) * accd[q];
+                ldep[q] = c.y;
+                dL_dalpha += (c.y - accd[q]) * gd[q];
+                s_d += dchannel_dcolor * gd[q];
+                dL_dalpha *= T[q];
+                lalpha[q] = alpha;
+                dL_dalpha += (-Tfin[q] * inv1ma) * bgdot[q];
+                const float dL_dG = b.y * dL_dalpha;
+                const float gdx = G * dx;
+                const float gdy = G * dy;
+                const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                const float dG_ddely = -gdy * b.x - gdx * a.w;
+                s_mx += dL_dG * dG_ddelx * ddelx_dx;
+                s_my += dL_dG * dG_ddely * ddely_dy;
+                s_ca += -0.5f * gdx * dx * dL_dG;
+                s_cb += -0.5f * gdx * dy * dL_dG;
+                s_cc += -0.5f * gdy * dy * dL_dG;
+                s_op += G * dL_dalpha;
+              }
+            }
+          }
+        }
+      }
+      if (__ballot(touched) != 0ull) {
+        s_mx = dgs_wave_sum63(s_mx);
+        s_my = dgs_wave_sum63(s_my);
+        s_ca = dgs_wave_sum63(s_ca);
+        s_cb = dgs_wave_sum63(s_cb);
+        s_cc = dgs_wave_sum63(s_cc);
+        s_op = dgs_wave_sum63(s_op);
+        s_r = dgs_wave_sum63(s_r);
+        s_g = dgs_wave_sum63(s_g);
+        s_b_ = dgs_wave_sum63(s_b_);
+        s_d = dgs_wave_sum63(s_d);
+        if (lane == 63) {
+          s_acc[w][j][0] = make_float4(s_mx, s_my, s_ca, s_cb);
+          s_acc[w][j][1] = make_float4(s_cc, s_op, s_r, s_g);
+          s_acc[w][j][2] = make_float4(s_b_, s_d, 0.0f, 0.0f);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (has) {
+      float4* dst = reinterpret_cast<float4*>(contrib + (size_t)u * DGS_CONTRIB_F);
+      dst[0] = s_acc[w][lane][0];
+      dst[1] = s_acc[w][lane][1];
+      dst[2] = s_acc[w][lane][2];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace
+
+static uint32_t per_xcd_blocks(const DgsView& v) {
+  const uint64_t KT = (uint64_t)v.K * v.T;
+  const uint64_t nblk = (KT + CW - 1) / CW;
+  return (uint32_t)((nblk + 7) / 8);
+}
+
+hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,
+                                    float* out_depth, hipStream_t s) {
+  const uint32_t per = per_xcd_blocks(v);
+  if (per == 0) return hipSuccess;
+  hipLaunchKernelGGL(composite_fwd_kernel, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
+                     c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth);
+  return hipGetLastError();
+}
+
+hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const float* bg, const float* dL_dpix,
+                                    const float* dL_ddepth, float* contrib, hipStream_t s) {
+  const uint32_t per = per_xcd_blocks(v);
+  if (per == 0) return hipSuccess;
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
+                     c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth, contrib);
+  return hipGetLastError();
+}

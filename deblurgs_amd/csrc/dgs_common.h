@@ -1,0 +1,117 @@
+// dgs_common.h -- shared declarations of the gfx950 kernels behind include/dgs_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dgs_hip.h"
+
+#define DGS_TILE 16                 // reference BLOCK_X/BLOCK_Y (config.h:16-17): tile ids must match
+#define DGS_ROW_F 12                // floats per geometry row (48 B)
+#define DGS_CONTRIB_F 12            // floats per backward contribution row (48 B): 10 used
+#define DGS_WAVE 64
+
+// Geometry row: everything the per-tile compositing needs about one (subframe, Gaussian), gathered by one
+// lane with three 16-byte loads.  Replaces the reference's separate means2D / conic_opacity / rgb / depths
+// arrays (rasterizer_impl.h:31-45) whose per-pair global reads (forward.cu:371-373) become LDS reads.
+struct __attribute__((aligned(16))) DgsRow {
+  float x, y;            // pixel-space mean (ndc2Pix)
+  float cx, cy, cz, op;  // conic (a, b, c of the inverse 2-D covariance) and opacity
+  float r, g, b, depth;  // activated colour, view-space depth
+  uint32_t dup_offset;   // first duplicate index of this (k, Gaussian): exclusive scan of tiles_touched
+  int32_t radius;        // ceil(3 sigma_max) in pixels
+};
+static_assert(sizeof(DgsRow) == 4 * DGS_ROW_F, "row must be 48 bytes");
+
+struct DgsCarve {  // resolved device pointers of the three blobs
+  DgsRow* rows;
+  float* cov3D;
+  float* pre_sigmoid;
+  uint32_t* tiles_touched;
+  uint32_t* point_offsets;
+  uint32_t* scan_tmp;
+  uint32_t* num_rendered;
+  float* final_T;
+  uint32_t* n_contrib;
+  uint2* ranges;
+  uint64_t* keys_sorted;
+  uint32_t* point_list;
+  uint64_t* keys_unsorted;
+  uint32_t* vals_unsorted;
+  uint32_t* sort_tmp;
+};
+
+// rasterizer_impl.cu:35-50
+static inline uint32_t dgs_higher_msb(uint32_t n) {
+  uint32_t msb = sizeof(n) * 4;
+  uint32_t step = msb;
+  while (step > 1) {
+    step /= 2;
+    if (n >> msb)
+      msb += step;
+    else
+      msb -= step;
+  }
+  if (n >> msb) msb++;
+  return msb;
+}
+
+// auxiliary.h:46-56.  v_cvt_i32_f32 saturates, like the reference's cvt.rzi.
+__device__ __forceinline__ void dgs_get_rect(float px, float py, int max_radius, int gx, int gy, int& minx,
+                                             int& miny, int& maxx, int& maxy) {
+  minx = min(gx, max(0, (int)((px - max_radius) / DGS_TILE)));
+  miny = min(gy, max(0, (int)((py - max_radius) / DGS_TILE)));
+  maxx = min(gx, max(0, (int)((px + max_radius + DGS_TILE - 1) / DGS_TILE)));
+  maxy = min(gy, max(0, (int)((py + max_radius + DGS_TILE - 1) / DGS_TILE)));
+}
+
+// ---- wave64 helpers -------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dgs_dpp(float v) {
+  // lanes disabled by ROW_MASK (or reading out of range) see 0.0f
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// Sum over the 64 lanes of a wave; the total is valid in lane 63 (DPP butterflies inside each row of 16,
+// then row_bcast15 / row_bcast31 across rows).  6 VALU ops, no LDS.
+__device__ __forceinline__ float dgs_wave_sum63(float v) {
+  v += dgs_dpp<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dgs_dpp<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dgs_dpp<0x141, 0xf>(v);  // row_half_mirror
+  v += dgs_dpp<0x140, 0xf>(v);  // row_mirror
+  v += dgs_dpp<0x142, 0xa>(v);  // row_bcast15 -> rows 1,3
+  v += dgs_dpp<0x143, 0xc>(v);  // row_bcast31 -> rows 2,3
+  return v;
+}
+
+__device__ __forceinline__ int dgs_lane() { return (int)(threadIdx.x & 63); }
+
+// ---- host-side launch entry points (one per .hip file) -----------------------------------------------------
+struct DgsView {  // per-launch scalars shared by the kernels
+  int P, D, M, W, H, K;
+  int gx, gy, T;  // tile grid and tiles per subframe
+  float tanfovx, tanfovy, focal_x, focal_y, scale_modifier, z_far;
+  int use_sigmoid, prefiltered;
+};
+
+hipError_t dgs_launch_preprocess(const DgsProblem& p, const DgsView& v, const DgsCarve& c, int32_t* radii,
+                                 hipStream_t s);
+hipError_t dgs_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+hipError_t dgs_launch_duplicate(const DgsView& v, const DgsCarve& c, hipStream_t s);
+hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s);
+hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, uint32_t* total,
+                           hipStream_t s);
+hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
+                           int end_bit, uint32_t* tmp, int* result_in_alt, hipStream_t s);
+hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,
+                                    float* out_depth, hipStream_t s);
+hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const float* bg, const float* dL_dpix,
+                                    const float* dL_ddepth, float* contrib, hipStream_t s);
+hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const DgsCarve& c, const DgsBackwardIO& io,
+                                   const float* contrib, float* partials, hipStream_t s);
+hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t, float* blur,
+                                float* dsub, float* losses, hipStream_t s);
+
+size_t dgs_scan_tmp_words(uint64_t n);
+size_t dgs_sort_tmp_words(uint64_t n);
+int dgs_sort_num_passes(int end_bit);
+int dgs_geometry_bwd_blocks(int P);

@@ -1,0 +1,458 @@
+// geometry_bwd.hip -- K-fused backward of the per-Gaussian stages
+// (replaces computeCov2DCUDA, backward.cu:145-295, and preprocessCUDA<3> backward, backward.cu:367-460, with
+// computeColorFromSH backward :20-140 and computeCov3D backward :299-362).
+//
+// One thread per Gaussian walks the K subframes:
+//   * sums that (subframe, Gaussian)'s contribution rows written by composite_bwd in duplicate order
+//     (replaces the reference's 10 float atomics per (pixel, Gaussian): deterministic);
+//   * conic -> cov2D -> cov3D / mean gradients, projection and depth terms, SH gradients;
+//   * accumulates dL/d{mean3D, SH, opacity, cov3D} over the K subframes IN REGISTERS and writes them once
+//     (the reference allocates, zero-fills and re-accumulates 220 B/Gaussian per subframe,
+//     rasterize_points.cu:162-174).  cov3D -> scale/rotation is linear in dL_dcov3D, so it runs once on the
+//     K-summed dL_dcov3D instead of K times.
+//   * dL_dviewmatrix / dL_dprojmatrix (reference: 28 same-address float atomics per visible Gaussian,
+//     backward.cu:279-293,432-457) are wave-reduced with DPP, combined per block in LDS in wave order and
+//     written as per-block partials that a second kernel sums in block order: deterministic as well.
+#include "dgs_common.h"
+
+namespace {
+
+__device__ const float SH_C0 = 0.28209479177387814f;
+__device__ const float SH_C1 = 0.4886025119029199f;
+__device__ const float SH_C2[] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                  -1.0925484305920792f, 0.5462742152960396f};
+__device__ const float SH_C3[] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                  0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                  -0.5900435899266435f};
+
+constexpr int GB_THREADS = 256;
+constexpr int NMAT = 24;  // 12 view entries + 8 proj entries + 1 shared last-column value (+3 pad)
+
+struct M3 {  // column-major like glm::mat3
+  float m[3][3];
+};
+__device__ __forceinline__ M3 mul(const M3& A, const M3& B) {
+  M3 R;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) R.m[c][r] = A.m[0][r] * B.m[c][0] + A.m[1][r] * B.m[c][1] + A.m[2][r] * B.m[c][2];
+  return R;
+}
+__device__ __forceinline__ M3 tr(const M3& A) {
+  M3 R;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) R.m[c][r] = A.m[r][c];
+  return R;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int MAXC>  // MAXC = SH coefficients held in registers: 1, 4, 9 or 16
+__global__ void __launch_bounds__(GB_THREADS)
+geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* __restrict__ shs,
+                    const float* __restrict__ scales, const float* __restrict__ rotations,
+                    const float* __restrict__ cov3D_precomp, const float* __restrict__ viewm,
+                    const float* __restrict__ projm, const float* __restrict__ campos,
+                    const DgsRow* __restrict__ rows, const float* __restrict__ cov3Ds,
+                    const float* __restrict__ pre_sigmoid, const uint32_t* __restrict__ tiles_touched,
+                    const float* __restrict__ contrib, float* __restrict__ dL_dmeans3D,
+                    float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors,
+                    float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales, float* __restrict__ dL_drots,
+                    float* __restrict__ dL_dcov3D_out, float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float s_part[];  // [waves][K][NMAT]
+  const int idx = blockIdx.x * GB_THREADS + threadIdx.x;
+  const bool valid = idx < v.P;
+  const int gi = valid ? idx : 0;
+  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  const float mx = means3D[3 * gi], my = means3D[3 * gi + 1], mz = means3D[3 * gi + 2];
+  const float* c3p = (cov3D_precomp != nullptr ? cov3D_precomp : cov3Ds) + 6 * (size_t)gi;
+  float c3[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) c3[i] = c3p[i];
+  const float h_x = v.focal_x, h_y = v.focal_y;
+  const int ncoef = (v.D + 1) * (v.D + 1);
+
+  float a_mean[3] = {0, 0, 0};
+  float a_cov[6] = {0, 0, 0, 0, 0, 0};
+  float a_col[3] = {0, 0, 0};
+  float a_op = 0;
+  float a_sh[MAXC * 3];
+#pragma unroll
+  for (int i = 0; i < MAXC * 3; i++) a_sh[i] = 0.0f;
+
+  for (int k = 0; k < v.K; k++) {
+    const float* V = viewm + 16 * k;
+    const float* F = projm + 16 * k;
+    const size_t o = (size_t)k * v.P + gi;
+    float mat[NMAT];
+#pragma unroll
+    for (int i = 0; i < NMAT; i++) mat[i] = 0.0f;
+    float g2x = 0.0f, g2y = 0.0f;
+    const uint32_t ntiles = valid ? tiles_touched[o] : 0u;
+    if (ntiles > 0) {
+      // ---- sum this (subframe, Gaussian)'s duplicate rows in duplicate order
+      const uint32_t off = rows[o].dup_offset;
+      float s[10];
+#pragma unroll
+      for (int i = 0; i < 10; i++) s[i] = 0.0f;
+      const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)off * DGS_CONTRIB_F);
+      for (uint32_t i = 0; i < ntiles; i++) {
+        const float4 r0 = cp[3 * i], r1 = cp[3 * i + 1], r2 = cp[3 * i + 2];
+        s[0] += r0.x; s[1] += r0.y; s[2] += r0.z; s[3] += r0.w;
+        s[4] += r1.x; s[5] += r1.y; s[6] += r1.z; s[7] += r1.w;
+        s[8] += r2.x; s[9] += r2.y;
+      }
+      g2x = s[0];
+      g2y = s[1];
+      const float dcon_x = s[2], dcon_y = s[3], dcon_w = s[4];
+      a_op += s[5];
+      const float dcol[3] = {s[6], s[7], s[8]};
+      const float ddepth = s[9];
+
+      // ---- computeCov2DCUDA (backward.cu:145-295)
+      float tx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+      float ty = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+      const float tz_ = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+      const float limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
+      const float txtz = tx / tz_, tytz = ty / tz_;
+      tx = fminf(limx, fmaxf(-limx, txtz)) * tz_;
+      ty = fminf(limy, fmaxf(-limy, tytz)) * tz_;
+      const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+      const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+      M3 J = {{{h_x / tz_, 0.0f, -(h_x * tx) / (tz_ * tz_)}, {0.0f, h_y / tz_, -(h_y * ty) / (tz_ * tz_)}, {0, 0, 0}}};
+      M3 Wm = {{{V[0], V[4], V[8]}, {V[1], V[5], V[9]}, {V[2], V[6], V[10]}}};
+      M3 Vrk = {{{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}}};
+      M3 T = mul(Wm, J);
+      M3 cov2D = mul(mul(tr(T), tr(Vrk)), T);
+      const float a = cov2D.m[0][0] + 0.3f;
+      const float b = cov2D.m[0][1];
+      const float c = cov2D.m[1][1] + 0.3f;
+      const float denom = a * c - b * b;
+      float dL_da = 0, dL_db = 0, dL_dc = 0;
+      const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+      if (denom2inv != 0) {
+        dL_da = denom2inv * (-c * c * dcon_x + 2 * b * c * dcon_y + (denom - a * c) * dcon_w);
+        dL_dc = denom2inv * (-a * a * dcon_w + 2 * a * b * dcon_y + (denom - a * c) * dcon_x);
+        dL_db = denom2inv * 2 * (b * c * dcon_x - (denom + 2 * b * b) * dcon_y + a * b * dcon_w);
+        a_cov[0] += (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
+        a_cov[3] += (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
+        a_cov[5] += (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
+        a_cov[1] += 2 * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db +
+                    2 * T.m[1][0] * T.m[1][1] * dL_dc;
+        a_cov[2] += 2 * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db +
+                    2 * T.m[1][0] * T.m[1][2] * dL_dc;
+        a_cov[4] += 2 * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db +
+                    2 * T.m[1][1] * T.m[1][2] * dL_dc;
+      }
+      const float dL_dT00 = 2 * (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_da +
+                            (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_db;
+      const float dL_dT01 = 2 * (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_da +
+                            (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_db;
+      const float dL_dT02 = 2 * (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_da +
+                            (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_db;
+      const float dL_dT10 = 2 * (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_dc +
+                            (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_db;
+      const float dL_dT11 = 2 * (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_dc +
+                            (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_db;
+      const float dL_dT12 = 2 * (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_dc +
+                            (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_db;
+      const float dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
+      const float dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
+      const float dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
+      const float dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
+      const float tz = 1.f / tz_;
+      const float tz2 = tz * tz;
+      const float tz3 = tz2 * tz;
+      const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+      const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+      const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * tx) * tz3 * dL_dJ02 +
+                           (2 * h_y * ty) * tz3 * dL_dJ12;
+      // transformVec4x3Transpose (auxiliary.h:90-98)
+      float dmean_x = V[0] * dL_dtx + V[1] * dL_dty + V[2] * dL_dtz;
+      float dmean_y = V[4] * dL_dtx + V[5] * dL_dty + V[6] * dL_dtz;
+      float dmean_z = V[8] * dL_dtx + V[9] * dL_dty + V[10] * dL_dtz;
+      // view-matrix gradient through t = view * mean only (backward.cu:277-294) ...
+      mat[0] = dL_dtx * mx;  mat[1] = dL_dty * mx;  mat[2] = dL_dtz * mx;
+      mat[3] = dL_dtx * my;  mat[4] = dL_dty * my;  mat[5] = dL_dtz * my;
+      mat[6] = dL_dtx * mz;  mat[7] = dL_dty * mz;  mat[8] = dL_dtz * mz;
+      mat[9] = dL_dtx;       mat[10] = dL_dty;      mat[11] = dL_dtz;
+      // ... and through depth (backward.cu:454-457): view[2], [6], [10], [14]
+      mat[2] += ddepth * mx;
+      mat[5] += ddepth * my;
+      mat[8] += ddepth * mz;
+      mat[11] += ddepth;
+
+      // ---- preprocessCUDA backward (backward.cu:367-460)
+      const float mhx = F[0] * mx + F[4] * my + F[8] * mz + F[12];
+      const float mhy = F[1] * mx + F[5] * my + F[9] * mz + F[13];
+      const float mhw = F[3] * mx + F[7] * my + F[11] * mz + F[15];
+      const float m_w = 1.0f / (mhw + 0.0000001f);
+      const float mul1 = mhx * m_w * m_w;
+      const float mul2 = mhy * m_w * m_w;
+      dmean_x += (F[0] * m_w - F[3] * mul1) * g2x + (F[1] * m_w - F[3] * mul2) * g2y + ddepth * V[2];
+      dmean_y += (F[4] * m_w - F[7] * mul1) * g2x + (F[5] * m_w - F[7] * mul2) * g2y + ddepth * V[6];
+      dmean_z += (F[8] * m_w - F[11] * mul1) * g2x + (F[9] * m_w - F[11] * mul2) * g2y + ddepth * V[10];
+
+      if (shs != nullptr) {  // computeColorFromSH backward (backward.cu:20-140)
+        const float* cam = campos + 3 * k;
+        const float dox = mx - cam[0], doy = my - cam[1], doz = mz - cam[2];
+        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
+        const float x = dox / len, y = doy / len, z = doz / len;
+        const float* sh = shs + (size_t)gi * v.M * 3;
+        float dRGB[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+          const float ps = pre_sigmoid[3 * o + ch];
+          float f = ps;
+          if (v.use_sigmoid) {
+            const float sg = sigmoidf_(ps);
+            f = sg * (1.0f - sg);
+          }
+          dRGB[ch] = dcol[ch] * f;
+        }
+        float ddir[3] = {0, 0, 0};  // dL/ddir = sum_ch dRGBd{x,y,z}[ch] * dRGB[ch]
+        float cf[MAXC];             // dRGB/dsh_j (same for the three channels)
+        cf[0] = SH_C0;
+        if (MAXC > 1 && ncoef > 1) {
+          cf[1] = -SH_C1 * y;
+          cf[2] = SH_C1 * z;
+          cf[3] = -SH_C1 * x;
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) {
+            ddir[0] += (-SH_C1 * sh[9 + ch]) * dRGB[ch];
+            ddir[1] += (-SH_C1 * sh[3 + ch]) * dRGB[ch];
+            ddir[2] += (SH_C1 * sh[6 + ch]) * dRGB[ch];
+          }
+        }
+        if (MAXC > 4 && ncoef > 4) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          cf[4] = SH_C2[0] * xy;
+          cf[5] = SH_C2[1] * yz;
+          cf[6] = SH_C2[2] * (2.f * zz - xx - yy);
+          cf[7] = SH_C2[3] * xz;
+          cf[8] = SH_C2[4] * (xx - yy);
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) {
+            const float s4 = sh[12 + ch], s5 = sh[15 + ch], s6 = sh[18 + ch], s7 = sh[21 + ch], s8 = sh[24 + ch];
+            ddir[0] += (SH_C2[0] * y * s4 + SH_C2[2] * 2.f * -x * s6 + SH_C2[3] * z * s7 + SH_C2[4] * 2.f * x * s8) *
+                       dRGB[ch];
+            ddir[1] += (SH_C2[0] * x * s4 + SH_C2[1] * z * s5 + SH_C2[2] * 2.f * -y * s6 + SH_C2[4] * 2.f * -y * s8) *
+                       dRGB[ch];
+            ddir[2] += (SH_C2[1] * y * s5 + SH_C2[2] * 2.f * 2.f * z * s6 + SH_C2[3] * x * s7) * dRGB[ch];
+          }
+          if (MAXC > 9 && ncoef > 9) {
+            cf[9] = SH_C3[0] * y * (3.f * xx - yy);
+            cf[10] = SH_C3[1] * xy * z;
+            cf[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+            cf[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            cf[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+            cf[14] = SH_C3[5] * z * (xx - yy);
+            cf[15] = SH_C3[6] * x * (xx - 3.f * yy);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+              const float s9 = sh[27 + ch], s10 = sh[30 + ch], s11 = sh[33 + ch], s12 = sh[36 + ch],
+                          s13 = sh[39 + ch], s14 = sh[42 + ch], s15 = sh[45 + ch];
+              ddir[0] += (SH_C3[0] * s9 * 3.f * 2.f * xy + SH_C3[1] * s10 * yz + SH_C3[2] * s11 * -2.f * xy +
+                          SH_C3[3] * s12 * -3.f * 2.f * xz + SH_C3[4] * s13 * (-3.f * xx + 4.f * zz - yy) +
+                          SH_C3[5] * s14 * 2.f * xz + SH_C3[6] * s15 * 3.f * (xx - yy)) * dRGB[ch];
+              ddir[1] += (SH_C3[0] * s9 * 3.f * (xx - yy) + SH_C3[1] * s10 * xz +
+                          SH_C3[2] * s11 * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * s12 * -3.f * 2.f * yz +
+                          SH_C3[4] * s13 * -2.f * xy + SH_C3[5] * s14 * -2.f * yz +
+                          SH_C3[6] * s15 * -3.f * 2.f * xy) * dRGB[ch];
+              ddir[2] += (SH_C3[1] * s10 * xy + SH_C3[2] * s11 * 4.f * 2.f * yz +
+                          SH_C3[3] * s12 * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * s13 * 4.f * 2.f * xz +
+                          SH_C3[5] * s14 * (xx - yy)) * dRGB[ch];
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXC; j++)
+          if (j < ncoef) {
+            a_sh[3 * j + 0] += cf[j] * dRGB[0];
+            a_sh[3 * j + 1] += cf[j] * dRGB[1];
+            a_sh[3 * j + 2] += cf[j] * dRGB[2];
+          }
+        // dnormvdv (auxiliary.h:107-117)
+        const float sum2 = dox * dox + doy * doy + doz * doz;
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        dmean_x += ((+sum2 - dox * dox) * ddir[0] - doy * dox * ddir[1] - doz * dox * ddir[2]) * invsum32;
+        dmean_y += (-dox * doy * ddir[0] + (sum2 - doy * doy) * ddir[1] - doz * doy * ddir[2]) * invsum32;
+        dmean_z += (-dox * doz * ddir[0] - doy * doz * ddir[1] + (sum2 - doz * doz) * ddir[2]) * invsum32;
+      }
+      a_col[0] += dcol[0];
+      a_col[1] += dcol[1];
+      a_col[2] += dcol[2];
+      a_mean[0] += dmean_x;
+      a_mean[1] += dmean_y;
+      a_mean[2] += dmean_z;
+
+      // projection-matrix gradient exactly as the reference computes it (backward.cu:423-450): double
+      // arithmetic rounded to float per contribution; entries 3, 7, 11, 15 all receive -0.5*lastcol.
+      const float lastcol = (mhx * v.W * g2x + mhy * v.H * g2y) * m_w * m_w;
+      mat[12] = (float)(0.5 * g2x * mx * v.W * m_w);
+      mat[13] = (float)(0.5 * g2y * mx * v.H * m_w);
+      mat[14] = (float)(0.5 * g2x * my * v.W * m_w);
+      mat[15] = (float)(0.5 * g2y * my * v.H * m_w);
+      mat[16] = (float)(0.5 * g2x * mz * v.W * m_w);
+      mat[17] = (float)(0.5 * g2y * mz * v.H * m_w);
+      mat[18] = (float)(0.5 * g2x * v.W * m_w);
+      mat[19] = (float)(0.5 * g2y * v.H * m_w);
+      mat[20] = (float)(-0.5 * lastcol);
+    }
+    if (valid) {
+      float* d2 = dL_dmeans2D + 3 * o;
+      d2[0] = g2x;
+      d2[1] = g2y;
+      d2[2] = 0.0f;
+    }
+    // ---- per-subframe pose gradients: wave sum (skipped when no lane of the wave is visible in k)
+    if (__ballot(ntiles > 0) != 0ull) {
+#pragma unroll
+      for (int i = 0; i < 21; i++) mat[i] = dgs_wave_sum63(mat[i]);
+    }
+    if (lane == 63) {
+      float* sp = s_part + ((size_t)w * v.K + k) * NMAT;
+#pragma unroll
+      for (int i = 0; i < 21; i++) sp[i] = mat[i];
+    }
+  }
+
+  if (valid) {
+    dL_dmeans3D[3 * idx + 0] = a_mean[0];
+    dL_dmeans3D[3 * idx + 1] = a_mean[1];
+    dL_dmeans3D[3 * idx + 2] = a_mean[2];
+    dL_dopacity[idx] = a_op;
+    dL_dcolors[3 * idx + 0] = a_col[0];
+    dL_dcolors[3 * idx + 1] = a_col[1];
+    dL_dcolors[3 * idx + 2] = a_col[2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) dL_dcov3D_out[6 * (size_t)idx + i] = a_cov[i];
+    if (dL_dsh != nullptr) {
+      float* dsh = dL_dsh + (size_t)idx * v.M * 3;
+#pragma unroll
+      for (int jj = 0; jj < MAXC; jj++)
+        if (jj < v.M) {
+          dsh[3 * jj] = a_sh[3 * jj];
+          dsh[3 * jj + 1] = a_sh[3 * jj + 1];
+          dsh[3 * jj + 2] = a_sh[3 * jj + 2];
+        }
+      for (int j = MAXC; j < v.M; j++) {  // coefficients above the active degree get zero gradient
+        dsh[3 * j] = 0.0f;
+        dsh[3 * j + 1] = 0.0f;
+        dsh[3 * j + 2] = 0.0f;
+      }
+    }
+    if (scales != nullptr) {  // computeCov3D backward (backward.cu:299-362) on the K-summed dL_dcov3D
+      const float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2],
+                  z = rotations[4 * idx + 3];
+      M3 R = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+               {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+               {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
+      const float sx = v.scale_modifier * scales[3 * idx], sy = v.scale_modifier * scales[3 * idx + 1],
+                  sz = v.scale_modifier * scales[3 * idx + 2];
+      M3 S = {{{sx, 0, 0}, {0, sy, 0}, {0, 0, sz}}};
+      M3 Mm = mul(S, R);
+      M3 dSig = {{{a_cov[0], 0.5f * a_cov[1], 0.5f * a_cov[2]},
+                  {0.5f * a_cov[1], a_cov[3], 0.5f * a_cov[4]},
+                  {0.5f * a_cov[2], 0.5f * a_cov[4], a_cov[5]}}};
+      M3 M2;
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) M2.m[c][rr] = Mm.m[c][rr] * 2.0f;
+      M3 dL_dM = mul(M2, dSig);
+      M3 Rt = tr(R);
+      M3 dMt = tr(dL_dM);
+      dL_dscales[3 * idx + 0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
+      dL_dscales[3 * idx + 1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
+      dL_dscales[3 * idx + 2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++) {
+        dMt.m[0][rr] *= sx;
+        dMt.m[1][rr] *= sy;
+        dMt.m[2][rr] *= sz;
+      }
+      float4 dq;
+      dq.x = 2 * z * (dMt.m[0][1] - dMt.m[1][0]) + 2 * y * (dMt.m[2][0] - dMt.m[0][2]) +
+             2 * x * (dMt.m[1][2] - dMt.m[2][1]);
+      dq.y = 2 * y * (dMt.m[1][0] + dMt.m[0][1]) + 2 * z * (dMt.m[2][0] + dMt.m[0][2]) +
+             2 * r * (dMt.m[1][2] - dMt.m[2][1]) - 4 * x * (dMt.m[2][2] + dMt.m[1][1]);
+      dq.z = 2 * x * (dMt.m[1][0] + dMt.m[0][1]) + 2 * r * (dMt.m[2][0] - dMt.m[0][2]) +
+             2 * z * (dMt.m[1][2] + dMt.m[2][1]) - 4 * y * (dMt.m[2][2] + dMt.m[0][0]);
+      dq.w = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) +
+             2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
+      reinterpret_cast<float4*>(dL_drots)[idx] = dq;
+    }
+  }
+
+  // ---- combine the 4 waves in wave order and publish this block's partial pose gradients
+  __syncthreads();
+  const int total = v.K * NMAT;
+  for (int i = threadIdx.x; i < total; i += GB_THREADS) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int ww = 0; ww < GB_THREADS / 64; ww++) acc += s_part[(size_t)ww * total + i];
+    partials[(size_t)blockIdx.x * total + i] = acc;
+  }
+}
+
+// Sums the per-block partials in block order and scatters them into the two [K,4,4] outputs.
+__global__ void __launch_bounds__(64)
+pose_grad_reduce_kernel(int K, int nblocks, const float* __restrict__ partials, float* __restrict__ dL_dview,
+                        float* __restrict__ dL_dproj) {
+  const int k = blockIdx.x;
+  const int i = threadIdx.x;
+  if (i >= 32) return;
+  // output slot i: 0..15 view entry i, 16..31 proj entry i-16
+  int src = -1;
+  if (i < 16) {
+    const int r = i >> 2, c = i & 3;
+    if (c < 3) src = r * 3 + c;  // view[4r+c] <- mat[3r+c]
+  } else {
+    const int e = i - 16, r = e >> 2, c = e & 3;
+    if (c < 2) src = 12 + r * 2 + c;  // proj[4r+c], c in {0,1}
+    if (c == 3) src = 20;             // proj[3], [7], [11], [15]
+  }
+  float acc = 0.0f;
+  if (src >= 0) {
+    const size_t stride = (size_t)K * NMAT;
+    const float* p = partials + (size_t)k * NMAT + src;
+    for (int b = 0; b < nblocks; b++) acc += p[(size_t)b * stride];
+  }
+  if (i < 16)
+    dL_dview[16 * k + i] = acc;
+  else
+    dL_dproj[16 * k + (i - 16)] = acc;
+}
+
+}  // namespace
+
+int dgs_geometry_bwd_blocks(int P) { return (P + GB_THREADS - 1) / GB_THREADS; }
+
+hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const DgsCarve& c, const DgsBackwardIO& io,
+                                   const float* contrib, float* partials, hipStream_t s) {
+  const int blocks = dgs_geometry_bwd_blocks(v.P);
+  const size_t lds = (size_t)(GB_THREADS / 64) * v.K * NMAT * sizeof(float);
+  const int ncoef = (p.shs != nullptr) ? (v.D + 1) * (v.D + 1) : 1;
+#define DGS_GB_LAUNCH(MAXC)                                                                                          \
+  hipLaunchKernelGGL(geometry_bwd_kernel<MAXC>, dim3(blocks), dim3(GB_THREADS), lds, s, v, p.means3D, p.shs,         \
+                     p.scales, p.rotations, p.cov3D_precomp, p.viewmatrix, p.projmatrix, p.campos, c.rows, c.cov3D,  \
+                     c.pre_sigmoid, c.tiles_touched, contrib, io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh,             \
+                     io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations, io.dL_dcov3D, partials)
+  if (ncoef <= 1)
+    DGS_GB_LAUNCH(1);
+  else if (ncoef <= 4)
+    DGS_GB_LAUNCH(4);
+  else if (ncoef <= 9)
+    DGS_GB_LAUNCH(9);
+  else
+    DGS_GB_LAUNCH(16);
+#undef DGS_GB_LAUNCH
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(pose_grad_reduce_kernel, dim3(v.K), dim3(64), 0, s, v.K, blocks, partials, io.dL_dviewmatrix,
+                     io.dL_dprojmatrix);
+  return hipGetLastError();
+}

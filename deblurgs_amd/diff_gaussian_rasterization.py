@@ -1,0 +1,408 @@
+"""Operator surface of the rasteriser -- same names, argument order, return arity, dtypes and error behaviour
+as the reference's /root/reference/submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py
+(GaussianRasterizationSettings :172-187, GaussianRasterizer :189-241, rasterize_gaussians :21-46,
+_RasterizeGaussians :48-170), backed by libdgs_hip.so through ctypes instead of the pybind `_C` module.
+
+Additions for the blur-integration loop: `_RasterizeGaussiansK` / `rasterize_gaussians_subframes` /
+`GaussianRasterizer.forward_subframes` rasterise all K subframe poses of one blurry view in ONE fused launch
+chain (the reference calls the K=1 operator K times from scene/motion.py:141-143).
+"""
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    z_near: float
+    z_far: float
+    use_sigmoid: bool
+    sh_degree: int
+    campos: torch.Tensor      # [3]; [K,3] for the fused K-subframe operator
+    prefiltered: bool
+    debug: bool
+
+
+# ---------------------------------------------------------------------------------------------- plumbing
+_pinned = {}
+
+
+def _pinned_word(device):
+    key = (device.type, device.index)
+    if key not in _pinned:
+        _pinned[key] = torch.zeros(4, dtype=torch.int32).pin_memory()
+    return _pinned[key]
+
+
+def _opt(t):
+    """The reference passes torch.Tensor([]) for an absent input; map absent/empty to None."""
+    if t is None or t.numel() == 0:
+        return None
+    return t
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _State:
+    """What backward needs (the reference's geomBuffer / binningBuffer / imgBuffer + num_rendered)."""
+    __slots__ = ("R", "K", "P", "M", "W", "H")
+
+
+def _make_problem(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm, campos,
+                  rs, geom, image, binning):
+    p = _lib.DgsProblem()
+    p.P = means3D.shape[0]
+    p.D = int(rs.sh_degree)
+    p.M = 0 if sh is None else sh.shape[1]
+    p.W = int(rs.image_width)
+    p.H = int(rs.image_height)
+    p.K = K
+    p.tanfovx = float(rs.tanfovx)
+    p.tanfovy = float(rs.tanfovy)
+    p.scale_modifier = float(rs.scale_modifier)
+    p.z_near = float(rs.z_near)
+    p.z_far = float(rs.z_far)
+    p.use_sigmoid = int(bool(rs.use_sigmoid))
+    p.prefiltered = int(bool(rs.prefiltered))
+    p.debug = int(bool(rs.debug))
+    p.means3D = _ptr(means3D)
+    p.shs = _ptr(sh)
+    p.colors_precomp = _ptr(colors_precomp)
+    p.opacities = _ptr(opacities)
+    p.scales = _ptr(scales)
+    p.rotations = _ptr(rotations)
+    p.cov3D_precomp = _ptr(cov3D_precomp)
+    p.viewmatrix = _ptr(viewm)
+    p.projmatrix = _ptr(projm)
+    p.campos = _ptr(campos)
+    p.bg = _ptr(rs._bg_c)
+    p.geom_state = _ptr(geom)
+    p.geom_bytes = 0 if geom is None else geom.numel()
+    p.image_state = _ptr(image)
+    p.image_bytes = 0 if image is None else image.numel()
+    p.binning_state = _ptr(binning)
+    p.binning_bytes = 0 if binning is None else binning.numel()
+    return p
+
+
+class _RS:
+    """Settings with contiguous fp32 device copies of bg (kept alive for the call)."""
+
+    def __init__(self, rs, device):
+        self.__dict__.update(rs._asdict())
+        self._bg_c = _f32c(rs.bg.to(device))
+
+
+def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm, campos,
+                  raster_settings):
+    L = _lib.lib()
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:60-62
+    device = means3D.device
+    if device.type != "cuda":
+        raise RuntimeError("deblurgs_amd rasteriser needs CUDA/HIP tensors (no CPU fallback)")
+    rs = _RS(raster_settings, device)
+    P, H, W = means3D.shape[0], int(rs.image_height), int(rs.image_width)
+    color = torch.empty((K, 3, H, W), dtype=torch.float32, device=device)
+    depth = torch.empty((K, 1, H, W), dtype=torch.float32, device=device)
+    radii = torch.empty((K, P), dtype=torch.int32, device=device)
+    geom = torch.empty(L.dgs_geom_state_bytes(P, K), dtype=torch.uint8, device=device)
+    image = torch.empty(L.dgs_image_state_bytes(W, H, K), dtype=torch.uint8, device=device)
+    host_R = _pinned_word(device)
+    out = _lib.DgsForwardOut()
+    out.out_color = _ptr(color)
+    out.out_depth = _ptr(depth)
+    out.radii = _ptr(radii)
+    out.num_rendered_host = ctypes.c_void_p(host_R.data_ptr())
+    stream = _stream(device)
+    prob = _make_problem(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm,
+                         campos, rs, geom, image, None)
+    _lib.check(L.dgs_forward_geometry(ctypes.byref(prob), ctypes.byref(out), stream), "dgs_forward_geometry")
+    torch.cuda.current_stream(device).synchronize()   # the one host read of num_rendered (rasterizer_impl.cu:287)
+    R = int(host_R[0].item()) & 0xFFFFFFFF
+    binning = torch.empty(L.dgs_binning_state_bytes(R, W, H, K), dtype=torch.uint8, device=device)
+    prob.binning_state = _ptr(binning)
+    prob.binning_bytes = binning.numel()
+    _lib.check(L.dgs_forward_render(ctypes.byref(prob), ctypes.byref(out), R, stream), "dgs_forward_render")
+    return R, color, depth, radii, geom, binning, image
+
+
+def _backward_impl(K, R, means3D, sh, colors_precomp, opacities_shape, scales, rotations, cov3D_precomp, viewm, projm,
+                   campos, raster_settings, radii, geom, binning, image, grad_color, grad_depth):
+    L = _lib.lib()
+    device = means3D.device
+    rs = _RS(raster_settings, device)
+    P = means3D.shape[0]
+    M = 0 if sh is None else sh.shape[1]
+    f = dict(dtype=torch.float32, device=device)
+    g_means3D = torch.empty((P, 3), **f)
+    g_means2D = torch.empty((K, P, 3), **f)
+    g_sh = torch.empty((P, M, 3), **f) if sh is not None else None
+    g_colors = torch.empty((P, 3), **f)
+    g_opacity = torch.empty((P, 1), **f)
+    g_scales = torch.empty((P, 3), **f) if scales is not None else None
+    g_rots = torch.empty((P, 4), **f) if rotations is not None else None
+    g_cov3D = torch.empty((P, 6), **f)
+    g_view = torch.empty((K, 4, 4), **f)
+    g_proj = torch.empty((K, 4, 4), **f)
+    scratch = torch.empty(L.dgs_backward_scratch_bytes(R, P, K), dtype=torch.uint8, device=device)
+    io = _lib.DgsBackwardIO()
+    io.num_rendered = R
+    io.radii = _ptr(radii)
+    io.dL_dout_color = _ptr(grad_color)
+    io.dL_dout_depth = _ptr(grad_depth)
+    io.scratch = _ptr(scratch)
+    io.scratch_bytes = scratch.numel()
+    io.dL_dmeans3D = _ptr(g_means3D)
+    io.dL_dmeans2D = _ptr(g_means2D)
+    io.dL_dsh = _ptr(g_sh)
+    io.dL_dcolors = _ptr(g_colors)
+    io.dL_dopacity = _ptr(g_opacity)
+    io.dL_dscales = _ptr(g_scales)
+    io.dL_drotations = _ptr(g_rots)
+    io.dL_dcov3D = _ptr(g_cov3D)
+    io.dL_dviewmatrix = _ptr(g_view)
+    io.dL_dprojmatrix = _ptr(g_proj)
+    prob = _make_problem(K, means3D, sh, colors_precomp, None, scales, rotations, cov3D_precomp, viewm, projm, campos,
+                         rs, geom, image, binning)
+    prob.opacities = _ptr(means3D)   # not read by the backward; must be non-null for the argument check
+    _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), _stream(device)), "dgs_backward")
+    if P == 0:
+        for t in (g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D):
+            if t is not None:
+                t.zero_()
+    return g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rots, g_view, g_proj
+
+
+def _prep(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+    return (_f32c(means3D), _f32c(_opt(sh)), _f32c(_opt(colors_precomp)), _f32c(opacities), _f32c(_opt(scales)),
+            _f32c(_opt(rotations)), _f32c(_opt(cov3Ds_precomp)))
+
+
+# ------------------------------------------------------------------------------------- K = 1 (reference API)
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        viewmatrix, projmatrix, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, viewmatrix, projmatrix, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
+                projmatrix, raster_settings):
+        m3, shc, colc, opc, scc, rotc, covc = _prep(means3D, sh, colors_precomp, opacities, scales, rotations,
+                                                    cov3Ds_precomp)
+        viewm = _f32c(viewmatrix).reshape(1, 4, 4)
+        projm = _f32c(projmatrix).reshape(1, 4, 4)
+        campos = _f32c(raster_settings.campos.to(m3.device)).reshape(1, 3)
+        args = (m3, shc, colc, opc, scc, rotc, covc, viewm, projm, campos, raster_settings)
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args[:-1])  # copy them before they can be corrupted
+            try:
+                num_rendered, color, depth, radii, geom, binning, img = _forward_impl(1, *args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            num_rendered, color, depth, radii, geom, binning, img = _forward_impl(1, *args)
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.opacities_shape = opacities.shape
+        ctx.absent = (shc is None, colc is None, scc is None, rotc is None, covc is None)
+        dummy = m3.new_empty(0)
+        ctx.save_for_backward(*(dummy if t is None else t for t in (colc, m3, scc, rotc, covc, radii, shc, geom,
+                                                                    binning, img, viewm, projm, campos)))
+        ctx.set_materialize_grads(False)
+        color, depth, radii = color[0], depth[0], radii[0]
+        ctx.mark_non_differentiable(radii)
+        return color, depth, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_out_depth, _):
+        rs = ctx.raster_settings
+        colc, m3, scc, rotc, covc, radii, shc, geom, binning, img, viewm, projm, campos = (
+            None if t.numel() == 0 and i != 1 else t for i, t in enumerate(ctx.saved_tensors))
+        if grad_out_color is None and grad_out_depth is None:
+            return (None,) * 11
+        H, W = int(rs.image_height), int(rs.image_width)
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, H, W), dtype=torch.float32, device=m3.device)
+        gc = _f32c(grad_out_color)
+        gd = _f32c(grad_out_depth)
+        args = (1, ctx.num_rendered, m3, shc, colc, ctx.opacities_shape, scc, rotc, covc, viewm, projm, campos, rs,
+                radii, geom, binning, img, gc, gd)
+        if rs.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                grads = _backward_impl(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            grads = _backward_impl(*args)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations, grad_viewmatrix, grad_projmatrix) = grads
+        return (
+            grad_means3D,
+            grad_means2D[0],
+            grad_sh,
+            grad_colors_precomp if colc is not None else None,
+            grad_opacities.reshape(ctx.opacities_shape),
+            grad_scales,
+            grad_rotations,
+            grad_cov3Ds_precomp if covc is not None else None,
+            grad_viewmatrix[0],
+            grad_projmatrix[0],
+            None,
+        )
+
+
+# ------------------------------------------------------------------------------ K subframes, one fused launch
+def rasterize_gaussians_subframes(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                  viewmatrices, projmatrices, raster_settings):
+    return _RasterizeGaussiansK.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                      cov3Ds_precomp, viewmatrices, projmatrices, raster_settings)
+
+
+class _RasterizeGaussiansK(torch.autograd.Function):
+    """All K subframes of one blurry view: viewmatrices/projmatrices [K,4,4], raster_settings.campos [K,3],
+    means2D [K,P,3] (its .grad carries the per-subframe screen-space gradients that densification reads,
+    train.py:188-193).  Returns color [K,3,H,W], depth [K,1,H,W], radii [K,P]."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                viewmatrices, projmatrices, raster_settings):
+        m3, shc, colc, opc, scc, rotc, covc = _prep(means3D, sh, colors_precomp, opacities, scales, rotations,
+                                                    cov3Ds_precomp)
+        viewm = _f32c(viewmatrices)
+        projm = _f32c(projmatrices)
+        K = viewm.shape[0]
+        if viewm.shape != (K, 4, 4) or projm.shape != (K, 4, 4):
+            raise RuntimeError("viewmatrices / projmatrices must be [K,4,4]")
+        campos = _f32c(raster_settings.campos.to(m3.device)).reshape(-1, 3)
+        if campos.shape[0] != K:
+            raise RuntimeError("raster_settings.campos must be [K,3] for the K-subframe operator")
+        num_rendered, color, depth, radii, geom, binning, img = _forward_impl(
+            K, m3, shc, colc, opc, scc, rotc, covc, viewm, projm, campos, raster_settings)
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.K = K
+        ctx.opacities_shape = opacities.shape
+        dummy = m3.new_empty(0)
+        ctx.save_for_backward(*(dummy if t is None else t for t in (colc, m3, scc, rotc, covc, radii, shc, geom,
+                                                                    binning, img, viewm, projm, campos)))
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        return color, depth, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_out_depth, _):
+        rs = ctx.raster_settings
+        K = ctx.K
+        colc, m3, scc, rotc, covc, radii, shc, geom, binning, img, viewm, projm, campos = (
+            None if t.numel() == 0 and i != 1 else t for i, t in enumerate(ctx.saved_tensors))
+        if grad_out_color is None and grad_out_depth is None:
+            return (None,) * 11
+        H, W = int(rs.image_height), int(rs.image_width)
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((K, 3, H, W), dtype=torch.float32, device=m3.device)
+        grads = _backward_impl(K, ctx.num_rendered, m3, shc, colc, ctx.opacities_shape, scc, rotc, covc, viewm, projm,
+                               campos, rs, radii, geom, binning, img, _f32c(grad_out_color), _f32c(grad_out_depth))
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations, grad_viewmatrix, grad_projmatrix) = grads
+        return (
+            grad_means3D,
+            grad_means2D,
+            grad_sh,
+            grad_colors_precomp if colc is not None else None,
+            grad_opacities.reshape(ctx.opacities_shape),
+            grad_scales,
+            grad_rotations,
+            grad_cov3Ds_precomp if covc is not None else None,
+            grad_viewmatrix,
+            grad_projmatrix,
+            None,
+        )
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions, viewmatrix=None, projmatrix=None):
+        """Frustum-visibility mask.  In the reference fork this method reads raster_settings.viewmatrix, a field
+        that no longer exists (dead code, __init__.py:194-203); here the matrices are explicit arguments."""
+        with torch.no_grad():
+            positions = _f32c(positions)
+            vm = _f32c(viewmatrix if viewmatrix is not None else getattr(self.raster_settings, "viewmatrix"))
+            pm = _f32c(projmatrix if projmatrix is not None else getattr(self.raster_settings, "projmatrix", vm))
+            visible = torch.empty(positions.shape[0], dtype=torch.bool, device=positions.device)
+            _lib.check(_lib.lib().dgs_mark_visible(positions.shape[0], _ptr(positions), _ptr(vm), _ptr(pm),
+                                                   _ptr(visible), _stream(positions.device)), "dgs_mark_visible")
+        return visible
+
+    @staticmethod
+    def _check(shs, colors_precomp, scales, rotations, cov3D_precomp):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, viewmatrix=None, projmatrix=None):
+        raster_settings = self.raster_settings
+        self._check(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, viewmatrix, projmatrix, raster_settings)
+
+    def forward_subframes(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                          rotations=None, cov3D_precomp=None, viewmatrices=None, projmatrices=None):
+        """K-subframe sibling of forward(): matrices are [K,4,4], raster_settings.campos is [K,3]."""
+        self._check(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        e = torch.Tensor([])
+        return rasterize_gaussians_subframes(
+            means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp, opacities,
+            e if scales is None else scales, e if rotations is None else rotations,
+            e if cov3D_precomp is None else cov3D_precomp, viewmatrices, projmatrices, self.raster_settings)

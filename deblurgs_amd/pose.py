@@ -1,0 +1,178 @@
+"""Pose path of the blur-integration loop: Bezier curve in se(3) -> SE(3) -> rasteriser cameras.
+
+Mirrors (behaviour, names and argument meaning) of the reference's
+  scene/bezier.py:14-85                      BezierModel
+  utils/pytorch3d_functions.py:218-247       _so3_exp_map
+  utils/pytorch3d_functions.py:337-372       hat
+  utils/pytorch3d_functions.py:373-457       se3_exp_map
+  utils/pytorch3d_functions.py:546-573       _se3_V_matrix
+  scene/motion.py:258-294                    _c2w_to_minicam  (batched here: no Python loop over K)
+  scene/cameras.py:63-74                     MiniCam
+  utils/graphics_utils.py:51-71              getProjectionMatrix
+The se3/so3 maps are pinned by tests/golden/pose_golden.npz (generated from the reference's own module).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+
+def hat(v: torch.Tensor) -> torch.Tensor:
+    """Skew-symmetric matrices of a batch of 3-vectors (pytorch3d_functions.py:337-372)."""
+    N, dim = v.shape
+    if dim != 3:
+        raise ValueError("Input vectors have to be 3-dimensional.")
+    x, y, z = v.unbind(1)
+    zero = torch.zeros_like(x)
+    return torch.stack((zero, -z, y, z, zero, -x, -y, x, zero), dim=1).reshape(N, 3, 3)
+
+
+def _so3_exp_map(log_rot: torch.Tensor, eps: float = 0.0001):
+    _, dim = log_rot.shape
+    if dim != 3:
+        raise ValueError("Input tensor shape has to be Nx3.")
+    nrms = (log_rot * log_rot).sum(1)
+    rot_angles = torch.clamp(nrms, eps).sqrt()
+    rot_angles_inv = 1.0 / rot_angles
+    fac1 = rot_angles_inv * rot_angles.sin()
+    fac2 = rot_angles_inv * rot_angles_inv * (1.0 - rot_angles.cos())
+    skews = hat(log_rot)
+    skews_square = torch.bmm(skews, skews)
+    R = (fac1[:, None, None] * skews + fac2[:, None, None] * skews_square
+         + torch.eye(3, dtype=log_rot.dtype, device=log_rot.device)[None])
+    return R, rot_angles, skews, skews_square
+
+
+def so3_exp_map(log_rot: torch.Tensor, eps: float = 0.0001) -> torch.Tensor:
+    return _so3_exp_map(log_rot, eps=eps)[0]
+
+
+def _se3_V_matrix(log_rotation, log_rotation_hat, log_rotation_hat_square, rotation_angles, eps: float = 1e-4):
+    return (torch.eye(3, dtype=log_rotation.dtype, device=log_rotation.device)[None]
+            + log_rotation_hat * ((1 - torch.cos(rotation_angles)) / (rotation_angles ** 2))[:, None, None]
+            + log_rotation_hat_square
+            * ((rotation_angles - torch.sin(rotation_angles)) / (rotation_angles ** 3))[:, None, None])
+
+
+def se3_exp_map(log_transform: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
+    """[N,6] (log_translation | log_rotation) -> [N,4,4] SE(3) in the row-vector convention [[R,0],[T,1]]."""
+    if log_transform.ndim != 2 or log_transform.shape[1] != 6:
+        raise ValueError("Expected input to be of shape (N, 6).")
+    N, _ = log_transform.shape
+    log_translation = log_transform[..., :3]
+    log_rotation = log_transform[..., 3:]
+    R, rotation_angles, log_rotation_hat, log_rotation_hat_square = _so3_exp_map(log_rotation, eps=eps)
+    V = _se3_V_matrix(log_rotation, log_rotation_hat, log_rotation_hat_square, rotation_angles, eps=eps)
+    T = torch.bmm(V, log_translation[:, :, None])[:, :, 0]
+    transform = torch.zeros(N, 4, 4, dtype=log_transform.dtype, device=log_transform.device)
+    transform[:, :3, :3] = R
+    transform[:, :3, 3] = T
+    transform[:, 3, 3] = 1.0
+    return transform.permute(0, 2, 1)
+
+
+def _binom(n: int, k: int) -> float:
+    return float(math.comb(n, k))
+
+
+class BezierModel(nn.Module):
+    """Bernstein-basis Bezier curves, one per training image (scene/bezier.py).
+
+    Note the reference's parametrisation: control point 0 is reached at t = 1
+    (coeff_k = binom(C,k) * t^(C-k) * (1-t)^k, scene/bezier.py:54-64)."""
+
+    def __init__(self, initial_points, curve_order, initial_noise=0.001, device=None):
+        super().__init__()
+        self.curve_order = curve_order
+        initial_points = initial_points.float()
+        if device is not None:
+            initial_points = initial_points.to(device)
+        initial_points = initial_points[:, None, :].repeat(1, curve_order + 1, 1)
+        initial_points = initial_points + torch.randn_like(initial_points) * initial_noise
+        self._control_points = nn.Parameter(initial_points.clone().contiguous().requires_grad_(True))
+        # The reference builds this with scipy.special.binom as a float64 tensor (scene/bezier.py:48), which
+        # promotes coeff to float64; math.comb gives the same integers.
+        self.register_buffer(
+            "_bezier_binom_coeff",
+            torch.tensor([_binom(curve_order, k) for k in range(curve_order + 1)], dtype=torch.float64,
+                         device=self._control_points.device), persistent=False)
+
+    @property
+    def device(self):
+        return self._control_points.device
+
+    def _get_bezier_coeff(self, t):
+        C = self.curve_order
+        coeff = ((t[:, None] ** torch.arange(C, -1, -1, device=self.device))
+                 * ((1 - t)[:, None] ** torch.arange(0, C + 1, device=self.device))
+                 * self._bezier_binom_coeff.to(self.device))
+        return coeff
+
+    def forward(self, t: torch.Tensor, idx):
+        if isinstance(idx, int):
+            idx = torch.tensor([idx], device=self.device)
+        return (self._get_bezier_coeff(t)[:, :, None] * self._control_points[idx]).sum(dim=1)
+
+    def __len__(self):
+        return self._control_points.shape[0]
+
+
+def get_projection_matrix(znear, zfar, fovX, fovY):
+    """utils/graphics_utils.py:51-71 (returned un-transposed, like the reference)."""
+    tanHalfFovY = math.tan((fovY / 2))
+    tanHalfFovX = math.tan((fovX / 2))
+    top = tanHalfFovY * znear
+    bottom = -top
+    right = tanHalfFovX * znear
+    left = -right
+    P = torch.zeros(4, 4)
+    z_sign = 1.0
+    P[0, 0] = 2.0 * znear / (right - left)
+    P[1, 1] = 2.0 * znear / (top - bottom)
+    P[0, 2] = (right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[3, 2] = z_sign
+    P[2, 2] = z_sign * zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+class MiniCam:
+    """scene/cameras.py:63-74 -- the four tensors render() reads plus the intrinsics."""
+
+    def __init__(self, width, height, fovy, fovx, znear, zfar, world_view_transform, full_proj_transform,
+                 camera_center=None):
+        self.image_width = width
+        self.image_height = height
+        self.FoVy = fovy
+        self.FoVx = fovx
+        self.znear = znear
+        self.zfar = zfar
+        self.world_view_transform = world_view_transform
+        self.full_proj_transform = full_proj_transform
+        if camera_center is None:
+            view_inv = torch.inverse(self.world_view_transform)
+            camera_center = view_inv[3][:3]
+        self.camera_center = camera_center
+
+
+def c2w_to_view_proj(rots, transes, projection_matrix):
+    """Batched core of scene/motion.py:258-294: c2w rotations [K,3,3] + translations [K,3] ->
+    (world_view [K,4,4], full_proj [K,4,4], camera_center [K,3]), differentiable w.r.t. rots/transes."""
+    K = rots.shape[0]
+    # The reference evaluates the curve and the exponential map in float64 (the binomial table is float64,
+    # scene/bezier.py:48) and rounds to float32 when writing into torch.eye(4) (scene/motion.py:277-279).
+    world_view = torch.eye(4, device=rots.device, dtype=torch.float32)[None].repeat(K, 1, 1)
+    world_view[:, :3, :3] = rots.to(torch.float32)
+    world_view[:, 3, :3] = (-torch.bmm(transes[:, None, :], rots)[:, 0, :]).to(torch.float32)
+    full_proj = torch.matmul(world_view, projection_matrix.to(world_view)[None])
+    campos = torch.linalg.inv(world_view)[:, 3, :3]
+    return world_view, full_proj, campos
+
+
+def se3_to_view_proj(se3, projection_matrix):
+    """scene/motion.py:248-252 followed by :258-294, for all K subframes at once."""
+    c2w = se3_exp_map(se3)
+    rots = c2w[:, :3, :3].transpose(-2, -1)
+    transes = c2w[:, 3, :3]
+    return c2w_to_view_proj(rots, transes, projection_matrix)

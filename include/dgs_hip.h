@@ -1,0 +1,187 @@
+/* dgs_hip.h -- C ABI of libdgs_hip.so: the MI355X (gfx950) differentiable Gaussian-splat rasteriser for
+ * DeblurGS's blur-integration loop.
+ *
+ * This is the drop-in boundary for the reference's pybind module `diff_gaussian_rasterization._C`
+ * (/root/reference/submodules/diff-gaussian-rasterization/ext.cpp:15-19,
+ *  rasterize_points.h:18-73).  Differences, all deliberate:
+ *   - plain C: raw device pointers, sizes and a HIP stream handle; no torch types.  The caller owns every
+ *     byte (inputs, outputs, gradients, the three state blobs and the backward scratch); the library never
+ *     allocates device memory.  Blob sizes come from the dgs_*_bytes() queries, and the carving of a blob
+ *     into sub-arrays is a pure function of (P, W, H, K, R), replayed identically by forward and backward
+ *     (the reference does the same with GeometryState/ImageState/BinningState::fromChunk,
+ *     rasterizer_impl.cu:155-194,389-391).
+ *   - K >= 1 subframes per call ("K-fused"): one launch chain rasterises all K poses of a blurry view
+ *     (scene/motion.py:141-143 calls render() K times).  K = 1 is exactly `_C.rasterize_gaussians`.
+ *   - the forward is split in two calls around the one host read of num_rendered
+ *     (rasterizer_impl.cu:286-287): dgs_forward_geometry -> caller sizes the binning blob ->
+ *     dgs_forward_render.
+ * Every entry point returns 0 on success or a negative DGS_E_* code; dgs_last_error() gives the text.
+ * All kernels are enqueued on the given stream; nothing here synchronises unless `debug` is set.
+ */
+#ifndef DGS_HIP_H_INCLUDED
+#define DGS_HIP_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGS_ABI_VERSION 1
+#define DGS_MAX_K 128 /* subframes per fused call */
+
+#define DGS_OK 0
+#define DGS_E_ARG (-1)      /* bad shape / null pointer / exclusive-argument violation */
+#define DGS_E_CAPACITY (-2) /* a caller-provided blob is too small */
+#define DGS_E_HIP (-3)      /* a HIP runtime error (text in dgs_last_error) */
+
+typedef void* dgs_stream_t; /* hipStream_t */
+
+/* Arguments shared by forward and backward: replaces the 22 / 25 positional arguments of
+ * RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA (rasterize_points.cu:35-59,125-152). */
+typedef struct DgsProblem {
+  int32_t P;       /* Gaussians */
+  int32_t D;       /* active SH degree 0..3 */
+  int32_t M;       /* SH coefficients per Gaussian, (max_sh_degree+1)^2; 0 when colors_precomp is used */
+  int32_t W, H;    /* image size */
+  int32_t K;       /* subframes (poses) in this call, 1..DGS_MAX_K */
+  float tanfovx, tanfovy;
+  float scale_modifier;
+  float z_near, z_far; /* z_near is plumbed but unused, as in the reference */
+  int32_t use_sigmoid; /* colour activation: 0 = relu(x+0.5), 1 = sigmoid (forward.cu:63-80) */
+  int32_t prefiltered;
+  int32_t debug;       /* sync + check after every stage (auxiliary.h:179-186) */
+  /* inputs, device pointers, fp32 contiguous */
+  const float* means3D;        /* [P,3] */
+  const float* shs;            /* [P,M,3] or NULL */
+  const float* colors_precomp; /* [P,3]   or NULL   (exactly one of shs / colors_precomp) */
+  const float* opacities;      /* [P] */
+  const float* scales;         /* [P,3] or NULL */
+  const float* rotations;      /* [P,4] or NULL */
+  const float* cov3D_precomp;  /* [P,6] or NULL   (exactly one of scales+rotations / cov3D_precomp) */
+  const float* viewmatrix;     /* [K,4,4] row-vector convention, flat index 4r+c (auxiliary.h:58-66) */
+  const float* projmatrix;     /* [K,4,4] full projection = view @ proj */
+  const float* campos;         /* [K,3] */
+  const float* bg;             /* [3] */
+  /* state blobs kept alive by the caller between forward and backward */
+  void* geom_state;    size_t geom_bytes;    /* >= dgs_geom_state_bytes(P,K) */
+  void* image_state;   size_t image_bytes;   /* >= dgs_image_state_bytes(W,H,K) */
+  void* binning_state; size_t binning_bytes; /* >= dgs_binning_state_bytes(R,W,H,K); unused by dgs_forward_geometry */
+} DgsProblem;
+
+typedef struct DgsForwardOut {
+  float* out_color;   /* [K,3,H,W] */
+  float* out_depth;   /* [K,1,H,W] */
+  int32_t* radii;     /* [K,P] */
+  uint32_t* num_rendered_host; /* pinned host word: dgs_forward_geometry enqueues an async copy of R into it */
+} DgsForwardOut;
+
+typedef struct DgsBackwardIO {
+  uint32_t num_rendered;      /* R returned by the forward */
+  const int32_t* radii;       /* [K,P] from the forward */
+  const float* dL_dout_color; /* [K,3,H,W] */
+  const float* dL_dout_depth; /* [K,1,H,W] or NULL (= zeros) */
+  void* scratch; size_t scratch_bytes; /* >= dgs_backward_scratch_bytes(R,P,K) */
+  /* gradients, fully overwritten (no zero-fill needed).  Per-Gaussian grads are summed over the K
+   * subframes; the screen-space and pose grads stay per subframe because densification and the trajectory
+   * consume them per subframe (train.py:188-193, scene/motion.py:248-294). */
+  float* dL_dmeans3D;  /* [P,3] */
+  float* dL_dmeans2D;  /* [K,P,3] NDC-scaled screen gradient, .z = 0 (backward.cu:628-629) */
+  float* dL_dsh;       /* [P,M,3]  (NULL when colors_precomp was used) */
+  float* dL_dcolors;   /* [P,3]    (written always; the grad of colors_precomp when that was used) */
+  float* dL_dopacity;  /* [P] */
+  float* dL_dscales;   /* [P,3]  (NULL when cov3D_precomp was used) */
+  float* dL_drotations;/* [P,4]  (NULL when cov3D_precomp was used) */
+  float* dL_dcov3D;    /* [P,6] */
+  float* dL_dviewmatrix; /* [K,4,4] */
+  float* dL_dprojmatrix; /* [K,4,4] */
+} DgsBackwardIO;
+
+/* Byte offsets of the sub-arrays inside the three blobs (for debuggers and the parity tests).
+ * Element types: rows f32[12] = {x, y, conic.x, conic.y, conic.z, opacity, r, g, b, depth, u32 dup_offset,
+ * i32 radius}; keys u64 = ((k*T + tile) << 32) | depth_bits; ranges uint2 per (k, tile). */
+typedef struct DgsLayout {
+  /* geometry blob */
+  size_t geom_rows;      /* f32 [K,P,12] */
+  size_t cov3D;          /* f32 [P,6] */
+  size_t pre_sigmoid;    /* f32 [K,P,3]  pre-activation colour (sigmoid) or 0/1 clamp mask (relu) */
+  size_t tiles_touched;  /* u32 [K*P] */
+  size_t point_offsets;  /* u32 [K*P] exclusive prefix sum of tiles_touched */
+  size_t scan_tmp;       /* u32 scan block sums */
+  size_t num_rendered;   /* u32 [4] device copy of R (+ spare) */
+  size_t geom_total;
+  /* image blob */
+  size_t final_T;        /* f32 [K,H*W] */
+  size_t n_contrib;      /* u32 [K,H*W] */
+  size_t ranges;         /* u32 [K*T,2] */
+  size_t image_total;
+  /* binning blob */
+  size_t keys_sorted;    /* u64 [R] */
+  size_t point_list;     /* u32 [R] sorted Gaussian ids */
+  size_t keys_unsorted;  /* u64 [R] (also the sort's ping-pong buffer) */
+  size_t vals_unsorted;  /* u32 [R] */
+  size_t sort_tmp;       /* u32 radix histogram table */
+  size_t binning_total;
+  int32_t sort_bits;     /* 32 + bits(K*T) */
+  int32_t sort_passes;
+} DgsLayout;
+
+int dgs_abi_version(void);
+const char* dgs_last_error(void);
+
+size_t dgs_geom_state_bytes(int32_t P, int32_t K);
+size_t dgs_image_state_bytes(int32_t W, int32_t H, int32_t K);
+size_t dgs_binning_state_bytes(uint64_t R, int32_t W, int32_t H, int32_t K);
+size_t dgs_backward_scratch_bytes(uint64_t R, int32_t P, int32_t K);
+int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, DgsLayout* out);
+
+/* Replaces Rasterizer::forward up to the host read of num_rendered (rasterizer_impl.cu:198-287):
+ * preprocess for all K subframes + prefix sum, then an async copy of R to out->num_rendered_host. */
+int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stream_t stream);
+/* Replaces the rest of Rasterizer::forward (rasterizer_impl.cu:289-345): duplicateWithKeys, the stable
+ * radix sort, identifyTileRanges and the per-tile alpha compositing, for all K subframes. */
+int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t num_rendered, dgs_stream_t stream);
+/* Replaces Rasterizer::backward (rasterizer_impl.cu:350-463). */
+int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream);
+/* Replaces Rasterizer::markVisible (rasterizer_impl.cu:141-153); present is bool[P] as bytes. */
+int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, dgs_stream_t stream);
+
+/* Stand-alone building blocks, exported so the parity tests can pin them against numpy
+ * (cub::DeviceScan::InclusiveSum / cub::DeviceRadixSort::SortPairs call sites,
+ * rasterizer_impl.cu:166,188-191,283,309-314). */
+size_t dgs_scan_tmp_bytes(uint64_t n);
+int dgs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, void* tmp, uint32_t* total_out,
+                           dgs_stream_t stream);
+size_t dgs_sort_tmp_bytes(uint64_t n);
+/* Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [0, end_bit).  Both buffer pairs are
+ * clobbered; *result_in_alt tells which pair holds the result (0: keys/vals, 1: keys_alt/vals_alt). */
+int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
+                   int32_t end_bit, void* tmp, int32_t* result_in_alt, dgs_stream_t stream);
+
+/* Fused loss-gradient image (train.py:143-165, utils/loss_utils.py:17-18,80-93): from the K rendered
+ * subframes and the target, produces blur = mean_k, the L1 and temporal-smoothness loss values and
+ * dL/dsubframes in one pass.  losses = {l1, smooth}. */
+int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW,
+                       float lambda_t, float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream);
+
+/* Stage timing with HIP events recorded on the caller's stream (bench.py's roofline leg). */
+#define DGS_STAGE_PREPROCESS 0
+#define DGS_STAGE_SCAN 1
+#define DGS_STAGE_DUPLICATE 2
+#define DGS_STAGE_SORT 3
+#define DGS_STAGE_RANGES 4
+#define DGS_STAGE_COMPOSITE_FWD 5
+#define DGS_STAGE_COMPOSITE_BWD 6
+#define DGS_STAGE_GEOMETRY_BWD 7
+#define DGS_STAGE_COUNT 8
+int dgs_profile_enable(int32_t on);
+int dgs_profile_reset(void);
+/* Synchronises on the recorded events; ms[i] = summed duration of stage i, calls[i] = launches timed. */
+int dgs_profile_read(float* ms, int32_t* calls, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGS_HIP_H_INCLUDED */

@@ -1,0 +1,351 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on seeded synthetic scenes.
+
+Bars (BASELINE.json north_star): tile ids / sort keys / radii / point lists bit-exact; images and gradients
+within 1e-4 (absolute for images, relative to the largest reference magnitude for gradients, whose absolute
+scale is arbitrary)."""
+import numpy as np
+import pytest
+
+from helpers import (hip_forward_backward, hip_forward_state, oracle_forward, oracle_forward_backward, relerr,
+                     synthetic, unstable_pixels)
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 1e-4      # abs, colour (values O(1))
+DEPTH_TOL = 1e-4    # relative to z_far-scale depths
+GRAD_TOL = 1e-4     # relative to max |reference|
+
+
+def small_scene(P=3000, W=200, H=136, K=3, seed=1, **kw):
+    return synthetic.make_scene(P, W, H, K=K, seed=seed, **kw)
+
+
+# ------------------------------------------------------------------------------------------ building blocks
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 4096, 4097, 100_000, 3_000_001])
+def test_exclusive_scan(gpu, n):
+    import ctypes
+    import torch
+    from deblurgs_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 50, size=n, dtype=np.uint32)
+    x = torch.from_numpy(a.astype(np.int64)).to(torch.int32).to(gpu)   # values < 2^31
+    out = torch.empty_like(x)
+    tmp = torch.empty(L.dgs_scan_tmp_bytes(n) + 16, dtype=torch.uint8, device=gpu)
+    total = torch.zeros(1, dtype=torch.int32, device=gpu)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.dgs_exclusive_scan_u32(x.data_ptr(), out.data_ptr(), n, tmp.data_ptr(), total.data_ptr(), st), "scan")
+    torch.cuda.synchronize()
+    ref = np.concatenate([[0], np.cumsum(a, dtype=np.uint64)[:-1]]).astype(np.uint32) if n else a
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref)
+    assert int(total.item()) == int(a.sum())
+
+
+@pytest.mark.parametrize("n,bits", [(0, 40), (1, 33), (777, 41), (4096, 45), (50_001, 49), (1_000_003, 45),
+                                     (300_000, 64), (100_000, 7)])
+def test_radix_sort_pairs_stable(gpu, n, bits):
+    import ctypes
+    import torch
+    from deblurgs_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(bits * 1000 + n)
+    keys = rng.integers(0, 2 ** 63, size=n, dtype=np.uint64)
+    if bits < 64:
+        # keep many duplicates in the sorted bits (stability) and garbage above end_bit (must be ignored)
+        keys = (keys & np.uint64((1 << bits) - 1) & np.uint64(0xFFFFFFF00FF00FFF)) | (keys & ~np.uint64((1 << bits) - 1))
+    vals = np.arange(n, dtype=np.uint32)
+    tk = lambda a: torch.from_numpy(a.view(np.int64)).to(gpu)
+    k0, k1 = tk(keys.copy()), tk(np.zeros(n, np.uint64))
+    v0 = torch.from_numpy(vals.view(np.int32).copy()).to(gpu)
+    v1 = torch.zeros_like(v0)
+    tmp = torch.empty(L.dgs_sort_tmp_bytes(n) + 16, dtype=torch.uint8, device=gpu)
+    alt = ctypes.c_int32(0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.dgs_sort_pairs(k0.data_ptr(), v0.data_ptr(), k1.data_ptr(), v1.data_ptr(), n, bits, tmp.data_ptr(),
+                                ctypes.byref(alt), st), "sort")
+    torch.cuda.synchronize()
+    ko = (k1 if alt.value else k0).cpu().numpy().view(np.uint64)
+    vo = (v1 if alt.value else v0).cpu().numpy().view(np.uint32)
+    mask = np.uint64((1 << bits) - 1) if bits < 64 else np.uint64(2 ** 64 - 1)
+    order = np.argsort(keys & mask, kind="stable")
+    assert np.array_equal(vo, vals[order])
+    assert np.array_equal(ko, keys[order])
+
+
+# --------------------------------------------------------------------------------------------- stage parity
+@pytest.fixture(scope="module")
+def scene_states(gpu):
+    sc = small_scene()
+    hip = hip_forward_state(sc, sc["K"])
+    ora = [oracle_forward(sc, k) for k in range(sc["K"])]
+    return sc, hip, ora
+
+
+def test_preprocess_bit_exact(scene_states):
+    sc, hip, ora = scene_states
+    for k, o in enumerate(ora):
+        vis = o["radii"] > 0
+        assert vis.sum() > 100
+        assert np.array_equal(hip["radii"][k], o["radii"]), "radii"
+        assert np.array_equal(hip["tiles_touched"][k], o["tiles_touched"]), "tiles_touched"
+        rows = hip["rows"][k][vis]
+        # pixel-space means, conic, opacity, depth: same IEEE op order, no FMA contraction -> identical bits
+        assert np.array_equal(rows[:, 0:2].view(np.uint32), o["means2D"][vis].view(np.uint32)), "means2D bits"
+        assert np.array_equal(rows[:, 9].view(np.uint32), o["depths"][vis].view(np.uint32)), "depth bits"
+        assert np.array_equal(rows[:, 2:6].view(np.uint32), o["conic_opacity"][vis].view(np.uint32)), "conic bits"
+        assert np.abs(rows[:, 6:9] - o["rgb"][vis]).max() <= 1e-6, "rgb"
+        assert np.array_equal(hip["rows_u32"][k][vis][:, 11].view(np.int32), o["radii"][vis])
+        assert np.array_equal(hip["pre_sigmoid"][k][vis], o["pre_sigmoid"][vis]), "relu mask"
+    wrote = np.any(ora[0]["cov3D"] != 0, axis=1)     # the oracle fills cov3D only past the near-plane cull
+    assert np.array_equal(hip["cov3D"][wrote].view(np.uint32), ora[0]["cov3D"][wrote].view(np.uint32)), "cov3D bits"
+
+
+def test_binning_bit_exact(scene_states):
+    sc, hip, ora = scene_states
+    P, T = sc["P"], hip["T"]
+    Rs = [o["num_rendered"] for o in ora]
+    assert hip["R"] == sum(Rs)
+    # exclusive offsets over the [K,P] order
+    flat_tt = hip["tiles_touched"].reshape(-1).astype(np.uint64)
+    assert np.array_equal(hip["point_offsets"].reshape(-1), np.concatenate([[0], np.cumsum(flat_tt)[:-1]]).astype(np.uint32))
+    off = 0
+    for k, o in enumerate(ora):
+        R = Rs[k]
+        keys = hip["keys"][off:off + R]
+        # reference key = (tile << 32) | depth_bits; the fused key carries k*T on top of the tile id
+        assert np.array_equal(keys - (np.uint64(k * T) << np.uint64(32)), o["keys"]), "sort keys"
+        assert np.array_equal(hip["point_list"][off:off + R], o["point_list"]), "point_list"
+        rng = hip["ranges"][k].astype(np.int64)
+        ref = o["ranges"].astype(np.int64)
+        nonempty = ref[:, 1] > ref[:, 0]
+        assert np.array_equal(rng[nonempty] - off, ref[nonempty]), "tile ranges"
+        assert np.all(rng[~nonempty, 1] - rng[~nonempty, 0] == 0)
+        off += R
+    assert hip["sort_bits"] == 32 + __import__("oracle.oracle", fromlist=["x"]).higher_msb(T * sc["K"])
+
+
+def test_forward_images(scene_states):
+    sc, hip, ora = scene_states
+    for k, o in enumerate(ora):
+        unstable = unstable_pixels(o)
+        assert unstable.mean() < 0.02
+        dc = np.abs(hip["color"][k] - o["color"]).max(axis=0)
+        dd = np.abs(hip["depth"][k][0] - o["depth"][0]) / sc["z_far"]
+        assert dc[~unstable].max() <= IMG_TOL, f"colour k={k}: {dc[~unstable].max()}"
+        assert dd[~unstable].max() <= DEPTH_TOL, f"depth k={k}: {dd[~unstable].max()}"
+        assert dc.max() <= 2e-2 and dd.max() <= 2e-2       # a flipped threshold moves one pair's weight only
+        s = ~unstable.reshape(-1)
+        assert np.array_equal(hip["n_contrib"][k][s], o["n_contrib"][s]), "n_contrib"
+        assert np.abs(hip["final_T"][k][s] - o["final_T"][s]).max() <= 1e-5, "final_T"
+
+
+def _grads(sc, K, seed=5, depth=True, **kw):
+    rng = np.random.default_rng(seed)
+    gC = rng.normal(size=(K, 3, sc["H"], sc["W"])).astype(np.float32)
+    gD = (rng.normal(size=(K, 1, sc["H"], sc["W"])) * 0.05).astype(np.float32) if depth else None
+    return gC, gD
+
+
+GRAD_KEYS = ["dL_dmeans3D", "dL_dopacities", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dmeans2D",
+             "dL_dviewmatrix", "dL_dprojmatrix"]
+
+
+@pytest.mark.parametrize("depth", [True, False])
+def test_backward_vs_oracle(gpu, depth):
+    sc = small_scene(P=2500, W=160, H=120, K=3, seed=2)
+    gC, gD = _grads(sc, 3, depth=depth)
+    hip = hip_forward_backward(sc, 3, gC, gD)
+    ora = oracle_forward_backward(sc, 3, gC, gD)
+    for key in GRAD_KEYS:
+        a, b = hip[key], ora[key]
+        assert a.shape == b.shape or a.reshape(b.shape) is not None
+        e = relerr(a.reshape(b.shape), b)
+        assert e <= GRAD_TOL, f"{key}: rel err {e:.3e}"
+    assert np.array_equal(hip["radii"], ora["radii"])
+
+
+def test_fused_equals_per_subframe_calls(gpu):
+    """K fused subframes == K calls of the reference-shaped K=1 operator (scene/motion.py:141-143)."""
+    sc = small_scene(P=2000, W=128, H=96, K=4, seed=3)
+    gC, gD = _grads(sc, 4)
+    f = hip_forward_backward(sc, 4, gC, gD, fused=True)
+    s = hip_forward_backward(sc, 4, gC, gD, fused=False)
+    assert np.array_equal(f["color"], s["color"]) and np.array_equal(f["depth"], s["depth"])
+    assert np.array_equal(f["radii"], s["radii"])
+    for key in ["dL_dmeans2D", "dL_dviewmatrix", "dL_dprojmatrix"]:
+        assert np.array_equal(f[key], s[key]), key          # per-subframe outputs: identical bits
+    for key in ["dL_dmeans3D", "dL_dopacities", "dL_dsh", "dL_dscales", "dL_drotations"]:
+        assert relerr(f[key], s[key]) <= 1e-5, key          # summed over k in a different order
+
+
+def test_backward_is_deterministic(gpu):
+    sc = small_scene(P=2000, W=128, H=96, K=2, seed=4)
+    gC, gD = _grads(sc, 2)
+    a = hip_forward_backward(sc, 2, gC, gD)
+    b = hip_forward_backward(sc, 2, gC, gD)
+    for key in GRAD_KEYS + ["color", "depth"]:
+        assert np.array_equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("variant", ["sigmoid", "deg0", "deg3", "colors_precomp", "cov3D_precomp"])
+def test_variants(gpu, variant):
+    kw, sckw = {}, {}
+    if variant == "deg3":
+        sckw = dict(sh_degree=3)
+    sc = small_scene(P=1500, W=112, H=80, K=2, seed=6, **sckw)
+    rng = np.random.default_rng(9)
+    if variant == "sigmoid":
+        kw = dict(use_sigmoid=True)
+    elif variant == "deg0":
+        kw = dict(sh_degree=0)
+    elif variant == "colors_precomp":
+        kw = dict(colors_precomp=rng.random((sc["P"], 3)).astype(np.float32))
+    elif variant == "cov3D_precomp":
+        st = oracle_forward(sc, 0, render=False)
+        kw = dict(cov3D_precomp=st["cov3D"].copy())
+        kw["cov3D_precomp"][st["depths"] == 0] = np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], np.float32)
+    gC, gD = _grads(sc, 2, seed=11)
+    hip = hip_forward_backward(sc, 2, gC, gD, **kw)
+    ora = oracle_forward_backward(sc, 2, gC, gD, **kw)
+    keys = ["dL_dmeans3D", "dL_dopacities", "dL_dmeans2D", "dL_dviewmatrix", "dL_dprojmatrix"]
+    if variant == "colors_precomp":
+        keys += ["dL_dcolors_precomp", "dL_dscales", "dL_drotations"]
+    elif variant == "cov3D_precomp":
+        keys += ["dL_dcov3D_precomp", "dL_dsh"]
+    else:
+        keys += ["dL_dsh", "dL_dscales", "dL_drotations"]
+    for k in range(2):
+        un = unstable_pixels(ora["states"][k])
+        assert np.abs(hip["color"][k] - ora["color"][k]).max(axis=0)[~un].max() <= IMG_TOL
+    for key in keys:
+        assert relerr(hip[key].reshape(ora[key].shape), ora[key]) <= GRAD_TOL, key
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+def test_ragged_image_and_empty_tiles(gpu):
+    """W, H not multiples of 16 (partial tiles, partial quadrants) and many empty tiles."""
+    sc = small_scene(P=300, W=75, H=41, K=2, seed=7)
+    hip = hip_forward_state(sc, 2)
+    for k in range(2):
+        o = oracle_forward(sc, k)
+        un = unstable_pixels(o)
+        assert np.abs(hip["color"][k] - o["color"]).max(axis=0)[~un].max() <= IMG_TOL
+        assert np.array_equal(hip["radii"][k], o["radii"])
+
+
+def test_all_culled_and_empty(gpu):
+    import torch
+    sc = small_scene(P=64, W=64, H=48, K=2, seed=8)
+    sc["means3D"][:, 2] = -5.0            # everything behind the camera: R == 0
+    hip = hip_forward_state(sc, 2)
+    assert hip["R"] == 0 and not hip["radii"].any()
+    bg = sc["bg"][None, :, None, None]
+    assert np.allclose(hip["color"], np.broadcast_to(bg, hip["color"].shape))
+    assert np.allclose(hip["depth"], sc["z_far"])
+    gC, gD = _grads(sc, 2)
+    g = hip_forward_backward(sc, 2, gC, gD)
+    for key in GRAD_KEYS:
+        assert not np.any(g[key]), key
+    # P == 0 (rasterize_points.cu:85): zero images, no launch
+    from helpers import hip_settings, _t
+    from deblurgs_amd.diff_gaussian_rasterization import GaussianRasterizer
+    rs = hip_settings(sc, 1)
+    e = torch.zeros((0, 3), device="cuda")
+    c, d, r = GaussianRasterizer(rs)(e, e.clone(), torch.zeros((0, 1), device="cuda"), shs=torch.zeros((0, 9, 3), device="cuda"),
+                                     scales=e.clone(), rotations=torch.zeros((0, 4), device="cuda"),
+                                     viewmatrix=_t(sc["viewmatrix"][0]), projmatrix=_t(sc["projmatrix"][0]))
+    assert c.shape == (3, 48, 64) and not c.any() and r.numel() == 0
+
+
+def test_huge_gaussian_and_long_tile_lists(gpu):
+    """One Gaussian covering every tile + a dense clump: tile lists much longer than a 64-entry batch, early
+    termination, and rect clamping at the image border."""
+    sc = small_scene(P=4000, W=96, H=64, K=1, seed=10, sigma_px=6.0)
+    sc["scales"][0] = 50.0
+    sc["means3D"][0] = [0, 0, 5]
+    sc["opacities"][0] = 0.3
+    hip = hip_forward_state(sc, 1)
+    o = oracle_forward(sc, 0)
+    assert np.array_equal(hip["point_list"], o["point_list"])
+    assert (o["ranges"][:, 1] - o["ranges"][:, 0]).max() > 256
+    un = unstable_pixels(o)
+    assert np.abs(hip["color"][0] - o["color"]).max(axis=0)[~un].max() <= IMG_TOL
+    gC, gD = _grads(sc, 1)
+    a = hip_forward_backward(sc, 1, gC, gD)
+    b = oracle_forward_backward(sc, 1, gC, gD)
+    for key in GRAD_KEYS:
+        assert relerr(a[key].reshape(b[key].shape), b[key]) <= GRAD_TOL, key
+
+
+def test_argument_errors(gpu):
+    import torch
+    from helpers import hip_settings, _t
+    from deblurgs_amd.diff_gaussian_rasterization import GaussianRasterizer
+    sc = small_scene(P=10, W=32, H=32, K=1)
+    r = GaussianRasterizer(hip_settings(sc, 1))
+    m = _t(sc["means3D"])
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(m, m, _t(sc["opacities"]), scales=_t(sc["scales"]), rotations=_t(sc["rotations"]))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+        r(m, m, _t(sc["opacities"]), shs=_t(sc["sh"]))
+
+
+def test_mark_visible(gpu):
+    from helpers import hip_settings, _t
+    from deblurgs_amd.diff_gaussian_rasterization import GaussianRasterizer
+    from oracle import oracle
+    sc = small_scene(P=500, W=64, H=64, K=1)
+    sc["means3D"][::3, 2] *= -1
+    vis = GaussianRasterizer(hip_settings(sc, 1)).markVisible(_t(sc["means3D"]), _t(sc["viewmatrix"][0]),
+                                                              _t(sc["projmatrix"][0]))
+    assert np.array_equal(vis.cpu().numpy(), oracle.mark_visible(sc["means3D"], sc["viewmatrix"][0]))
+
+
+def test_fused_blur_loss_vs_golden(gpu):
+    import os
+    import torch
+    from deblurgs_amd import losses
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_golden.npz"))
+    sub = torch.tensor(g["sub"], device="cuda", requires_grad=True)
+    gt = torch.tensor(g["gt"], device="cuda")
+    lam = float(g["lam"][0])
+    total, blur, ls = losses.blur_l1_smooth(sub, gt, lam)
+    total.backward()
+    assert abs(ls[0].item() - float(g["l1"])) <= 1e-6 and abs(ls[1].item() - float(g["smooth"])) <= 1e-6
+    # golden g_sub also contains nothing else that depends on `sub`
+    assert np.abs(sub.grad.cpu().numpy() - g["g_sub"]).max() <= 1e-7
+    assert np.abs(blur.cpu().numpy() - g["sub"].mean(0)).max() <= 1e-6
+
+
+# ------------------------------------------------------------- BASELINE-size, size-independent properties
+def test_metric_size_properties(gpu):
+    """cfg2-sized fused run (100k Gaussians, 800x800, K=9): sortedness, range/key consistency, checksum of
+    duplicates, and linearity of the backward in the upstream gradient."""
+    import torch
+    sc = synthetic.make_config("cfg2")
+    K = sc["K"]
+    st = hip_forward_state(sc, K)
+    keys = st["keys"]
+    assert np.all(keys[1:] >= keys[:-1]), "sorted"
+    assert st["R"] == int(st["tiles_touched"].astype(np.uint64).sum())
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    rng = st["ranges"].reshape(-1, 2).astype(np.int64)
+    counts = np.bincount(tiles, minlength=rng.shape[0])
+    assert np.array_equal(rng[:, 1] - rng[:, 0], counts)
+    # every duplicate's Gaussian really lists that tile: radius > 0
+    k_of = tiles // st["T"]
+    assert np.all(st["radii"][k_of, st["point_list"]] > 0)
+    vis = st["radii"] > 0
+    assert 0.6 < vis.mean() < 0.95
+    # one subframe against the oracle at full cfg2 size
+    o = oracle_forward(sc, 4)
+    un = unstable_pixels(o)
+    assert np.abs(st["color"][4] - o["color"]).max(axis=0)[~un].max() <= IMG_TOL
+    off = int(st["tiles_touched"][:4].astype(np.uint64).sum())
+    assert np.array_equal(st["point_list"][off:off + o["num_rendered"]], o["point_list"])
+    # linearity: grads(2g) == 2 grads(g) bit-for-bit (power-of-two scaling commutes with every rounding)
+    gC, _ = _grads(sc, K, depth=False)
+    a = hip_forward_backward(sc, K, gC)
+    b = hip_forward_backward(sc, K, 2.0 * gC)
+    for key in ["dL_dmeans3D", "dL_dsh", "dL_dviewmatrix"]:
+        assert np.array_equal(2.0 * a[key], b[key]), key
