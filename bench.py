@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- subframe-renders/sec (fwd+bwd) of the blur-integration hot path on synthetic Gaussian clouds.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+One "step" = one query()-equivalent of the reference's training iteration (train.py:126-165) for one blurry view:
+pose path (Bezier -> se3_exp_map -> K cameras), ONE fused K-subframe rasterisation, the fused loss-gradient
+image (L1 of the pixel-averaged blur + temporal smoothness) + opacity hinge, and the full backward to the
+per-Gaussian and trajectory gradients.  Optimiser step, densification and data loading are excluded
+(SURVEY.md 8d).  Default workload = BASELINE.json's metric configuration: 1M Gaussians, 1920x1080, K=15,
+curve order 3, SH degree 2.
+
+N GPUs ("views" sharding, weak scaling): every rank renders all K subframes of its own view; per-Gaussian
+gradients are averaged with one flat RCCL all-reduce per step.  value = N * K * steps / seconds.
+
+Prints ONE JSON line on rank 0 (metric contract + "roofline" for the dominant kernel + "cpu_baseline").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def stage_bytes(P, Pv_tot, R_tot, N, K, s):
+    """Algorithmic bytes per K-fused launch of each stage (SURVEY.md 8d byte model, summed over the K subframes;
+    K-fused: the P*(44+12s) input read and the per-Gaussian gradient write are paid once per launch)."""
+    return {
+        "preprocess": P * (44 + 12 * s) + 84 * Pv_tot,
+        "scan": 8 * P * K,
+        "duplicate": 20 * P * K + 12 * R_tot,
+        "sort": 24 * R_tot,
+        "ranges": 8 * R_tot,
+        "composite_fwd": (28 + 16) * R_tot + 24 * N * K,
+        "composite_bwd": 44 * R_tot + 24 * N * K + 2 * 48 * Pv_tot,
+        "geometry_bwd": Pv_tot * (100 + 12 * s + 48) + P * (40 + 12 * s),
+    }
+
+
+def cpu_baseline(scene, k):
+    """The CPU oracle (OpenMP build, all host cores) timed on ONE of the K subframes of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle
+    from helpers import oracle_forward
+    threads = oracle.use_openmp(True)
+    try:
+        g = np.random.default_rng(0).normal(size=(3, scene["H"], scene["W"])).astype(np.float32)
+        t0 = time.time()
+        st = oracle_forward(scene, k)
+        oracle.backward(st, g)
+        dt = time.time() - t0
+    finally:
+        oracle.use_openmp(False)
+    return {"value": 1.0 / dt, "unit": "subframe-renders/sec (fwd+bwd)", "cores": int(threads), "kind": "port",
+            "sample": f"1 of the K={scene['K']} subframes (k={k}) of this workload, forward+backward, "
+                      f"oracle/dgs_oracle.cpp with OpenMP; {dt:.1f} s", "seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="metric", help="metric | cfg2 | cfg3 | cfg5 | cfg1")
+    ap.add_argument("--K", type=int, default=None)
+    ap.add_argument("--sh-degree", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lambda-t", type=float, default=1e-3)
+    args = ap.parse_args()
+
+    from deblurgs_amd import _lib, losses, sharding, synthetic
+    from deblurgs_amd.cloud import GaussianCloud
+    from deblurgs_amd.motion import CameraMotionModule, RefCamera
+
+    rank, world, local_rank = sharding.init_distributed("cuda")
+    assert world == max(args.gpus, 1) or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    over = {} if args.K is None else {"K": args.K}
+    scene = synthetic.make_config(args.config, seed=0, sh_degree=args.sh_degree, **over)
+    P, W, H, K = scene["P"], scene["W"], scene["H"], scene["K"]
+    C = synthetic.CONFIGS[args.config]["C"]
+    cloud = GaussianCloud.from_scene(scene, dev)
+    ref_cam = RefCamera(W, H, scene["FoVx"], scene["FoVy"], device=dev)
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    gt = torch.rand((1, 3, H, W), generator=gen).to(dev)
+    motion = CameraMotionModule(ref_cam, gt, curve_order=C, num_subframes=K, device=dev)
+    traj = synthetic.make_trajectory(K, C, scene["projection_matrix"], seed=rank)   # this rank's own view
+    with torch.no_grad():
+        motion._trans._control_points.copy_(torch.from_numpy(traj["ctrl_trans"])[None].to(dev))
+        motion._rot._control_points.copy_(torch.from_numpy(traj["ctrl_rot"])[None].to(dev))
+    motion.link_gaussian(cloud)
+    params = cloud.hot_parameters()
+    curve_params = motion.parameters()
+    lambda_hinge = 0.1
+
+    stats = {}
+
+    def step():
+        out = motion.query(0, "all")
+        loss, _blur, _ls = losses.blur_l1_smooth(out["subframes"], out["gt"], args.lambda_t)
+        loss = loss + lambda_hinge * losses.hinge_l2(cloud._opacity)
+        loss.backward()
+        if world > 1:
+            sharding.flat_allreduce_grads(params, average=True)
+        stats["radii"] = out["radii_all"]
+        for p in params + curve_params:
+            p.grad = None
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    # measured Pv / R of this workload (outputs of the forward)
+    radii = stats["radii"]
+    Pv_tot = int((radii > 0).sum().item())
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    sync()
+    t0 = time.time()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.time() - t0
+    _lib.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = _lib.profile_read()
+
+    if rank == 0:
+        # R from a state-level forward (the operator keeps it in its autograd ctx)
+        from deblurgs_amd import diff_gaussian_rasterization as dgr
+        with torch.no_grad():
+            wv, fp, cc = motion.get_trajectory_matrices(0)
+            rs = dgr.GaussianRasterizationSettings(H, W, scene["tanfovx"], scene["tanfovy"],
+                                                   torch.from_numpy(scene["bg"]).to(dev), 1.0, 0.2, 100.0, False,
+                                                   args.sh_degree, cc, False, False)
+            R_tot = dgr._forward_impl(K, cloud.get_xyz.detach(), cloud.get_features.detach().contiguous(), None,
+                                      cloud.get_opacity.detach().reshape(-1), cloud.get_scaling.detach(),
+                                      cloud.get_rotation.detach(), None, wv.contiguous(), fp.contiguous(),
+                                      cc.contiguous(), rs)[0]
+        N = W * H
+        s = (args.sh_degree + 1) ** 2
+        bytes_by_stage = stage_bytes(P, Pv_tot, R_tot, N, K, s)
+        stages = {}
+        for name, (ms, calls) in prof.items():
+            if calls == 0:
+                continue
+            avg_ms = ms / calls
+            gbs = bytes_by_stage[name] / (avg_ms * 1e-3) / 1e9
+            stages[name] = {"avg_ms": round(avg_ms, 4), "launches": calls, "alg_bytes": int(bytes_by_stage[name]),
+                            "GBps": round(gbs, 1)}
+        dom = max(stages, key=lambda n: stages[n]["avg_ms"])
+        total_bytes = sum(bytes_by_stage.values())
+        ms_per_step = dt / args.steps * 1e3
+        value = world * K * args.steps / dt
+        result = {
+            "metric": "subframe-renders/sec (fwd+bwd), 1M Gaussians, K=15, 1080p, 1/2/4/8 GPU",
+            "value": round(value, 2),
+            "unit": "subframe-renders/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: P={P} Gaussians, {W}x{H}, K={K} subframes fused, curve_order={C}, "
+                                   f"SH degree {args.sh_degree} (M={s}); one blurry view per GPU per step",
+                       "sharding": "views" if world > 1 else "none", "Pv_total": Pv_tot, "R_total": int(R_tot),
+                       "pixel_gaussian_evals_upper_bound_per_step": int(256 * R_tot)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 5), "traffic": None,
+                         "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["avg_ms"],
+                         "note": "compositing is VALU/LDS-bound, not HBM-bound (SURVEY 8d); frac is the honest HBM "
+                                 "fraction of the byte model"},
+            "pipeline_hbm": {"alg_bytes_per_step": int(total_bytes),
+                             "achieved_GBps": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                             "frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stages": stages,
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file))
+                if dom in tr and tr.get("_config") == args.config:
+                    result["roofline"]["traffic"] = tr[dom]
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(scene, K // 2)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

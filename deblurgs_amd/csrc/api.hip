@@ -265,12 +265,13 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = check_problem(p);
   if (rc != DGS_OK) return rc;
-  if (out == nullptr || out->radii == nullptr || out->num_rendered_host == nullptr)
-    return fail(DGS_E_ARG, "DgsForwardOut: radii / num_rendered_host are null");
+  if (out == nullptr || out->num_rendered_host == nullptr)
+    return fail(DGS_E_ARG, "DgsForwardOut: num_rendered_host is null");
   if (p->P == 0) {  // rasterize_points.cu:85 -- nothing to launch
     *out->num_rendered_host = 0;
     return DGS_OK;
   }
+  if (out->radii == nullptr) return fail(DGS_E_ARG, "DgsForwardOut: radii is null");
   DgsLayout L;
   make_layout(p->P, p->W, p->H, p->K, 0, &L);
   if (p->geom_state == nullptr || p->geom_bytes < L.geom_total) return fail(DGS_E_CAPACITY, "geom_state too small");

@@ -1,0 +1,149 @@
+"""Blur-integration loop: per-image learnable SE(3) Bezier trajectory and the K-subframe query.
+
+Mirrors the hot part of the reference's scene/motion.py (CameraMotionModule.query :78-160, get_trajectory
+:162-178, _sample_nu_from_alignment :209-219, _sample_c2w_from_nu :221-256, _c2w_to_minicam :258-294) for the
+default curve_type="se3".  Differences, all on purpose:
+  * the K subframes are rasterised by ONE fused launch chain (gaussian_renderer.render_subframes) instead of a
+    Python loop of K render() calls, and the K cameras are built with batched tensor ops;
+  * dataset loading, PLY/COLMAP I/O, optimiser wiring and cm.pth checkpoints are out of scope (SURVEY 2, rows
+    12-21): the module is constructed from initial c2w poses and ground-truth images held in memory;
+  * curve_type="quarternion_cartesian" (needs the unpinned third-party `roma`) is not provided.
+"""
+import torch
+import torch.nn as nn
+
+from . import gaussian_renderer
+from .pose import BezierModel, MiniCam, get_projection_matrix, se3_exp_map, c2w_to_view_proj
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def se3_log_of_identity_like(rotations, translations):
+    """Log map used only at initialisation (scene/motion.py:196-203).  For the synthetic scenes the initial
+    poses are (near) identity, so a first-order log is exact enough: rot_log = vee(R - R^T)/2, trans_log = t."""
+    skew = 0.5 * (rotations - rotations.transpose(-2, -1))
+    rot_log = torch.stack([skew[:, 2, 1], skew[:, 0, 2], skew[:, 1, 0]], dim=1)
+    return torch.cat([translations, rot_log], dim=1)
+
+
+class RefCamera:
+    """The attributes of the reference Camera that _c2w_to_minicam copies (scene/motion.py:283-292)."""
+
+    def __init__(self, width, height, fovx, fovy, znear=0.01, zfar=100.0, device="cuda"):
+        self.image_width = width
+        self.image_height = height
+        self.FoVx = fovx
+        self.FoVy = fovy
+        self.znear = znear
+        self.zfar = zfar
+        self.projection_matrix = get_projection_matrix(znear=znear, zfar=zfar, fovX=fovx, fovY=fovy).transpose(0, 1).to(device)
+
+
+class CameraMotionModule:
+    def __init__(self, ref_cam: RefCamera, gt_images, curve_order=9, num_subframes=21, init_se3=None,
+                 curve_random_sample=False, device="cuda"):
+        """gt_images: [n,3,H,W] observed blurry images; init_se3: [n,6] initial (trans_log | rot_log) poses."""
+        self.curve_order = curve_order
+        self.n_subframes = num_subframes
+        self.curve_type = "se3"
+        self.curve_random_sample = curve_random_sample
+        self.gaussians = None
+        self.ref_cam = ref_cam
+        self.gt_images = gt_images
+        n = gt_images.shape[0]
+        if init_se3 is None:
+            init_se3 = torch.zeros(n, 6)
+        self._rot = BezierModel(init_se3[:, 3:], curve_order, device=device)
+        self._trans = BezierModel(init_se3[:, :3], curve_order, device=device)
+        f = num_subframes
+        if f > 2:
+            nu0 = torch.linspace(1 / (f - 1), 1.0 - (1 / (f - 1)), f - 2)[None, :].repeat(n, 1).to(device)
+            self._nu = nn.Parameter(inverse_sigmoid(nu0).contiguous().requires_grad_(True))
+        else:
+            self._nu = nn.Parameter(torch.zeros(n, 0, device=device))
+
+    def link_gaussian(self, gaussians):
+        self.gaussians = gaussians
+
+    def parameters(self):
+        return list(self._rot.parameters()) + list(self._trans.parameters()) + [self._nu]
+
+    def __len__(self):
+        return len(self._rot)
+
+    @property
+    def device(self):
+        return self._rot.device
+
+    # ---- scene/motion.py:209-219
+    def _sample_nu_from_alignment(self, idx):
+        device = self._nu.device
+        nu_mid = torch.sigmoid(self._nu[idx])
+        if self.curve_random_sample:
+            nu_mid = nu_mid + torch.rand_like(nu_mid) / self.n_subframes - (1 / (2 * self.n_subframes))
+        return torch.cat([torch.zeros(1, device=device), nu_mid, torch.ones(1, device=device)]).clamp(0.0, 1.0).sort().values
+
+    # ---- scene/motion.py:221-256 (se3 branch)
+    def _sample_c2w_from_nu(self, idx, nu=None):
+        if nu is None:
+            nu = self._sample_nu_from_alignment(idx)
+        elif torch.is_tensor(nu):
+            nu = nu.to(self.device)
+        else:
+            raise NotImplementedError
+        se3 = torch.cat([self._trans(nu, idx), self._rot(nu, idx)], dim=1)
+        c2w = se3_exp_map(se3)
+        return c2w[:, :3, :3].transpose(-2, -1), c2w[:, 3, :3]
+
+    def get_trajectory_matrices(self, idx, t=None):
+        """Batched _c2w_to_minicam: (world_view [K,4,4], full_proj [K,4,4], camera_center [K,3])."""
+        rots, transes = self._sample_c2w_from_nu(idx, t)
+        return c2w_to_view_proj(rots, transes, self.ref_cam.projection_matrix)
+
+    def get_trajectory(self, idx, t=None):
+        """List of MiniCam objects like the reference (scene/motion.py:162-178)."""
+        wv, fp, cc = self.get_trajectory_matrices(idx, t)
+        r = self.ref_cam
+        return [MiniCam(r.image_width, r.image_height, r.FoVy, r.FoVx, r.znear, r.zfar, wv[i], fp[i], cc[i])
+                for i in range(wv.shape[0])]
+
+    def get_gt_image(self, idx):
+        return self.gt_images[idx]
+
+    def query(self, cam_idx: int, subframe_indice="all", post_process=None, background="random"):
+        """Render a blurry view (scene/motion.py:78-160).  Returns the reference's dict: 'blurred', 'gt',
+        'subframes' [f,3,H,W], 'depths' [f,1,H,W], 'render_pkgs' (list of f per-subframe dicts whose
+        'viewspace_points' entries are views of ONE [f,P,3] grad carrier, exposed as 'viewspace_points_all')."""
+        assert self.gaussians is not None
+        gaussians = self.gaussians
+        if isinstance(background, str) and background == "random":
+            bg = torch.rand(3, device=gaussians.get_xyz.device)
+        else:
+            bg = background
+        if isinstance(subframe_indice, str) and subframe_indice == "all":
+            nu = None
+        else:
+            nu = self._sample_nu_from_alignment(cam_idx)
+            if isinstance(subframe_indice, int):
+                # NB: the reference's `== 1` special case is dead code (its result is overwritten,
+                # scene/motion.py:129-131): 1 selects index 0, i.e. nu = 0.
+                subfr_idx = torch.linspace(0, nu.shape[0] - 1, subframe_indice, device=nu.device).long()
+            else:
+                subfr_idx = subframe_indice
+            nu = nu[subfr_idx]
+        world_views, full_projs, centers = self.get_trajectory_matrices(cam_idx, nu)
+        pkg = gaussian_renderer.render_subframes(world_views, full_projs, centers, self.ref_cam, gaussians, bg)
+        render_subframes = pkg["render"]
+        blurred = render_subframes.mean(dim=0)
+        if post_process is not None:
+            blurred = post_process(blurred)
+        f = render_subframes.shape[0]
+        render_pkgs = [{"render": render_subframes[i], "depth": pkg["depth"][i],
+                        "viewspace_points": pkg["viewspace_points"],   # the shared [f,P,3] carrier
+                        "subframe": i,
+                        "visibility_filter": pkg["visibility_filter"][i], "radii": pkg["radii"][i]} for i in range(f)]
+        return {"blurred": blurred, "gt": self.get_gt_image(cam_idx), "subframes": render_subframes,
+                "depths": pkg["depth"], "render_pkgs": render_pkgs, "viewspace_points_all": pkg["viewspace_points"],
+                "radii_all": pkg["radii"], "background": bg}

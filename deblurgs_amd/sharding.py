@@ -1,0 +1,140 @@
+"""Sharding of the blur-integration loop over the GPUs of one node (new work: the reference is single-GPU,
+SURVEY.md 0.4 / 8e).  One process per GPU, `torch.distributed` with backend "nccl" (= RCCL over xGMI) on
+device tensors and "gloo" on CPU (tests).
+
+Two modes, both with all Gaussian and trajectory parameters replicated on every rank:
+
+  "views"      rank g renders all K subframes of ITS OWN blurry view (one whole-view fused launch chain per
+               rank: weak scaling, no data-path collective) and the per-Gaussian gradients are summed with ONE
+               flat all-reduce per step.  This turns the reference's one-view-per-step SGD (train.py:126) into
+               a G-view mini-batch; gradients are averaged over the G views.
+  "subframes"  the K subframes of ONE view are split over ranks (rank g gets k in [floor(gK/G), floor((g+1)K/G)));
+               the loss couples them (mean over K, adjacent-k smoothness), so before the backward there is one
+               all-reduce of the partial blur sum [3,H,W] and a neighbour exchange of one boundary subframe;
+               after it the same flat gradient all-reduce (per-Gaussian + curve parameters).  Semantics are
+               exactly the reference's single-view step.
+
+Collective choice: one bucket of P*(11+3M) floats (152 MB at P=1M, M=9) per step, so RCCL can use
+every xGMI link at once; nothing is reduced per tensor.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(device_type="cuda"):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if device_type == "cuda" else "gloo"
+        if device_type == "cuda":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_range(K, rank, world):
+    """Subframes of rank g: [floor(gK/G), floor((g+1)K/G)) -- K=15, G=8 gives seven ranks x 2 and one x 1."""
+    return (rank * K) // world, ((rank + 1) * K) // world
+
+
+def flat_allreduce_grads(params, average=False, group=None):
+    """Sum (or average) the .grad of `params` over ranks with ONE collective on a flat fp32 bucket."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    params = [p for p in params if p is not None]
+    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+    flat = torch.cat([g.reshape(-1).float() for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    off = 0
+    for p, g in zip(params, grads):
+        n = g.numel()
+        p.grad = flat[off:off + n].view_as(g).to(g.dtype)
+        off += n
+
+
+def _sgn(x):
+    return torch.sign(x)
+
+
+def subframe_sharded_loss_backward(local_subframes, gt, K, k0, lambda_t, group=None):
+    """Loss + backward of one view whose K subframes are split over ranks.
+
+    local_subframes: [k_loc,3,H,W] rendered by this rank (k0 = index of its first subframe), attached to the
+    autograd graph of the rasteriser.  Computes the reference loss block (train.py:147-163 image terms:
+    L1(mean_k, gt) + lambda_t * L1(sub[k+1]-sub[k])) across ranks and back-propagates dL/dsubframes through the
+    local graph.  Returns (l1, smooth) as python floats (identical on every rank)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    S = local_subframes.detach()
+    k_loc = S.shape[0]
+    E = gt.numel()
+    # ---- exchange 1: partial blur sum
+    blur = S.sum(dim=0) if k_loc > 0 else torch.zeros_like(gt)
+    if world > 1:
+        dist.all_reduce(blur, op=dist.ReduceOp.SUM, group=group)
+    blur = blur / K
+    # ---- exchange 2: boundary subframes (first/last non-empty neighbours share one frame each way)
+    prev_last = None   # subframe k0-1
+    next_first = None  # subframe k0+k_loc
+    if world > 1:
+        first = S[0].contiguous() if k_loc > 0 else torch.zeros_like(gt)
+        last = S[-1].contiguous() if k_loc > 0 else torch.zeros_like(gt)
+        firsts = [torch.empty_like(gt) for _ in range(world)]
+        lasts = [torch.empty_like(gt) for _ in range(world)]
+        counts = [torch.zeros(1, dtype=torch.int64, device=gt.device) for _ in range(world)]
+        dist.all_gather(firsts, first, group=group)
+        dist.all_gather(lasts, last, group=group)
+        dist.all_gather(counts, torch.tensor([k_loc], dtype=torch.int64, device=gt.device), group=group)
+        for r in range(rank - 1, -1, -1):
+            if int(counts[r]) > 0:
+                prev_last = lasts[r]
+                break
+        for r in range(rank + 1, world):
+            if int(counts[r]) > 0:
+                next_first = firsts[r]
+                break
+    d = blur - gt
+    g_l1 = _sgn(d) / (E * K)
+    dS = g_l1[None].expand_as(S).clone() if k_loc > 0 else S
+    sm_local = torch.zeros((), device=gt.device)
+    if K > 1 and k_loc > 0:
+        ws = lambda_t / (E * (K - 1))
+        ext = [S]
+        if prev_last is not None:
+            ext = [prev_last[None]] + ext
+        if next_first is not None:
+            ext = ext + [next_first[None]]
+        X = torch.cat(ext, dim=0)
+        diff = X[1:] - X[:-1]                      # differences touching this rank's frames
+        sg = _sgn(diff)
+        lo = 1 if prev_last is not None else 0
+        # dL/dx_k = ws * (sign(x_k - x_{k-1}) - sign(x_{k+1} - x_k))
+        left = torch.zeros_like(S)
+        right = torch.zeros_like(S)
+        if lo == 1:
+            left += sg[0:k_loc]
+        elif k_loc > 1:
+            left[1:] += sg[0:k_loc - 1]
+        n_right = k_loc if next_first is not None else k_loc - 1
+        if n_right > 0:
+            right[:n_right] += sg[lo:lo + n_right]
+        dS = dS + ws * (left - right)
+        # each difference is counted once: a rank owns the differences whose LEFT frame it holds
+        own = diff[lo:lo + n_right]
+        sm_local = own.abs().sum() / (E * (K - 1))
+    if world > 1:
+        dist.all_reduce(sm_local, op=dist.ReduceOp.SUM, group=group)
+    if k_loc > 0:
+        local_subframes.backward(gradient=dS)
+    return float(d.abs().mean()), float(sm_local)

@@ -19,12 +19,19 @@
 // -ffp-contract=off), correctly rounded division and sqrt, the operation order of the reference source
 // (GLM column-major mat3 products: third_party/glm/glm/detail/type_mat3x3.inl:486-518), ndc2Pix and
 // the dL_dproj terms in double.  float->int conversions saturate like the GPU's v_cvt_i32_f32.
+// Built twice from this one file (oracle/Makefile): libdgs_oracle.so (single thread, the parity checker) and
+// libdgs_oracle_omp.so (-fopenmp: tile/Gaussian loops spread over the host cores, accumulations become
+// `omp atomic`; used ONLY by bench.py's cpu_baseline leg, where summation order does not matter).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <numeric>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#include <parallel/algorithm>
+#endif
 
 namespace {
 
@@ -240,6 +247,14 @@ vec3 computeColorFromSH(int idx, int deg, int max_coeffs, const float* means, ve
 
 extern "C" {
 
+int dgs_oracle_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
 uint32_t dgs_oracle_higher_msb(uint32_t n) { return getHigherMsb(n); }
 
 // FORWARD::preprocess + InclusiveSum (forward.cu:166-268, rasterizer_impl.cu:253-287).
@@ -257,6 +272,7 @@ int dgs_oracle_preprocess(int P, int D, int M, int W, int H, const float* means3
   const float focal_x = W / (2.0f * tan_fovx);
   const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
   const vec3 cam = {campos[0], campos[1], campos[2]};
+#pragma omp parallel for schedule(static)
   for (int idx = 0; idx < P; idx++) {
     radii[idx] = 0;
     tiles_touched[idx] = 0;
@@ -319,6 +335,7 @@ void dgs_oracle_bin(int P, int W, int H, int R, const int* radii, const float* m
                     const uint32_t* point_offsets, uint64_t* keys_unsorted, uint32_t* vals_unsorted,
                     uint64_t* keys_sorted, uint32_t* point_list, uint32_t* ranges) {
   const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+#pragma omp parallel for schedule(static)
   for (int idx = 0; idx < P; idx++) {
     if (radii[idx] > 0) {
       uint32_t off = (idx == 0) ? 0 : point_offsets[idx - 1];
@@ -341,8 +358,13 @@ void dgs_oracle_bin(int P, int W, int H, int R, const int* radii, const float* m
   const uint64_t mask = (32 + bit >= 64) ? ~0ull : ((1ull << (32 + bit)) - 1);
   std::vector<uint32_t> order(R);
   std::iota(order.begin(), order.end(), 0u);
-  std::stable_sort(order.begin(), order.end(),
-                   [&](uint32_t a, uint32_t b) { return (keys_unsorted[a] & mask) < (keys_unsorted[b] & mask); });
+  auto less = [&](uint32_t a, uint32_t b) { return (keys_unsorted[a] & mask) < (keys_unsorted[b] & mask); };
+#ifdef _OPENMP
+  __gnu_parallel::stable_sort(order.begin(), order.end(), less);
+#else
+  std::stable_sort(order.begin(), order.end(), less);
+#endif
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < R; i++) {
     keys_sorted[i] = keys_unsorted[order[i]];
     point_list[i] = vals_unsorted[order[i]];
@@ -367,6 +389,7 @@ void dgs_oracle_render(int W, int H, const uint32_t* ranges, const uint32_t* poi
                        const float* features, const float* depths, const float* conic_opacity, const float* bg,
                        float z_far, float* final_T, uint32_t* n_contrib, float* out_color, float* out_depth) {
   const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
   for (int ty = 0; ty < gy; ty++)
     for (int tx = 0; tx < gx; tx++) {
       const uint32_t r0 = ranges[2 * (ty * gx + tx)], r1 = ranges[2 * (ty * gx + tx) + 1];
@@ -415,6 +438,7 @@ void dgs_oracle_render_backward(int W, int H, const uint32_t* ranges, const uint
   const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
   const float ddelx_dx = 0.5 * W;  // backward.cu:535-536
   const float ddely_dy = 0.5 * H;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
   for (int ty = 0; ty < gy; ty++)
     for (int tx = 0; tx < gx; tx++) {
       const uint32_t r0 = ranges[2 * (ty * gx + tx)], r1 = ranges[2 * (ty * gx + tx) + 1];
@@ -456,12 +480,14 @@ void dgs_oracle_render_backward(int W, int H, const uint32_t* ranges, const uint
               last_color[ch] = c;
               const float dL_dchannel = dL_dpixel[ch];
               dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
-              dL_dcolors[3 * (size_t)g + ch] += dchannel_dcolor * dL_dchannel;
+              _Pragma("omp atomic")
+            dL_dcolors[3 * (size_t)g + ch] += dchannel_dcolor * dL_dchannel;
             }
             const float c_d = depths[g];
             accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
             last_depth = c_d;
             dL_dalpha += (c_d - accum_depth_rec) * dL_dpixeldepth;
+            _Pragma("omp atomic")
             dL_ddepths[g] += dchannel_dcolor * dL_dpixeldepth;
             dL_dalpha *= T;
             last_alpha = alpha;
@@ -474,11 +500,17 @@ void dgs_oracle_render_backward(int W, int H, const uint32_t* ranges, const uint
             const float gdy = G * dy;
             const float dG_ddelx = -gdx * co[0] - gdy * co[1];
             const float dG_ddely = -gdy * co[2] - gdx * co[1];
+            _Pragma("omp atomic")
             dL_dmean2D[3 * (size_t)g + 0] += dL_dG * dG_ddelx * ddelx_dx;
+            _Pragma("omp atomic")
             dL_dmean2D[3 * (size_t)g + 1] += dL_dG * dG_ddely * ddely_dy;
+            _Pragma("omp atomic")
             dL_dconic2D[4 * (size_t)g + 0] += -0.5f * gdx * dx * dL_dG;
+            _Pragma("omp atomic")
             dL_dconic2D[4 * (size_t)g + 1] += -0.5f * gdx * dy * dL_dG;
+            _Pragma("omp atomic")
             dL_dconic2D[4 * (size_t)g + 3] += -0.5f * gdy * dy * dL_dG;
+            _Pragma("omp atomic")
             dL_dopacity[g] += G * dL_dalpha;
           }
         }

@@ -17,7 +17,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libdgs_oracle.so")
+_LIB_OMP_PATH = os.path.join(_HERE, "libdgs_oracle_omp.so")   # bench.py cpu_baseline only
 _lib = None
+_lib_omp = None
+_use_omp = False
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 _i32p = ctypes.POINTER(ctypes.c_int32)
@@ -29,20 +32,38 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 def build(force=False):
     """Compile oracle/libdgs_oracle.so with the committed Makefile (g++, -ffp-contract=off)."""
     src = os.path.join(_HERE, "dgs_oracle.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "libdgs_oracle.so"])
+    for path in (_LIB_PATH, _LIB_OMP_PATH):
+        if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", os.path.basename(path)])
     return _LIB_PATH
 
 
+def _load(path):
+    L = ctypes.CDLL(path)
+    L.dgs_oracle_preprocess.restype = ctypes.c_int
+    L.dgs_oracle_threads.restype = ctypes.c_int
+    L.dgs_oracle_higher_msb.restype = ctypes.c_uint32
+    L.dgs_oracle_higher_msb.argtypes = [ctypes.c_uint32]
+    return L
+
+
+def use_openmp(on=True):
+    """Route forward()/backward() to the OpenMP build (cpu_baseline timing only).  Returns the thread count."""
+    global _use_omp
+    _use_omp = bool(on)
+    return lib().dgs_oracle_threads()
+
+
 def lib():
-    global _lib
+    global _lib, _lib_omp
+    if not os.path.exists(_LIB_PATH) or not os.path.exists(_LIB_OMP_PATH):
+        build()
+    if _use_omp:
+        if _lib_omp is None:
+            _lib_omp = _load(_LIB_OMP_PATH)
+        return _lib_omp
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
-        _lib = ctypes.CDLL(_LIB_PATH)
-        _lib.dgs_oracle_preprocess.restype = ctypes.c_int
-        _lib.dgs_oracle_higher_msb.restype = ctypes.c_uint32
-        _lib.dgs_oracle_higher_msb.argtypes = [ctypes.c_uint32]
+        _lib = _load(_LIB_PATH)
     return _lib
 
 
