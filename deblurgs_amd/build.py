@@ -15,7 +15,8 @@ ARCH = "gfx950"
 SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
-    "composite.hip": [],
+    # SLP packing into v_pk_*_f32 costs more v_mov shuffles than it saves here (920 vs 715 VALU instructions)
+    "composite.hip": ["-fno-slp-vectorize"],
     "geometry_bwd.hip": [],
     "api.hip": [],
 }

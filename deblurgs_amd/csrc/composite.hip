@@ -32,7 +32,9 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t per_xcd) { re
 __device__ __forceinline__ bool load_tile_ctx(const DgsView& v, const uint2* __restrict__ ranges, uint32_t per_xcd,
                                               TileCtx& t) {
   const uint32_t logical = xcd_remap(blockIdx.x, per_xcd);
-  const uint32_t gw = logical * CW + (threadIdx.x >> 6);
+  // threadIdx.x >> 6 is wave-uniform, but the compiler only knows that through readfirstlane: without it the
+  // tile range, every loop bound and the ballot masks end up in VGPRs under exec-mask control flow.
+  const uint32_t gw = logical * CW + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t KT = (uint32_t)v.K * (uint32_t)v.T;
   if (gw >= KT) return false;
   t.k = (int)(gw / (uint32_t)v.T);
@@ -86,7 +88,7 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   __shared__ float2 s_c[CW][64];  // b, depth
   TileCtx t;
   if (!load_tile_ctx(v, ranges, per_xcd, t)) return;
-  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  const int lane = dgs_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lx = lane & 7, ly = lane >> 3;
   const int px0 = t.tx * DGS_TILE + lx, py0 = t.ty * DGS_TILE + ly;  // quadrant 0 pixel; +8 for the others
   const float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
@@ -145,30 +147,26 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       const float dx0 = a.x - pxf0, dx1 = a.x - pxf1, dy0 = a.y - pyf0, dy1 = a.y - pyf1;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        if ((m[q] >> j) & 1ull) {
-          if (!done[q]) {
-            const float dx = (q & 1) ? dx1 : dx0;
-            const float dy = (q >> 1) ? dy1 : dy0;
-            // forward.cu:348-368
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            if (power <= 0.0f) {
-              const float alpha = fminf(0.99f, b.y * __expf(power));
-              if (alpha >= 1.0f / 255.0f) {
-                const float test_T = T[q] * (1.0f - alpha);
-                if (test_T < 0.0001f) {
-                  done[q] = true;
-                } else {
-                  const float wgt = alpha * T[q];
-                  C0[q] += b.z * wgt;
-                  C1[q] += b.w * wgt;
-                  C2[q] += c.x * wgt;
-                  Dd[q] += c.y * wgt;
-                  T[q] = test_T;
-                  last[q] = base + (uint32_t)j + 1u;
-                }
-              }
-            }
-          }
+        if ((m[q] >> j) & 1ull) {  // wave-uniform: this Gaussian can reach quadrant q
+          const float dx = (q & 1) ? dx1 : dx0;
+          const float dy = (q >> 1) ? dy1 : dy0;
+          // forward.cu:348-380, branch-free: a pair that fails one of the reference's tests gets alpha = 0,
+          // which leaves T, C, D and `last` untouched (T >= 1e-4 always, so alpha = 0 can never terminate).
+          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+          const float alpha_raw = fminf(0.99f, b.y * __expf(power));
+          const bool ok = (!done[q]) && (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
+          const float alpha = ok ? alpha_raw : 0.0f;
+          const float test_T = T[q] * (1.0f - alpha);
+          const bool stop = test_T < 0.0001f;
+          const bool blend = ok && !stop;
+          const float wgt = blend ? alpha * T[q] : 0.0f;
+          C0[q] += b.z * wgt;
+          C1[q] += b.w * wgt;
+          C2[q] += c.x * wgt;
+          Dd[q] += c.y * wgt;
+          T[q] = blend ? test_T : T[q];
+          last[q] = blend ? (base + (uint32_t)j + 1u) : last[q];
+          done[q] = done[q] || stop;
         }
       }
     }
@@ -208,7 +206,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   __shared__ float4 s_acc[CW][64][3];  // per-duplicate gradient rows of the current batch
   TileCtx t;
   if (!load_tile_ctx(v, ranges, per_xcd, t)) return;
-  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  const int lane = dgs_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lx = lane & 7, ly = lane >> 3;
   const int px0 = t.tx * DGS_TILE + lx, py0 = t.ty * DGS_TILE + ly;
   const float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
@@ -297,53 +295,55 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       bool touched = false;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        if ((m[q] >> j) & 1ull) {
-          if (pos < last[q]) {
-            const float dx = (q & 1) ? dx1 : dx0;
-            const float dy = (q >> 1) ? dy1 : dy0;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            if (power <= 0.0f) {
-              const float G = __expf(power);
-              const float alpha = fminf(0.99f, b.y * G);
-              if (alpha >= 1.0f / 255.0f) {  // backward.cu:571-637
-                touched = true;
-                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
-                T[q] = T[q] * inv1ma;
-                const float dchannel_dcolor = alpha * T[q];
-                float dL_dalpha;
-                acc0[q] = lalpha[q] * lc0[q] + (1.f - lalpha[q]) * acc0[q];
-                lc0[q] = b.z;
-                dL_dalpha = (b.z - acc0[q]) * g0[q];
-                s_r += dchannel_dcolor * g0[q];
-                acc1[q] = lalpha[q] * lc1[q] + (1.f - lalpha[q]) * acc1[q];
-                lc1[q] = b.w;
-                dL_dalpha += (b.w - acc1[q]) * g1[q];
-                s_g += dchannel_dcolor * g1[q];
-                acc2[q] = lalpha[q] * lc2[q] + (1.f - lalpha[q]) * acc2[q];
-                lc2[q] = c.x;
-                dL_dalpha += (c.x - acc2[q]) * g2[q];
-                s_b_ += dchannel_dcolor * g2[q];
-                accd[q] = lalpha[q] * ldep[q] + (1.f - lalpha[q]) * accd[q];
-                ldep[q] = c.y;
-                dL_dalpha += (c.y - accd[q]) * gd[q];
-                s_d += dchannel_dcolor * gd[q];
-                dL_dalpha *= T[q];
-                lalpha[q] = alpha;
-                dL_dalpha += (-Tfin[q] * inv1ma) * bgdot[q];
-                const float dL_dG = b.y * dL_dalpha;
-                const float gdx = G * dx;
-                const float gdy = G * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * b.x - gdx * a.w;
-                s_mx += dL_dG * dG_ddelx * ddelx_dx;
-                s_my += dL_dG * dG_ddely * ddely_dy;
-                s_ca += -0.5f * gdx * dx * dL_dG;
-                s_cb += -0.5f * gdx * dy * dL_dG;
-                s_cc += -0.5f * gdy * dy * dL_dG;
-                s_op += G * dL_dalpha;
-              }
-            }
-          }
+        if ((m[q] >> j) & 1ull) {  // wave-uniform
+          const float dx = (q & 1) ? dx1 : dx0;
+          const float dy = (q >> 1) ? dy1 : dy0;
+          // backward.cu:566-637, branch-free.  A pair that the reference skips gets alpha = 0 and G = 0: then
+          // T/(1-alpha) = T, every gradient term is an exact 0, and the accum_rec recurrence
+          //   accum = last_alpha*last_c + (1-last_alpha)*accum;  last_c = c;  last_alpha = alpha
+          // merely applies its pending update early (the next valid pair would compute 0*c + 1*accum = accum),
+          // so the results are bit-identical to skipping.
+          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+          const float G_raw = __expf(power);
+          const float alpha_raw = fminf(0.99f, b.y * G_raw);
+          const bool ok = (pos < last[q]) && (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
+          touched = touched || ok;
+          const float G = ok ? G_raw : 0.0f;
+          const float alpha = ok ? alpha_raw : 0.0f;
+          const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+          T[q] = T[q] * inv1ma;
+          const float dchannel_dcolor = alpha * T[q];
+          const float oml = 1.f - lalpha[q];
+          acc0[q] = lalpha[q] * lc0[q] + oml * acc0[q];
+          acc1[q] = lalpha[q] * lc1[q] + oml * acc1[q];
+          acc2[q] = lalpha[q] * lc2[q] + oml * acc2[q];
+          accd[q] = lalpha[q] * ldep[q] + oml * accd[q];
+          lc0[q] = b.z;
+          lc1[q] = b.w;
+          lc2[q] = c.x;
+          ldep[q] = c.y;
+          lalpha[q] = alpha;
+          float dL_dalpha = (b.z - acc0[q]) * g0[q];
+          dL_dalpha += (b.w - acc1[q]) * g1[q];
+          dL_dalpha += (c.x - acc2[q]) * g2[q];
+          dL_dalpha += (c.y - accd[q]) * gd[q];
+          s_r += dchannel_dcolor * g0[q];
+          s_g += dchannel_dcolor * g1[q];
+          s_b_ += dchannel_dcolor * g2[q];
+          s_d += dchannel_dcolor * gd[q];
+          dL_dalpha *= T[q];
+          dL_dalpha += (-Tfin[q] * inv1ma) * bgdot[q];
+          const float dL_dG = b.y * dL_dalpha;
+          const float gdx = G * dx;
+          const float gdy = G * dy;
+          const float dG_ddelx = -gdx * a.z - gdy * a.w;
+          const float dG_ddely = -gdy * b.x - gdx * a.w;
+          s_mx += dL_dG * dG_ddelx * ddelx_dx;
+          s_my += dL_dG * dG_ddely * ddely_dy;
+          s_ca += -0.5f * gdx * dx * dL_dG;
+          s_cb += -0.5f * gdx * dy * dL_dG;
+          s_cc += -0.5f * gdy * dy * dL_dG;
+          s_op += G * dL_dalpha;
         }
       }
       if (__ballot(touched) != 0ull) {
