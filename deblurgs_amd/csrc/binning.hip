@@ -187,7 +187,8 @@ ranges_kernel(uint32_t L, const uint64_t* __restrict__ keys, uint2* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------ radix sort
-// Stable LSD radix sort, RB-bit digits (RB <= 9).  Per pass: (1) per-block digit histogram written
+// Stable LSD radix sort, RB-bit digits (RB <= 9; 10-bit digits were measured slower per key: 5 x 1.11 ms vs
+// 6 x 0.81 ms at the metric config).  Per pass: (1) per-block digit histogram written
 // digit-major [digit][block]; (2) exclusive scan of that table = global scatter bases; (3) scatter with
 // stable in-block ranks.  A block owns SORT_TILE consecutive pairs; wave w owns a contiguous quarter of them,
 // read in rounds of 64, so the stable order inside a block is (wave, round, lane).

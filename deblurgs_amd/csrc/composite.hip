@@ -6,7 +6,7 @@
 //     barriers, no __syncthreads_count: termination votes and culling masks are 64-bit ballots in SGPRs.
 //   * The tile's sorted duplicate list is consumed in batches of 64: lane j gathers Gaussian j's 48-byte
 //     geometry row with three 16-byte loads, tests its alpha>=1/255 ellipse against the four quadrants
-//     (conservative bounding box) and publishes the row to LDS.  The per-Gaussian loop then walks only the
+//     (exact ellipse/box minimum with rounding slack) and publishes the row to LDS.  The per-Gaussian loop then walks only the
 //     set bits of the ballot masks, so a (Gaussian, quadrant) pair that cannot contribute costs nothing.
 //     Culling is conservative, hence the per-pixel tests below are exactly the reference's.
 //   * Backward: no global atomics.  The 10 per-Gaussian partial gradients are summed over a lane's pixels
@@ -17,6 +17,8 @@
 #include "dgs_common.h"
 
 namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));  // lowers to v_pk_{mul,add,fma}_f32 on gfx950
 
 constexpr int CW = 4;  // waves (= tiles) per 256-thread block; the waves never synchronise with each other
 
@@ -47,34 +49,50 @@ __device__ __forceinline__ bool load_tile_ctx(const DgsView& v, const uint2* __r
   return true;
 }
 
-// Conservative test: can Gaussian (x, y, conic cx/cy/cz, opacity op) reach alpha >= 1/255 anywhere in the
-// pixel square [qx0, qx0+7] x [qy0, qy0+7]?  alpha = op*exp(power) >= 1/255  <=>  q(d) <= 2 ln(255 op), and
-// the bounding box of that ellipse has half extents sqrt(r2*cz/det), sqrt(r2*cx/det).
-struct CullBox {
-  float x0, x1, y0, y1;  // inclusive pixel bounds the ellipse can touch
-  bool any;
+// Conservative-but-tight test: can Gaussian (x, y, conic a/b/c, opacity op) reach alpha >= 1/255 at some pixel
+// centre of the 8x8 quadrant?  alpha = op*exp(power) >= 1/255  <=>  q(d) = a dx^2 + 2 b dx dy + c dy^2 <= r2 with
+// r2 = 2 ln(255 op), so the question is whether the minimum of the convex quadratic q over the box
+// d in [dx_lo, dx_hi] x [dy_lo, dy_hi] (d = mean - pixel) is <= r2.  The minimum is 0 if the box contains the
+// origin, otherwise it sits on one of the four edges, where q is a 1-D quadratic with a closed-form clamped
+// minimiser.  A slack on r2 and a relative slack on q keep it conservative under fp32 rounding, so the exact
+// per-pixel tests of the reference still decide every pair that survives.
+struct CullGauss {
+  float a, b, c, inv_a, inv_c, r2;
+  bool always;  // degenerate conic: never cull
+  bool never;   // opacity too small to ever reach 1/255
 };
-__device__ __forceinline__ CullBox make_cullbox(float x, float y, float cx, float cy, float cz, float op) {
-  CullBox c;
+__device__ __forceinline__ CullGauss make_cull(float cx, float cy, float cz, float op) {
+  CullGauss g;
+  g.a = cx;
+  g.b = cy;
+  g.c = cz;
+  g.r2 = 2.0f * __logf(255.0f * op) + 0.02f;  // slack >> fp32 error of `power`
   const float det = cx * cz - cy * cy;
-  const float r2 = 2.0f * __logf(255.0f * op) + 0.02f;  // slack >> fp32 error of `power`
-  c.any = !(r2 < 0.0f);                                  // NaN -> keep
-  float hx = 3.0e38f, hy = 3.0e38f;
-  if (det > 0.0f && r2 >= 0.0f) {
-    const float inv = 1.0f / det;
-    hx = sqrtf(r2 * cz * inv) * 1.001f + 0.01f;
-    hy = sqrtf(r2 * cx * inv) * 1.001f + 0.01f;
-    if (!(hx == hx)) hx = 3.0e38f;
-    if (!(hy == hy)) hy = 3.0e38f;
-  }
-  c.x0 = x - hx;
-  c.x1 = x + hx;
-  c.y0 = y - hy;
-  c.y1 = y + hy;
-  return c;
+  g.always = !(det > 0.0f && cx > 0.0f && cz > 0.0f);  // also catches NaN
+  g.never = (g.r2 < 0.0f);
+  g.inv_a = 1.0f / cx;
+  g.inv_c = 1.0f / cz;
+  return g;
 }
-__device__ __forceinline__ bool cull_hit(const CullBox& c, float qx0, float qy0) {
-  return c.any && (c.x1 >= qx0) && (c.x0 <= qx0 + 7.0f) && (c.y1 >= qy0) && (c.y0 <= qy0 + 7.0f);
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
+// min over dy in [lo, hi] of q(e, dy)
+__device__ __forceinline__ float edge_min_x(const CullGauss& g, float e, float lo, float hi) {
+  const float t = clampf(-g.b * e * g.inv_c, lo, hi);
+  return g.a * e * e + (2.0f * g.b * e + g.c * t) * t;
+}
+// min over dx in [lo, hi] of q(dx, e)
+__device__ __forceinline__ float edge_min_y(const CullGauss& g, float e, float lo, float hi) {
+  const float t = clampf(-g.b * e * g.inv_a, lo, hi);
+  return g.c * e * e + (2.0f * g.b * e + g.a * t) * t;
+}
+__device__ __forceinline__ bool cull_hit(const CullGauss& g, float dx_lo, float dx_hi, float dy_lo, float dy_hi) {
+  if (g.always) return true;
+  if (g.never) return false;
+  const bool inside = (dx_lo <= 0.0f) && (dx_hi >= 0.0f) && (dy_lo <= 0.0f) && (dy_hi >= 0.0f);
+  float qm = fminf(fminf(edge_min_x(g, dx_lo, dy_lo, dy_hi), edge_min_x(g, dx_hi, dy_lo, dy_hi)),
+                   fminf(edge_min_y(g, dy_lo, dx_lo, dx_hi), edge_min_y(g, dy_hi, dx_lo, dx_hi)));
+  qm = inside ? 0.0f : qm;
+  return !(qm * 0.9999f > g.r2);  // NaN -> keep
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -122,11 +140,13 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       B = rp[1];
       Cc = rp[2];
     }
-    const CullBox cb = make_cullbox(A.x, A.y, A.z, A.w, B.x, B.y);
+    const CullGauss cg = make_cull(A.z, A.w, B.x, B.y);
     uint64_t m[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const bool hit = has && cull_hit(cb, qx0 + (float)((q & 1) * 8), qy0 + (float)((q >> 1) * 8));
+      // d = mean - pixel over the quadrant's pixel centres [q0, q0+7]
+      const float ex = A.x - (qx0 + (float)((q & 1) * 8)), ey = A.y - (qy0 + (float)((q >> 1) * 8));
+      const bool hit = has && cull_hit(cg, ex - 7.0f, ex, ey - 7.0f, ey);
       const uint64_t bh = __ballot(hit);
       m[q] = alive[q] ? bh : 0ull;
     }
@@ -215,8 +235,9 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const float ddelx_dx = 0.5f * (float)v.W, ddely_dy = 0.5f * (float)v.H;  // backward.cu:535-536
 
-  float T[4], Tfin[4], acc0[4], acc1[4], acc2[4], accd[4], lalpha[4], lc0[4], lc1[4], lc2[4], ldep[4];
-  float g0[4], g1[4], g2[4], gd[4], bgdot[4];
+  // per-pixel channel state kept as (r,g) and (b,depth) pairs so the channel arithmetic issues as packed fp32
+  float T[4], Tfin[4], lalpha[4], bgdot[4];
+  v2f accA[4], accB[4], lcA[4], lcB[4], gA[4], gB[4];
   uint32_t last[4];
   uint32_t maxc = 0;
 #pragma unroll
@@ -228,13 +249,15 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     T[q] = Tfin[q];
     last[q] = inside ? n_contrib[(size_t)t.k * N + pix] : 0u;
     const float* gp = dL_dpix + (size_t)t.k * 3 * N;
-    g0[q] = inside ? gp[pix] : 0.0f;
-    g1[q] = inside ? gp[N + pix] : 0.0f;
-    g2[q] = inside ? gp[2 * N + pix] : 0.0f;
-    gd[q] = (inside && dL_ddepth != nullptr) ? dL_ddepth[(size_t)t.k * N + pix] : 0.0f;
-    bgdot[q] = bg0 * g0[q] + bg1 * g1[q] + bg2 * g2[q] + v.z_far * gd[q];  // backward.cu:613-617
-    acc0[q] = acc1[q] = acc2[q] = accd[q] = 0.0f;
-    lalpha[q] = lc0[q] = lc1[q] = lc2[q] = ldep[q] = 0.0f;
+    const float g0 = inside ? gp[pix] : 0.0f;
+    const float g1 = inside ? gp[N + pix] : 0.0f;
+    const float g2 = inside ? gp[2 * N + pix] : 0.0f;
+    const float gd = (inside && dL_ddepth != nullptr) ? dL_ddepth[(size_t)t.k * N + pix] : 0.0f;
+    gA[q] = (v2f){g0, g1};
+    gB[q] = (v2f){g2, gd};
+    bgdot[q] = bg0 * g0 + bg1 * g1 + bg2 * g2 + v.z_far * gd;  // backward.cu:613-617
+    accA[q] = accB[q] = lcA[q] = lcB[q] = (v2f){0.0f, 0.0f};
+    lalpha[q] = 0.0f;
     maxc = max(maxc, last[q]);
   }
   // wave-wide max of n_contrib: entries at or beyond it are skipped by every pixel (backward.cu:566-568)
@@ -263,11 +286,11 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     }
     uint64_t m[4] = {0, 0, 0, 0};
     if (base < maxc) {
-      const CullBox cb = make_cullbox(A.x, A.y, A.z, A.w, B.x, B.y);
+      const CullGauss cg = make_cull(A.z, A.w, B.x, B.y);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const bool hit = has && (base + lane < maxc) &&
-                         cull_hit(cb, qx0 + (float)((q & 1) * 8), qy0 + (float)((q >> 1) * 8));
+        const float ex = A.x - (qx0 + (float)((q & 1) * 8)), ey = A.y - (qy0 + (float)((q >> 1) * 8));
+        const bool hit = has && (base + lane < maxc) && cull_hit(cg, ex - 7.0f, ex, ey - 7.0f, ey);
         m[q] = __ballot(hit);
       }
       s_a[w][lane] = A;
@@ -291,7 +314,9 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       const float2 c = s_c[w][j];
       const uint32_t pos = base + (uint32_t)j;  // 0-based position in the tile list
       const float dx0 = a.x - pxf0, dx1 = a.x - pxf1, dy0 = a.y - pyf0, dy1 = a.y - pyf1;
-      float s_mx = 0, s_my = 0, s_ca = 0, s_cb = 0, s_cc = 0, s_op = 0, s_r = 0, s_g = 0, s_b_ = 0, s_d = 0;
+      float s_mx = 0, s_my = 0, s_ca = 0, s_cb = 0, s_cc = 0, s_op = 0;
+      v2f sA = {0.0f, 0.0f}, sB = {0.0f, 0.0f};  // (dL_dr, dL_dg), (dL_db, dL_ddepth)
+      const v2f colA = {b.z, b.w}, colB = {c.x, c.y};
       bool touched = false;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -314,23 +339,15 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           T[q] = T[q] * inv1ma;
           const float dchannel_dcolor = alpha * T[q];
           const float oml = 1.f - lalpha[q];
-          acc0[q] = lalpha[q] * lc0[q] + oml * acc0[q];
-          acc1[q] = lalpha[q] * lc1[q] + oml * acc1[q];
-          acc2[q] = lalpha[q] * lc2[q] + oml * acc2[q];
-          accd[q] = lalpha[q] * ldep[q] + oml * accd[q];
-          lc0[q] = b.z;
-          lc1[q] = b.w;
-          lc2[q] = c.x;
-          ldep[q] = c.y;
+          accA[q] = lcA[q] * lalpha[q] + accA[q] * oml;
+          accB[q] = lcB[q] * lalpha[q] + accB[q] * oml;
+          lcA[q] = colA;
+          lcB[q] = colB;
           lalpha[q] = alpha;
-          float dL_dalpha = (b.z - acc0[q]) * g0[q];
-          dL_dalpha += (b.w - acc1[q]) * g1[q];
-          dL_dalpha += (c.x - acc2[q]) * g2[q];
-          dL_dalpha += (c.y - accd[q]) * gd[q];
-          s_r += dchannel_dcolor * g0[q];
-          s_g += dchannel_dcolor * g1[q];
-          s_b_ += dchannel_dcolor * g2[q];
-          s_d += dchannel_dcolor * gd[q];
+          const v2f dd = (colA - accA[q]) * gA[q] + (colB - accB[q]) * gB[q];
+          float dL_dalpha = dd.x + dd.y;
+          sA += gA[q] * dchannel_dcolor;
+          sB += gB[q] * dchannel_dcolor;
           dL_dalpha *= T[q];
           dL_dalpha += (-Tfin[q] * inv1ma) * bgdot[q];
           const float dL_dG = b.y * dL_dalpha;
@@ -353,10 +370,10 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         s_cb = dgs_wave_sum63(s_cb);
         s_cc = dgs_wave_sum63(s_cc);
         s_op = dgs_wave_sum63(s_op);
-        s_r = dgs_wave_sum63(s_r);
-        s_g = dgs_wave_sum63(s_g);
-        s_b_ = dgs_wave_sum63(s_b_);
-        s_d = dgs_wave_sum63(s_d);
+        const float s_r = dgs_wave_sum63(sA.x);
+        const float s_g = dgs_wave_sum63(sA.y);
+        const float s_b_ = dgs_wave_sum63(sB.x);
+        const float s_d = dgs_wave_sum63(sB.y);
         if (lane == 63) {
           s_acc[w][j][0] = make_float4(s_mx, s_my, s_ca, s_cb);
           s_acc[w][j][1] = make_float4(s_cc, s_op, s_r, s_g);

@@ -3,8 +3,9 @@
 // computeColorFromSH backward :20-140 and computeCov3D backward :299-362).
 //
 // One thread per Gaussian walks the K subframes:
-//   * sums that (subframe, Gaussian)'s contribution rows written by composite_bwd in duplicate order
-//     (replaces the reference's 10 float atomics per (pixel, Gaussian): deterministic);
+//   * reads that (subframe, Gaussian)'s total of the contribution rows written by composite_bwd (summed in
+//     duplicate order by contrib_reduce_kernel; replaces the reference's 10 float atomics per (pixel, Gaussian):
+//     deterministic);
 //   * conic -> cov2D -> cov3D / mean gradients, projection and depth terms, SH gradients;
 //   * accumulates dL/d{mean3D, SH, opacity, cov3D} over the K subframes IN REGISTERS and writes them once
 //     (the reference allocates, zero-fills and re-accumulates 220 B/Gaussian per subframe,
@@ -49,13 +50,37 @@ __device__ __forceinline__ M3 tr(const M3& A) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Stage 1: one thread per (subframe, Gaussian) sums that pair's contribution rows in duplicate order and
+// leaves the total IN PLACE in the first row of its segment.  Small register footprint -> full occupancy, so
+// the dependent row loop is latency-hidden by sheer thread count (it was the bottleneck when it lived inside
+// the 180-VGPR geometry kernel).
+__global__ void __launch_bounds__(256)
+contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ offsets,
+                      float* __restrict__ contrib) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t nt = tiles_touched[i];
+  if (nt < 2) return;  // nothing to add
+  float4* cp = reinterpret_cast<float4*>(contrib + (size_t)offsets[i] * DGS_CONTRIB_F);
+  float4 a0 = cp[0], a1 = cp[1], a2 = cp[2];
+  for (uint32_t r = 1; r < nt; r++) {
+    const float4 r0 = cp[3 * r], r1 = cp[3 * r + 1], r2 = cp[3 * r + 2];
+    a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w;
+    a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
+    a2.x += r2.x; a2.y += r2.y;
+  }
+  cp[0] = a0;
+  cp[1] = a1;
+  cp[2] = a2;
+}
+
 template <int MAXC>  // MAXC = SH coefficients held in registers: 1, 4, 9 or 16
 __global__ void __launch_bounds__(GB_THREADS)
 geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* __restrict__ shs,
                     const float* __restrict__ scales, const float* __restrict__ rotations,
                     const float* __restrict__ cov3D_precomp, const float* __restrict__ viewm,
                     const float* __restrict__ projm, const float* __restrict__ campos,
-                    const DgsRow* __restrict__ rows, const float* __restrict__ cov3Ds,
+                    const uint32_t* __restrict__ offsets, const float* __restrict__ cov3Ds,
                     const float* __restrict__ pre_sigmoid, const uint32_t* __restrict__ tiles_touched,
                     const float* __restrict__ contrib, float* __restrict__ dL_dmeans3D,
                     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors,
@@ -92,18 +117,10 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     float g2x = 0.0f, g2y = 0.0f;
     const uint32_t ntiles = valid ? tiles_touched[o] : 0u;
     if (ntiles > 0) {
-      // ---- sum this (subframe, Gaussian)'s duplicate rows in duplicate order
-      const uint32_t off = rows[o].dup_offset;
-      float s[10];
-#pragma unroll
-      for (int i = 0; i < 10; i++) s[i] = 0.0f;
-      const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)off * DGS_CONTRIB_F);
-      for (uint32_t i = 0; i < ntiles; i++) {
-        const float4 r0 = cp[3 * i], r1 = cp[3 * i + 1], r2 = cp[3 * i + 2];
-        s[0] += r0.x; s[1] += r0.y; s[2] += r0.z; s[3] += r0.w;
-        s[4] += r1.x; s[5] += r1.y; s[6] += r1.z; s[7] += r1.w;
-        s[8] += r2.x; s[9] += r2.y;
-      }
+      // ---- the (subframe, Gaussian) total left by contrib_reduce_kernel in the first row of the segment
+      const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)offsets[o] * DGS_CONTRIB_F);
+      const float4 r0 = cp[0], r1 = cp[1], r2 = cp[2];
+      const float s[10] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
       g2x = s[0];
       g2y = s[1];
       const float dcon_x = s[2], dcon_y = s[3], dcon_w = s[4];
@@ -398,33 +415,43 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
   }
 }
 
-// Sums the per-block partials in block order and scatters them into the two [K,4,4] outputs.
-__global__ void __launch_bounds__(64)
+// Sums the per-block partials and scatters them into the two [K,4,4] outputs.  Deterministic: thread t adds
+// blocks t, t+256, ... in order, then a fixed-shape tree combines the 256 partial sums.
+__global__ void __launch_bounds__(256)
 pose_grad_reduce_kernel(int K, int nblocks, const float* __restrict__ partials, float* __restrict__ dL_dview,
                         float* __restrict__ dL_dproj) {
+  __shared__ float red[256];
   const int k = blockIdx.x;
-  const int i = threadIdx.x;
-  if (i >= 32) return;
-  // output slot i: 0..15 view entry i, 16..31 proj entry i-16
-  int src = -1;
-  if (i < 16) {
-    const int r = i >> 2, c = i & 3;
-    if (c < 3) src = r * 3 + c;  // view[4r+c] <- mat[3r+c]
-  } else {
-    const int e = i - 16, r = e >> 2, c = e & 3;
-    if (c < 2) src = 12 + r * 2 + c;  // proj[4r+c], c in {0,1}
-    if (c == 3) src = 20;             // proj[3], [7], [11], [15]
+  const size_t stride = (size_t)K * NMAT;
+  for (int i = 0; i < 32; i++) {  // output slot i: 0..15 view entry i, 16..31 proj entry i-16
+    int src = -1;
+    if (i < 16) {
+      const int r = i >> 2, c = i & 3;
+      if (c < 3) src = r * 3 + c;  // view[4r+c] <- mat[3r+c]
+    } else {
+      const int e = i - 16, r = e >> 2, c = e & 3;
+      if (c < 2) src = 12 + r * 2 + c;  // proj[4r+c], c in {0,1}
+      if (c == 3) src = 20;             // proj[3], [7], [11], [15]
+    }
+    float acc = 0.0f;
+    if (src >= 0) {
+      const float* p = partials + (size_t)k * NMAT + src;
+      for (int b = threadIdx.x; b < nblocks; b += 256) acc += p[(size_t)b * stride];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+      if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      if (i < 16)
+        dL_dview[16 * k + i] = red[0];
+      else
+        dL_dproj[16 * k + (i - 16)] = red[0];
+    }
+    __syncthreads();
   }
-  float acc = 0.0f;
-  if (src >= 0) {
-    const size_t stride = (size_t)K * NMAT;
-    const float* p = partials + (size_t)k * NMAT + src;
-    for (int b = 0; b < nblocks; b++) acc += p[(size_t)b * stride];
-  }
-  if (i < 16)
-    dL_dview[16 * k + i] = acc;
-  else
-    dL_dproj[16 * k + (i - 16)] = acc;
 }
 
 }  // namespace
@@ -436,9 +463,12 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
   const int blocks = dgs_geometry_bwd_blocks(v.P);
   const size_t lds = (size_t)(GB_THREADS / 64) * v.K * NMAT * sizeof(float);
   const int ncoef = (p.shs != nullptr) ? (v.D + 1) * (v.D + 1) : 1;
+  const uint64_t kp = (uint64_t)v.K * v.P;
+  hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((kp + 255) / 256)), dim3(256), 0, s, kp, c.tiles_touched,
+                     c.point_offsets, const_cast<float*>(contrib));
 #define DGS_GB_LAUNCH(MAXC)                                                                                          \
   hipLaunchKernelGGL(geometry_bwd_kernel<MAXC>, dim3(blocks), dim3(GB_THREADS), lds, s, v, p.means3D, p.shs,         \
-                     p.scales, p.rotations, p.cov3D_precomp, p.viewmatrix, p.projmatrix, p.campos, c.rows, c.cov3D,  \
+                     p.scales, p.rotations, p.cov3D_precomp, p.viewmatrix, p.projmatrix, p.campos, c.point_offsets, c.cov3D,  \
                      c.pre_sigmoid, c.tiles_touched, contrib, io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh,             \
                      io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations, io.dL_dcov3D, partials)
   if (ncoef <= 1)
@@ -452,7 +482,7 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
 #undef DGS_GB_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(pose_grad_reduce_kernel, dim3(v.K), dim3(64), 0, s, v.K, blocks, partials, io.dL_dviewmatrix,
+  hipLaunchKernelGGL(pose_grad_reduce_kernel, dim3(v.K), dim3(256), 0, s, v.K, blocks, partials, io.dL_dviewmatrix,
                      io.dL_dprojmatrix);
   return hipGetLastError();
 }

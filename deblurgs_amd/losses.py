@@ -35,10 +35,10 @@ def batchwise_smoothness_loss(x: torch.Tensor):
 
 
 def hinge_l2(x: torch.Tensor):
-    loss = torch.zeros_like(x)
-    loss[x <= 0.0] = x[x <= 0.0] ** 2
-    loss[x >= 1.0] = (x[x >= 1.0] - 1.0) ** 2
-    return loss.mean()
+    """Same values and gradients as the reference's masked assignments (utils/loss_utils.py:96-104), written
+    with torch.where so that no boolean-index nonzero() forces a host synchronisation per step."""
+    zero = torch.zeros_like(x)
+    return (torch.where(x <= 0.0, x ** 2, zero) + torch.where(x >= 1.0, (x - 1.0) ** 2, zero)).mean()
 
 
 class ToneMapping(torch.nn.Module):
