@@ -87,7 +87,10 @@ def main():
     K, h, w = 5, 12, 10
     sub = torch.tensor(rng.random((K, 3, h, w)), dtype=torch.float32, requires_grad=True)
     gt = torch.tensor(rng.random((3, h, w)), dtype=torch.float32)
-    dep = torch.tensor(rng.random((K, 1, h, w)) * 5, dtype=torch.float32, requires_grad=True)
+    # NB train.py:152 feeds tv_loss a 5-D [f,1,1,h,w] tensor (depths are stacked [1,H,W] maps), for which the
+    # reference's slicing yields an empty tensor and a NaN loss; lambda_depth_tv defaults to 0 so it never runs.
+    # The fixture pins tv_loss on the 4-D input its docstring describes.
+    dep = torch.tensor(rng.random((K, h, w)) * 5, dtype=torch.float32, requires_grad=True)
     opa = torch.tensor(rng.normal(0.5, 0.6, (40, 1)), dtype=torch.float32, requires_grad=True)
     blur = sub.mean(0)
     l1 = loss_utils.l1_loss(blur, gt)

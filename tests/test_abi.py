@@ -1,0 +1,110 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol
+include/dgs_hip.h declares, its size queries are consistent, and argument errors come back as codes + text
+(no compute calls here: there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "dgs_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dgs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from deblurgs_amd import _lib
+    L = _lib.lib()
+    syms = header_symbols()
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(L, s), f"libdgs_hip.so does not export {s}"
+    assert set(syms) == set(_lib.EXPORTS), "ctypes binding and header disagree"
+    assert L.dgs_abi_version() == 1
+
+
+def test_no_torch_types_in_the_abi():
+    text = open(os.path.join(ROOT, "include", "dgs_hip.h")).read()
+    assert "torch" not in text.lower().replace("pytorch", "").replace("no torch types", "")
+    assert "#include <hip" not in text      # plain C: stream handle is a void*
+
+
+def test_struct_sizes_match_the_header_layout():
+    from deblurgs_amd import _lib
+    # 6 ints + 5 floats + 3 ints = 56 bytes, then 11 pointers, then 3 x (pointer + size_t)
+    assert ctypes.sizeof(_lib.DgsProblem) == 56 + 11 * 8 + 3 * 16
+    assert ctypes.sizeof(_lib.DgsForwardOut) == 32
+    assert ctypes.sizeof(_lib.DgsBackwardIO) == 8 + 8 * 3 + 16 + 10 * 8
+    assert ctypes.sizeof(_lib.DgsLayout) == 18 * 8 + 8
+
+
+def test_size_queries_and_layout():
+    from deblurgs_amd import _lib
+    L = _lib.lib()
+    P, W, H, K, R = 1000, 1920, 1080, 15, 4_000_000
+    lay = _lib.layout(P, W, H, K, R)
+    assert lay.geom_total == L.dgs_geom_state_bytes(P, K)
+    assert lay.image_total == L.dgs_image_state_bytes(W, H, K)
+    assert lay.binning_total == L.dgs_binning_state_bytes(R, W, H, K)
+    T = 120 * 68
+    assert lay.sort_bits == 32 + 17 and lay.sort_passes == 6          # bits(15*8160) = 17
+    assert _lib.layout(P, W, H, 1, R).sort_bits == 45                  # the reference's key width at 1080p
+    assert lay.geom_rows == 0 and lay.cov3D >= K * P * 48
+    assert lay.final_T == 0 and lay.n_contrib >= K * W * H * 4 and lay.ranges >= 2 * K * W * H * 4
+    assert lay.image_total >= lay.ranges + K * T * 8
+    assert lay.point_list >= R * 8 and lay.binning_total >= R * 24
+    for off in (lay.cov3D, lay.pre_sigmoid, lay.tiles_touched, lay.n_contrib, lay.ranges, lay.point_list,
+                lay.keys_unsorted, lay.sort_tmp):
+        assert off % 256 == 0
+    assert L.dgs_backward_scratch_bytes(R, P, K) >= R * 48
+    assert L.dgs_binning_state_bytes(0, W, H, K) > 0
+
+
+def test_argument_errors_are_codes_with_text():
+    from deblurgs_amd import _lib
+    L = _lib.lib()
+    p = _lib.DgsProblem()
+    out = _lib.DgsForwardOut()
+    p.P, p.W, p.H, p.K = 10, 64, 64, 0
+    assert L.dgs_forward_geometry(ctypes.byref(p), ctypes.byref(out), None) == -1
+    assert b"K must be" in L.dgs_last_error()
+    p.K = 1
+    p.D = 7
+    assert L.dgs_forward_geometry(ctypes.byref(p), ctypes.byref(out), None) == -1
+    assert b"SH degree" in L.dgs_last_error()
+    p.D = 2
+    assert L.dgs_forward_geometry(ctypes.byref(p), ctypes.byref(out), None) == -1   # null means3D
+    dummy = ctypes.create_string_buffer(64)
+    addr = ctypes.cast(dummy, ctypes.c_void_p)
+    p.means3D = p.opacities = addr
+    assert L.dgs_forward_geometry(ctypes.byref(p), ctypes.byref(out), None) == -1
+    assert b"excatly one of either SHs or precomputed colors" in L.dgs_last_error()
+    p.shs = addr
+    p.M = 9
+    assert L.dgs_forward_geometry(ctypes.byref(p), ctypes.byref(out), None) == -1
+    assert b"exactly one of either scale/rotation pair" in L.dgs_last_error()
+    with pytest.raises(RuntimeError, match="dgs_forward_geometry failed"):
+        _lib.check(-1, "dgs_forward_geometry")
+
+
+def test_product_has_no_cpu_fallback():
+    """The package must not import the oracle, and the operator must refuse CPU tensors."""
+    import torch
+    pkg = os.path.join(ROOT, "deblurgs_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
+    from deblurgs_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    rs = GaussianRasterizationSettings(16, 16, 0.5, 0.5, torch.zeros(3), 1.0, 0.2, 100.0, False, 0, torch.zeros(3),
+                                       False, False)
+    m = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        GaussianRasterizer(rs)(m, m, torch.ones(4, 1), shs=torch.zeros(4, 1, 3), scales=torch.ones(4, 3),
+                               rotations=torch.ones(4, 4), viewmatrix=torch.eye(4), projmatrix=torch.eye(4))
+    with pytest.raises(Exception, match="excatly one"):
+        GaussianRasterizer(rs)(m, m, torch.ones(4, 1), scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
