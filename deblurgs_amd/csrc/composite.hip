@@ -9,9 +9,10 @@
 //     (exact ellipse/box minimum with rounding slack) and publishes the row to LDS.  The per-Gaussian loop then walks only the
 //     set bits of the ballot masks, so a (Gaussian, quadrant) pair that cannot contribute costs nothing.
 //     Culling is conservative, hence the per-pixel tests below are exactly the reference's.
-//   * Backward: no global atomics.  The 10 per-Gaussian partial gradients are summed over a lane's pixels
-//     in registers, over the wave with DPP (dgs_wave_sum63), staged per batch in LDS, and stored as ONE
-//     48-byte contribution row per (tile, Gaussian) duplicate.  geometry_bwd.hip sums a Gaussian's rows in
+//   * Backward: no global atomics.  The 10 per-Gaussian partial sums are accumulated over a lane's pixels
+//     in registers, over the wave with a permlane-swap/DPP reduce-scatter, staged per batch in LDS, and stored
+//     as ONE 48-byte contribution row per (tile, Gaussian) duplicate:
+//       [sum w*dx, sum w*dy, sum w*dx*dx, sum w*dx*dy, sum w*dy*dy, sum w, dL_dr, dL_dg, dL_db, dL_ddepth].  geometry_bwd.hip sums a Gaussian's rows in
 //     duplicate order, so the whole backward is bitwise reproducible (the reference issues 10 float
 //     atomicAdds per (pixel, Gaussian), backward.cu:599-637).
 #include "dgs_common.h"
@@ -314,7 +315,11 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       const float2 c = s_c[w][j];
       const uint32_t pos = base + (uint32_t)j;  // 0-based position in the tile list
       const float dx0 = a.x - pxf0, dx1 = a.x - pxf1, dy0 = a.y - pyf0, dy1 = a.y - pyf1;
-      float s_mx = 0, s_my = 0, s_ca = 0, s_cb = 0, s_cc = 0, s_op = 0;
+      // raw per-lane sums over this lane's pixels; with w = (opacity*G) * dL_dalpha every geometric gradient of
+      // backward.cu:620-637 is a per-Gaussian linear map of {sum w, sum w*dx, sum w*dy, sum w*dx*dx, sum w*dx*dy,
+      // sum w*dy*dy}; that map (conic / opacity / 0.5*W factors) is applied once per (subframe, Gaussian) in
+      // geometry_bwd.hip instead of once per pixel here.
+      float S_w = 0, S_wx = 0, S_wy = 0, S_xx = 0, S_xy = 0, S_yy = 0;
       v2f sA = {0.0f, 0.0f}, sB = {0.0f, 0.0f};  // (dL_dr, dL_dg), (dL_db, dL_ddepth)
       const v2f colA = {b.z, b.w}, colB = {c.x, c.y};
       bool touched = false;
@@ -329,11 +334,10 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           // merely applies its pending update early (the next valid pair would compute 0*c + 1*accum = accum),
           // so the results are bit-identical to skipping.
           const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-          const float G_raw = __expf(power);
-          const float alpha_raw = fminf(0.99f, b.y * G_raw);
+          const float au = b.y * __expf(power);  // opacity * G: the unclamped alpha the backward differentiates
+          const float alpha_raw = fminf(0.99f, au);
           const bool ok = (pos < last[q]) && (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
           touched = touched || ok;
-          const float G = ok ? G_raw : 0.0f;
           const float alpha = ok ? alpha_raw : 0.0f;
           const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
           T[q] = T[q] * inv1ma;
@@ -350,34 +354,34 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           sB += gB[q] * dchannel_dcolor;
           dL_dalpha *= T[q];
           dL_dalpha += (-Tfin[q] * inv1ma) * bgdot[q];
-          const float dL_dG = b.y * dL_dalpha;
-          const float gdx = G * dx;
-          const float gdy = G * dy;
-          const float dG_ddelx = -gdx * a.z - gdy * a.w;
-          const float dG_ddely = -gdy * b.x - gdx * a.w;
-          s_mx += dL_dG * dG_ddelx * ddelx_dx;
-          s_my += dL_dG * dG_ddely * ddely_dy;
-          s_ca += -0.5f * gdx * dx * dL_dG;
-          s_cb += -0.5f * gdx * dy * dL_dG;
-          s_cc += -0.5f * gdy * dy * dL_dG;
-          s_op += G * dL_dalpha;
+          const float wgt = ok ? au * dL_dalpha : 0.0f;
+          const float wx = wgt * dx, wy = wgt * dy;
+          S_w += wgt;
+          S_wx += wx;
+          S_wy += wy;
+          S_xx += wx * dx;
+          S_xy += wx * dy;
+          S_yy += wy * dy;
         }
       }
       if (__ballot(touched) != 0ull) {
-        s_mx = dgs_wave_sum63(s_mx);
-        s_my = dgs_wave_sum63(s_my);
-        s_ca = dgs_wave_sum63(s_ca);
-        s_cb = dgs_wave_sum63(s_cb);
-        s_cc = dgs_wave_sum63(s_cc);
-        s_op = dgs_wave_sum63(s_op);
-        const float s_r = dgs_wave_sum63(sA.x);
-        const float s_g = dgs_wave_sum63(sA.y);
-        const float s_b_ = dgs_wave_sum63(sB.x);
-        const float s_d = dgs_wave_sum63(sB.y);
-        if (lane == 63) {
-          s_acc[w][j][0] = make_float4(s_mx, s_my, s_ca, s_cb);
-          s_acc[w][j][1] = make_float4(s_cc, s_op, s_r, s_g);
-          s_acc[w][j][2] = make_float4(s_b_, s_d, 0.0f, 0.0f);
+        // 10 wave sums as a reduce-scatter: two fold levels (v_permlane32_swap / v_permlane16_swap) halve the
+        // number of live registers each, then 4 row-DPP steps finish 4 values per register: 27 VALU ops instead
+        // of 60 for ten independent butterflies.  Row r of the result registers holds:
+        //   ua: (S_wx, S_xx, S_wy, S_xy)   ub: (S_yy, sA.x, S_w, sA.y)   uc: rows 1,3 = (sB.x, sB.y)
+        const float ua = dgs_row_sum(dgs_fold16(dgs_fold32(S_wx, S_wy), dgs_fold32(S_xx, S_xy)));
+        const float ub = dgs_row_sum(dgs_fold16(dgs_fold32(S_yy, S_w), dgs_fold32(sA.x, sA.y)));
+        float uc = dgs_row_sum(dgs_fold32(sB.x, sB.y));
+        uc += dgs_dpp<0x142, 0xa>(uc);  // row_bcast15: row1 += row0, row3 += row2
+        if ((lane & 15) == 0) {
+          const int r = lane >> 4;
+          float* acc = reinterpret_cast<float*>(&s_acc[w][j][0]);
+          // row r of ua holds value index {0:S_wx, 1:S_xx, 2:S_wy, 3:S_xy}[r] -> contribution-row slots
+          const int slot_a = (r == 0) ? 0 : (r == 1) ? 2 : (r == 2) ? 1 : 3;  // [S_wx, S_wy, S_xx, S_xy, ...]
+          const int slot_b = (r == 0) ? 4 : (r == 1) ? 6 : (r == 2) ? 5 : 7;  // [..., S_yy, S_w, r, g, ...]
+          acc[slot_a] = ua;
+          acc[slot_b] = ub;
+          if (r & 1) acc[8 + (r >> 1)] = uc;                                  // [..., b, depth]
         }
       }
     }

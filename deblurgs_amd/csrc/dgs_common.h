@@ -85,6 +85,27 @@ __device__ __forceinline__ float dgs_wave_sum63(float v) {
 
 __device__ __forceinline__ int dgs_lane() { return (int)(threadIdx.x & 63); }
 
+// ---- reduce-scatter building blocks (gfx950 v_permlane{32,16}_swap + row DPP) -------------------------------------
+typedef unsigned int dgs_u2 __attribute__((ext_vector_type(2)));
+// lanes 0..31 <- a[l] + a[l+32];  lanes 32..63 <- b[l-32] + b[l]
+__device__ __forceinline__ float dgs_fold32(float a, float b) {
+  const dgs_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// per 16-lane row: rows (0,1,2,3) <- (a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3)
+__device__ __forceinline__ float dgs_fold16(float a, float b) {
+  const dgs_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// every lane of a 16-lane row <- the sum over that row
+__device__ __forceinline__ float dgs_row_sum(float v) {
+  v += dgs_dpp<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dgs_dpp<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dgs_dpp<0x141, 0xf>(v);  // row_half_mirror
+  v += dgs_dpp<0x140, 0xf>(v);  // row_mirror
+  return v;
+}
+
 // ---- host-side launch entry points (one per .hip file) -----------------------------------------------------
 struct DgsView {  // per-launch scalars shared by the kernels
   int P, D, M, W, H, K;

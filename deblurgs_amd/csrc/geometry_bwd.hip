@@ -80,7 +80,8 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
                     const float* __restrict__ scales, const float* __restrict__ rotations,
                     const float* __restrict__ cov3D_precomp, const float* __restrict__ viewm,
                     const float* __restrict__ projm, const float* __restrict__ campos,
-                    const uint32_t* __restrict__ offsets, const float* __restrict__ cov3Ds,
+                    const uint32_t* __restrict__ offsets, const DgsRow* __restrict__ rows,
+                    const float* __restrict__ cov3Ds,
                     const float* __restrict__ pre_sigmoid, const uint32_t* __restrict__ tiles_touched,
                     const float* __restrict__ contrib, float* __restrict__ dL_dmeans3D,
                     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors,
@@ -121,10 +122,15 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
       const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)offsets[o] * DGS_CONTRIB_F);
       const float4 r0 = cp[0], r1 = cp[1], r2 = cp[2];
       const float s[10] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
-      g2x = s[0];
-      g2y = s[1];
-      const float dcon_x = s[2], dcon_y = s[3], dcon_w = s[4];
-      a_op += s[5];
+      // raw sums -> the reference's per-Gaussian sinks (backward.cu:620-637; see composite.hip):
+      //   dL_dmean2D = -(0.5 W, 0.5 H) * (cx*Swx + cy*Swy, cz*Swy + cy*Swx),  dL_dconic = -0.5 * (Sxx, Sxy, Syy),
+      //   dL_dopacity = Sw / opacity
+      const float4 ga = reinterpret_cast<const float4*>(rows + o)[0];   // x, y, cx, cy
+      const float4 gb = reinterpret_cast<const float4*>(rows + o)[1];   // cz, op, r, g
+      g2x = -(0.5f * (float)v.W) * (ga.z * s[0] + ga.w * s[1]);
+      g2y = -(0.5f * (float)v.H) * (gb.x * s[1] + ga.w * s[0]);
+      const float dcon_x = -0.5f * s[2], dcon_y = -0.5f * s[3], dcon_w = -0.5f * s[4];
+      a_op += (gb.y > 0.0f) ? s[5] / gb.y : 0.0f;
       const float dcol[3] = {s[6], s[7], s[8]};
       const float ddepth = s[9];
 
@@ -468,7 +474,8 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
                      c.point_offsets, const_cast<float*>(contrib));
 #define DGS_GB_LAUNCH(MAXC)                                                                                          \
   hipLaunchKernelGGL(geometry_bwd_kernel<MAXC>, dim3(blocks), dim3(GB_THREADS), lds, s, v, p.means3D, p.shs,         \
-                     p.scales, p.rotations, p.cov3D_precomp, p.viewmatrix, p.projmatrix, p.campos, c.point_offsets, c.cov3D,  \
+                     p.scales, p.rotations, p.cov3D_precomp, p.viewmatrix, p.projmatrix, p.campos, c.point_offsets, c.rows,       \
+                     c.cov3D,  \
                      c.pre_sigmoid, c.tiles_touched, contrib, io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh,             \
                      io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations, io.dL_dcov3D, partials)
   if (ncoef <= 1)
