@@ -4,6 +4,9 @@
 //
 // All integer work, HBM-bound.  Key = ((k*T + tile) << 32) | depth_bits so that ONE sort orders the
 // duplicates of all K subframes; within a subframe the low 32+bits(T) bits are exactly the reference's key.
+#include <stdlib.h>
+#include <string.h>
+
 #include "dgs_common.h"
 
 namespace {
@@ -280,6 +283,260 @@ sort_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __rest
   }
 }
 
+// ----------------------------------------------------------------------- tile-major histogram table + column scan
+// The classic table is digit-major ([digit][tile]) so that one flat scan yields scatter bases, but that makes
+// every tile read and write 512 words at a 61 KB stride (one 64-byte line per 4 useful bytes: ~1 GB of hidden
+// traffic per pass at the metric config).  Here a tile owns one contiguous 2 KB row; the bases come from a
+// column-wise scan done in two small kernels whose loads are all full rows.
+constexpr int CS_CHUNK = 64;  // tiles per column-scan chunk
+
+__global__ void __launch_bounds__(SORT_THREADS)
+sort_hist_rows_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift, int rb, uint32_t* __restrict__ table) {
+  __shared__ uint32_t h[SORT_MAX_BINS];
+  for (int i = threadIdx.x; i < SORT_MAX_BINS; i += SORT_THREADS) h[i] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
+  const uint32_t mask = (1u << rb) - 1;
+#pragma unroll 4
+  for (int r = 0; r < SORT_ITEMS; r++) {
+    const uint64_t i = base + (uint64_t)r * SORT_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  uint32_t* row = table + (size_t)blockIdx.x * SORT_MAX_BINS;
+  for (int i = threadIdx.x; i < SORT_MAX_BINS; i += SORT_THREADS) row[i] = h[i];
+}
+
+// chunk c: per digit, exclusive running count over the chunk's tiles (in place) and the chunk total
+__global__ void __launch_bounds__(256)
+colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nblocks, uint32_t* __restrict__ ctot) {
+  const uint32_t t0 = blockIdx.x * CS_CHUNK;
+  const uint32_t t1 = min(t0 + CS_CHUNK, nblocks);
+  uint32_t run0 = 0, run1 = 0;
+  for (uint32_t t = t0; t < t1; t++) {
+    uint32_t* row = table + (size_t)t * SORT_MAX_BINS;
+    const uint32_t a = row[threadIdx.x], b = row[threadIdx.x + 256];
+    row[threadIdx.x] = run0;
+    row[threadIdx.x + 256] = run1;
+    run0 += a;
+    run1 += b;
+  }
+  ctot[(size_t)blockIdx.x * SORT_MAX_BINS + threadIdx.x] = run0;
+  ctot[(size_t)blockIdx.x * SORT_MAX_BINS + threadIdx.x + 256] = run1;
+}
+
+// one block: chunk totals -> exclusive chunk bases per digit, plus the exclusive base of each digit
+__global__ void __launch_bounds__(256)
+colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nchunks) {
+  __shared__ uint32_t lds[8];
+  uint32_t run0 = 0, run1 = 0;
+  for (uint32_t c = 0; c < nchunks; c++) {
+    uint32_t* row = ctot + (size_t)c * SORT_MAX_BINS;
+    const uint32_t a = row[threadIdx.x], b = row[threadIdx.x + 256];
+    row[threadIdx.x] = run0;
+    row[threadIdx.x + 256] = run1;
+    run0 += a;
+    run1 += b;
+  }
+  // digit order is 0..255 (run0 of thread t) then 256..511 (run1 of thread t)
+  uint32_t tot0, tot1;
+  const uint32_t pre0 = block_excl_scan(run0, &tot0, lds);
+  const uint32_t pre1 = block_excl_scan(run1, &tot1, lds) + tot0;
+  for (uint32_t c = 0; c < nchunks; c++) {
+    uint32_t* row = ctot + (size_t)c * SORT_MAX_BINS;
+    row[threadIdx.x] += pre0;
+    row[threadIdx.x + 256] += pre1;
+  }
+}
+
+// ------------------------------------------------------------------------------------ onesweep radix sort
+// Single-pass-per-digit variant (default): the digit histograms of ALL passes come from one read of the keys;
+// each pass then reads every pair once and writes it once.  A tile (4096 pairs) takes a ticket, ranks its pairs
+// exactly like sort_scatter_kernel, publishes its per-digit counts as self-tagged 32-bit words
+// {flag:2 | count:30} and resolves its global offsets by decoupled look-back over the preceding tiles.  The words
+// are written/read with relaxed agent-scope atomics (sc1): flag and payload travel in one word, so no fence is
+// needed and no dispatch-order or XCD-placement assumption is made beyond "a tile with a smaller ticket has
+// started" (MI355X_MICROARCH.md, inter-workgroup visibility).  Pairs are re-ordered through LDS so that the
+// global writes are contiguous runs per digit instead of 64 scattered 8-byte stores per wave instruction.
+constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_INCL = 2u << 30, OS_VALUE_MASK = (1u << 30) - 1;
+constexpr int OS_MAX_PASSES = 8;
+
+struct OsPlan {
+  int n;
+  int shift[OS_MAX_PASSES];
+  int rb[OS_MAX_PASSES];
+};
+
+__global__ void __launch_bounds__(256)
+onesweep_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, OsPlan plan, uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t h[OS_MAX_PASSES * SORT_MAX_BINS];
+  const int total = plan.n * SORT_MAX_BINS;
+  for (int i = threadIdx.x; i < total; i += 256) h[i] = 0;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t k = keys[i];
+    for (int p = 0; p < plan.n; p++)
+      atomicAdd(&h[p * SORT_MAX_BINS + ((uint32_t)(k >> plan.shift[p]) & ((1u << plan.rb[p]) - 1))], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += 256)
+    if (h[i] != 0) atomicAdd(&ghist[i], h[i]);
+}
+
+// one block per pass: exclusive prefix over the (<= 512) bins, in place
+__global__ void __launch_bounds__(256) onesweep_prefix_kernel(uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t lds[8];
+  uint32_t* g = ghist + (size_t)blockIdx.x * SORT_MAX_BINS;
+  const uint32_t a = g[2 * threadIdx.x], b = g[2 * threadIdx.x + 1];
+  uint32_t tot;
+  const uint32_t pre = block_excl_scan(a + b, &tot, lds);
+  g[2 * threadIdx.x] = pre;
+  g[2 * threadIdx.x + 1] = pre + a;
+}
+
+// LOOKBACK = false (default): same ranking + LDS re-ordering, but the tile's global digit bases come from the
+// tile-major histogram table (gbase) and the column-scanned chunk bases (status); ticket unused.
+template <bool LOOKBACK>
+__global__ void __launch_bounds__(SORT_THREADS)
+onesweep_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                        uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint64_t n, int shift, int rb,
+                        const uint32_t* __restrict__ gbase, uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
+                        uint32_t nblocks) {
+  __shared__ uint64_t lds_k[SORT_TILE];  // 32 KB; re-used for the values
+  __shared__ uint32_t whist[SORT_THREADS / 64][SORT_MAX_BINS];
+  __shared__ uint32_t dstart[SORT_MAX_BINS];
+  __shared__ uint32_t gb[SORT_MAX_BINS];
+  __shared__ uint32_t s_scan[8];
+  __shared__ uint32_t s_tile;
+  const uint32_t mask = (1u << rb) - 1;
+  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  if (LOOKBACK) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  }
+  for (int i = lane; i < SORT_MAX_BINS; i += 64) whist[w][i] = 0;
+  __syncthreads();
+  const uint32_t tile = LOOKBACK ? s_tile : blockIdx.x;
+
+  const uint64_t tbase = (uint64_t)tile * SORT_TILE;
+  const uint64_t wbase = tbase + (uint64_t)w * (64 * SORT_ITEMS);
+  uint64_t key[SORT_ITEMS];
+  uint32_t val[SORT_ITEMS];
+  uint32_t rank[SORT_ITEMS];
+  volatile uint32_t* wh = whist[w];
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; r++) {
+    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
+    const bool valid = i < n;
+    key[r] = valid ? keys_in[i] : ~0ull;
+    val[r] = valid ? vals_in[i] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; r++) {
+    const bool valid = (wbase + (uint64_t)r * 64 + lane) < n;
+    const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+    uint64_t peers = __ballot(valid);
+    for (int b = 0; b < rb; b++) {
+      const uint64_t m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
+    uint32_t pre = 0;
+    if (valid) pre = wh[d];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && below == 0) wh[d] = pre + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    rank[r] = pre + below;
+  }
+  __syncthreads();
+
+  // thread t owns digits 2t, 2t+1: block totals, per-wave exclusive offsets, start of each digit inside the tile
+  uint32_t cnt[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const int d = 2 * threadIdx.x + e;
+    uint32_t run = 0;
+#pragma unroll
+    for (int ww = 0; ww < SORT_THREADS / 64; ww++) {
+      const uint32_t c = whist[ww][d];
+      whist[ww][d] = run;
+      run += c;
+    }
+    cnt[e] = run;
+  }
+  uint32_t tot;
+  const uint32_t pre2 = block_excl_scan(cnt[0] + cnt[1], &tot, s_scan);
+  dstart[2 * threadIdx.x] = pre2;
+  dstart[2 * threadIdx.x + 1] = pre2 + cnt[0];
+
+  // publish the tile aggregate, look back, publish the inclusive prefix
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const int d = 2 * threadIdx.x + e;
+    uint32_t* mine = status + (size_t)tile * SORT_MAX_BINS + d;
+    uint32_t excl = 0;
+    if (!LOOKBACK) {
+      // gbase = tile-major table of in-chunk exclusive counts, status = chunk bases (incl. digit bases)
+      gb[d] = gbase[(size_t)tile * SORT_MAX_BINS + d] + status[(size_t)(tile / CS_CHUNK) * SORT_MAX_BINS + d] -
+              (e == 0 ? pre2 : pre2 + cnt[0]);
+      continue;
+    }
+    if (tile == 0) {
+      __hip_atomic_store(mine, OS_FLAG_INCL | cnt[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(mine, OS_FLAG_AGG | cnt[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int64_t t = (int64_t)tile - 1; t >= 0; t--) {
+        const uint32_t* theirs = status + (size_t)t * SORT_MAX_BINS + d;
+        uint32_t s = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((s & ~OS_VALUE_MASK) == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          s = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        excl += s & OS_VALUE_MASK;
+        if (s & OS_FLAG_INCL) break;
+      }
+      __hip_atomic_store(mine, OS_FLAG_INCL | ((excl + cnt[e]) & OS_VALUE_MASK), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // global position of tile-local slot i holding digit d:  gb[d] + i
+    gb[d] = gbase[d] + excl - (e == 0 ? pre2 : pre2 + cnt[0]);
+  }
+  __syncthreads();
+
+  // stage the keys in tile-sorted order
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; r++) {
+    if ((wbase + (uint64_t)r * 64 + lane) < n) {
+      const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+      rank[r] = dstart[d] + whist[w][d] + rank[r];  // tile-local slot
+      lds_k[rank[r]] = key[r];
+    }
+  }
+  __syncthreads();
+  const uint32_t nvalid = (uint32_t)((n - tbase) < (uint64_t)SORT_TILE ? (n - tbase) : (uint64_t)SORT_TILE);
+  uint32_t gpos[SORT_ITEMS];
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; r++) {
+    const uint32_t i = (uint32_t)r * SORT_THREADS + threadIdx.x;
+    if (i < nvalid) {
+      const uint64_t k = lds_k[i];
+      gpos[r] = gb[(uint32_t)(k >> shift) & mask] + i;
+      keys_out[gpos[r]] = k;
+    }
+  }
+  __syncthreads();
+  uint32_t* lds_v = reinterpret_cast<uint32_t*>(lds_k);
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; r++)
+    if ((wbase + (uint64_t)r * 64 + lane) < n) lds_v[rank[r]] = val[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS; r++) {
+    const uint32_t i = (uint32_t)r * SORT_THREADS + threadIdx.x;
+    if (i < nvalid) vals_out[gpos[r]] = lds_v[i];
+  }
+}
+
 struct PassPlan {
   int n;
   int shift[16];
@@ -321,8 +578,22 @@ int dgs_sort_num_passes(int end_bit) { return plan_passes(end_bit).n; }
 
 size_t dgs_sort_tmp_words(uint64_t n) {
   const uint64_t nblocks = (n + SORT_TILE - 1) / SORT_TILE;
-  const uint64_t table = nblocks * SORT_MAX_BINS;
-  return (size_t)(table + dgs_scan_tmp_words(table) + 64);
+  const uint64_t table = nblocks * SORT_MAX_BINS;  // classic: histogram table; onesweep: look-back status words
+  const uint64_t chunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
+  return (size_t)(table + dgs_scan_tmp_words(table) + OS_MAX_PASSES * SORT_MAX_BINS + chunks * SORT_MAX_BINS + 256);
+}
+
+// DGS_SORT = classic | reorder | onesweep (A/B switch for the sort benchmark; default below)
+static int sort_mode() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DGS_SORT");
+    v = 1;
+    if (e != nullptr && strcmp(e, "classic") == 0) v = 0;
+    if (e != nullptr && strcmp(e, "reorder") == 0) v = 1;
+    if (e != nullptr && strcmp(e, "onesweep") == 0) v = 2;
+  }
+  return v;
 }
 
 hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
@@ -331,12 +602,65 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
   *result_in_alt = plan.n & 1;
   if (n == 0) return hipSuccess;
   const uint32_t nblocks = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
+  if (sort_mode() == 2 && n < (1ull << 30) && plan.n <= OS_MAX_PASSES) {
+    // tmp layout: [status: nblocks*512][ghist: passes*512][tickets: passes]
+    uint32_t* status = tmp;
+    uint32_t* ghist = tmp + (uint64_t)nblocks * SORT_MAX_BINS;
+    uint32_t* tickets = ghist + OS_MAX_PASSES * SORT_MAX_BINS;
+    OsPlan op;
+    op.n = plan.n;
+    for (int i = 0; i < plan.n; i++) {
+      op.shift[i] = plan.shift[i];
+      op.rb[i] = plan.rb[i];
+    }
+    hipError_t e = hipMemsetAsync(ghist, 0, (size_t)(OS_MAX_PASSES * SORT_MAX_BINS + OS_MAX_PASSES) * 4, s);
+    if (e != hipSuccess) return e;
+    const uint32_t hb = nblocks < 2048u ? nblocks : 2048u;
+    hipLaunchKernelGGL(onesweep_hist_kernel, dim3(hb), dim3(256), 0, s, keys, n, op, ghist);
+    hipLaunchKernelGGL(onesweep_prefix_kernel, dim3(plan.n), dim3(256), 0, s, ghist);
+    uint64_t* kin = keys;
+    uint32_t* vin = vals;
+    uint64_t* kout = keys_alt;
+    uint32_t* vout = vals_alt;
+    for (int p = 0; p < plan.n; p++) {
+      e = hipMemsetAsync(status, 0, (size_t)nblocks * SORT_MAX_BINS * 4, s);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(onesweep_scatter_kernel<true>, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout,
+                         n, plan.shift[p], plan.rb[p], ghist + (size_t)p * SORT_MAX_BINS, status, tickets + p, nblocks);
+      uint64_t* tk = kin;
+      kin = kout;
+      kout = tk;
+      uint32_t* tv = vin;
+      vin = vout;
+      vout = tv;
+    }
+    return hipGetLastError();
+  }
   uint32_t* table = tmp;
   uint32_t* scan_tmp = tmp + (uint64_t)nblocks * SORT_MAX_BINS;
   uint64_t* kin = keys;
   uint32_t* vin = vals;
   uint64_t* kout = keys_alt;
   uint32_t* vout = vals_alt;
+  if (sort_mode() == 1) {
+    const uint32_t nchunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
+    uint32_t* ctot = scan_tmp;  // [nchunks][512]
+    for (int p = 0; p < plan.n; p++) {
+      hipLaunchKernelGGL(sort_hist_rows_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, plan.shift[p],
+                         plan.rb[p], table);
+      hipLaunchKernelGGL(colscan_chunk_kernel, dim3(nchunks), dim3(256), 0, s, table, nblocks, ctot);
+      hipLaunchKernelGGL(colscan_top_kernel, dim3(1), dim3(256), 0, s, ctot, nchunks);
+      hipLaunchKernelGGL(onesweep_scatter_kernel<false>, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout,
+                         n, plan.shift[p], plan.rb[p], table, ctot, nullptr, nblocks);
+      uint64_t* tk = kin;
+      kin = kout;
+      kout = tk;
+      uint32_t* tv = vin;
+      vin = vout;
+      vout = tv;
+    }
+    return hipGetLastError();
+  }
   for (int p = 0; p < plan.n; p++) {
     const uint64_t tn = (uint64_t)nblocks << plan.rb[p];
     hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, plan.shift[p], plan.rb[p],
@@ -344,7 +668,7 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
     hipError_t e = dgs_launch_scan(table, table, tn, scan_tmp, nullptr, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout, n,
-                       plan.shift[p], plan.rb[p], nblocks, table);
+                         plan.shift[p], plan.rb[p], nblocks, table);
     uint64_t* tk = kin;
     kin = kout;
     kout = tk;
