@@ -44,6 +44,7 @@ def stage_bytes(P, Pv_tot, R_tot, N, K, s):
         "composite_fwd": (28 + 16) * R_tot + 24 * N * K,
         "composite_bwd": 44 * R_tot + 24 * N * K + 2 * 48 * Pv_tot,
         "geometry_bwd": Pv_tot * (100 + 12 * s + 48) + P * (40 + 12 * s),
+        "depth_order": 24 * P * K,   # ideal one-read-one-write sort of the K*P (key, index) pairs
     }
 
 

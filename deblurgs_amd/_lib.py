@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgs_hip.so")
 
 DGS_MAX_K = 128
-STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "composite_fwd", "composite_bwd", "geometry_bwd"]
+STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "composite_fwd", "composite_bwd", "geometry_bwd",
+          "depth_order"]
 
 _c_f32p = ctypes.c_void_p  # device pointers are passed as integers
 
@@ -52,6 +53,7 @@ class DgsBackwardIO(ctypes.Structure):
 class DgsLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in (
         "geom_rows", "cov3D", "pre_sigmoid", "tiles_touched", "point_offsets", "scan_tmp", "num_rendered",
+        "gsort_keys", "gsort_keys_alt", "gsort_vals", "gsort_vals_alt", "tt_sorted", "offs_sorted", "gsort_tmp",
         "geom_total", "final_T", "n_contrib", "ranges", "image_total", "keys_sorted", "point_list",
         "keys_unsorted", "vals_unsorted", "sort_tmp", "binning_total")] + [
         ("sort_bits", ctypes.c_int32), ("sort_passes", ctypes.c_int32)]
@@ -79,7 +81,7 @@ EXPORTS = {
                                               ctypes.c_void_p, ctypes.c_void_p]),
     "dgs_sort_tmp_bytes": (ctypes.c_size_t, [ctypes.c_uint64]),
     "dgs_sort_pairs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p]),
     "dgs_blur_loss_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,

@@ -41,6 +41,13 @@ void make_layout(int P, int W, int H, int K, uint64_t R, DgsLayout* L) {
   L->point_offsets = o;  o += up(KP * 4);
   L->scan_tmp = o;       o += up(dgs_scan_tmp_words(KP) * 4);
   L->num_rendered = o;   o += up(16);
+  L->gsort_keys = o;     o += up(KP * 8);
+  L->gsort_keys_alt = o; o += up(KP * 8);
+  L->gsort_vals = o;     o += up(KP * 4);
+  L->gsort_vals_alt = o; o += up(KP * 4);
+  L->tt_sorted = o;      o += up(KP * 4);
+  L->offs_sorted = o;    o += up(KP * 4);
+  L->gsort_tmp = o;      o += up(dgs_sort_tmp_words(KP) * 4);
   L->geom_total = o;
   o = 0;
   L->final_T = o;        o += up((size_t)K * N * 4);
@@ -55,7 +62,7 @@ void make_layout(int P, int W, int H, int K, uint64_t R, DgsLayout* L) {
   L->sort_tmp = o;       o += up(dgs_sort_tmp_words(R) * 4);
   L->binning_total = o;
   L->sort_bits = sort_bits_for(W, H, K);
-  L->sort_passes = dgs_sort_num_passes(L->sort_bits);
+  L->sort_passes = dgs_sort_num_passes(32, L->sort_bits);
 }
 
 int check_problem(const DgsProblem* p) {
@@ -105,6 +112,13 @@ void carve(const DgsProblem* p, const DgsLayout& L, DgsCarve* c) {
   c->point_offsets = reinterpret_cast<uint32_t*>(g + L.point_offsets);
   c->scan_tmp = reinterpret_cast<uint32_t*>(g + L.scan_tmp);
   c->num_rendered = reinterpret_cast<uint32_t*>(g + L.num_rendered);
+  c->gsort_keys = reinterpret_cast<uint64_t*>(g + L.gsort_keys);
+  c->gsort_keys_alt = reinterpret_cast<uint64_t*>(g + L.gsort_keys_alt);
+  c->gsort_vals = reinterpret_cast<uint32_t*>(g + L.gsort_vals);
+  c->gsort_vals_alt = reinterpret_cast<uint32_t*>(g + L.gsort_vals_alt);
+  c->tt_sorted = reinterpret_cast<uint32_t*>(g + L.tt_sorted);
+  c->offs_sorted = reinterpret_cast<uint32_t*>(g + L.offs_sorted);
+  c->gsort_tmp = reinterpret_cast<uint32_t*>(g + L.gsort_tmp);
   c->final_T = reinterpret_cast<float*>(im + L.final_T);
   c->n_contrib = reinterpret_cast<uint32_t*>(im + L.n_contrib);
   c->ranges = reinterpret_cast<uint2*>(im + L.ranges);
@@ -315,12 +329,31 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t R
       cd.keys_unsorted = c.keys_sorted;
       cd.vals_unsorted = c.point_list;
     }
-    DGS_STAGE(DGS_STAGE_DUPLICATE, "duplicateWithKeys", dgs_launch_duplicate(v, cd, s));
+    // (1) order the (k, Gaussian) pairs by (k, depth bits, index)
+    const int gbits = 32 + (p->K > 1 ? (int)dgs_higher_msb((uint32_t)p->K) : 0);
+    int g_in_alt = 0;
+    {
+      hipError_t e__;
+      {
+        StageTimer tm__(DGS_STAGE_DEPTH_ORDER, s);
+        e__ = dgs_launch_gaussian_keys(v, c, c.gsort_keys, c.gsort_vals, s);
+        if (e__ == hipSuccess)
+          e__ = dgs_launch_sort(c.gsort_keys, c.gsort_vals, c.gsort_keys_alt, c.gsort_vals_alt,
+                                (uint64_t)p->K * p->P, 0, gbits, c.gsort_tmp, &g_in_alt, s);
+      }
+      if (e__ != hipSuccess) return fail_hip(e__, "depth order");
+      if (p->debug && (e__ = hipStreamSynchronize(s)) != hipSuccess) return fail_hip(e__, "depth order (debug sync)");
+    }
+    const uint32_t* order = g_in_alt ? c.gsort_vals_alt : c.gsort_vals;
+    // (2) duplicate in that order, (3) stable sort on the tile bits only
+    DGS_STAGE(DGS_STAGE_DUPLICATE, "duplicateWithKeys",
+              dgs_launch_duplicate_sorted(v, cd, order, c.tt_sorted, c.offs_sorted, c.scan_tmp, s));
     int in_alt = 0;
     uint64_t* kalt = even ? c.keys_unsorted : c.keys_sorted;
     uint32_t* valt = even ? c.vals_unsorted : c.point_list;
     DGS_STAGE(DGS_STAGE_SORT, "radix sort",
-              dgs_launch_sort(cd.keys_unsorted, cd.vals_unsorted, kalt, valt, R, L.sort_bits, c.sort_tmp, &in_alt, s));
+              dgs_launch_sort(cd.keys_unsorted, cd.vals_unsorted, kalt, valt, R, 32, L.sort_bits, c.sort_tmp, &in_alt,
+                              s));
   }
   DGS_STAGE(DGS_STAGE_RANGES, "identifyTileRanges", dgs_launch_ranges(v, c, R, s));
   DGS_STAGE(DGS_STAGE_COMPOSITE_FWD, "composite forward",
@@ -386,10 +419,11 @@ int dgs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, void* 
 }
 size_t dgs_sort_tmp_bytes(uint64_t n) { return dgs_sort_tmp_words(n) * 4; }
 int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
-                   int32_t end_bit, void* tmp, int32_t* result_in_alt, dgs_stream_t stream) {
+                   int32_t begin_bit, int32_t end_bit, void* tmp, int32_t* result_in_alt, dgs_stream_t stream) {
   if (n >= (1ull << 32)) return fail(DGS_E_ARG, "sort: n must be < 2^32");
+  if (begin_bit < 0 || end_bit > 64 || end_bit <= begin_bit) return fail(DGS_E_ARG, "sort: bad bit range");
   int alt = 0;
-  hipError_t e = dgs_launch_sort(keys, vals, keys_alt, vals_alt, n, end_bit, reinterpret_cast<uint32_t*>(tmp), &alt,
+  hipError_t e = dgs_launch_sort(keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, reinterpret_cast<uint32_t*>(tmp), &alt,
                                  reinterpret_cast<hipStream_t>(stream));
   if (result_in_alt) *result_in_alt = alt;
   return e == hipSuccess ? DGS_OK : fail_hip(e, "sort");

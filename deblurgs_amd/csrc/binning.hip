@@ -171,6 +171,66 @@ duplicate_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __restric
     }
 }
 
+// ------------------------------------------------------------------------------ depth-ordered duplication
+// The duplicates only need a STABLE sort by (k, tile) if they are generated in (k, depth, index) order: the
+// low 32 key bits (depth) are then already in order inside every (k, tile) group, exactly as if the LSD passes
+// over the depth bits had run.  So the K*P Gaussians are sorted by (k, depth_bits) first (15 M pairs instead of
+// R = 63 M, 4 digit passes) and the big sort shrinks from 6 passes over all 49 bits to 2 passes over the
+// bits(K*T) = 17 tile bits.  Sorted keys and point list are bit-identical to the one-big-sort result.
+__global__ void __launch_bounds__(256)
+gaussian_keys_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restrict__ tiles_touched,
+                     uint64_t* __restrict__ gkeys, uint32_t* __restrict__ gvals) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t n = (uint64_t)v.K * v.P;
+  if (i >= n) return;
+  const uint64_t k = i / (uint64_t)v.P;
+  // invisible (k, Gaussian) pairs sort to the end of their subframe and emit nothing
+  const uint32_t low = tiles_touched[i] ? __float_as_uint(rows[i].depth) : 0xFFFFFFFFu;
+  gkeys[i] = (k << 32) | low;
+  gvals[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256)
+gather_u32_kernel(uint64_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ src,
+                  uint32_t* __restrict__ dst) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) dst[j] = src[idx[j]];
+}
+
+// thread j handles the j-th (k, Gaussian) pair in (k, depth, index) order
+__global__ void __launch_bounds__(256)
+duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __restrict__ order,
+                        const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ offs_sorted,
+                        uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
+                        uint32_t* __restrict__ vals) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t n = (uint64_t)v.K * v.P;
+  if (j >= n) return;
+  const uint32_t i = order[j];
+  uint32_t off = offs_sorted[j];
+  point_offsets[i] = off;
+  if (tt_sorted[j] == 0) return;
+  const uint32_t k = i / (uint32_t)v.P;
+  const uint32_t g = i - k * (uint32_t)v.P;
+  DgsRow* row = rows + i;
+  const float x = row->x, y = row->y;
+  const int radius = row->radius;
+  row->dup_offset = off;
+  int minx, miny, maxx, maxy;
+  dgs_get_rect(x, y, radius, v.gx, v.gy, minx, miny, maxx, maxy);
+  const uint32_t dbits = __float_as_uint(row->depth);
+  const uint32_t tbase = k * (uint32_t)v.T;
+  for (int ty = miny; ty < maxy; ty++)
+    for (int tx = minx; tx < maxx; tx++) {
+      uint64_t key = (uint64_t)(tbase + (uint32_t)ty * (uint32_t)v.gx + (uint32_t)tx);
+      key <<= 32;
+      key |= dbits;
+      keys[off] = key;
+      vals[off] = g;
+      off++;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- ranges
 __global__ void __launch_bounds__(256)
 ranges_kernel(uint32_t L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
@@ -543,12 +603,14 @@ struct PassPlan {
   int rb[16];
 };
 
-PassPlan plan_passes(int end_bit) {
+PassPlan plan_passes(int begin_bit, int end_bit) {
   PassPlan p;
-  if (end_bit < 1) end_bit = 1;
+  if (begin_bit < 0) begin_bit = 0;
   if (end_bit > 64) end_bit = 64;
-  p.n = (end_bit + SORT_MAX_RB - 1) / SORT_MAX_RB;
-  int lo = end_bit / p.n, extra = end_bit % p.n, s = 0;
+  if (end_bit < begin_bit + 1) end_bit = begin_bit + 1;
+  const int nbits = end_bit - begin_bit;
+  p.n = (nbits + SORT_MAX_RB - 1) / SORT_MAX_RB;
+  int lo = nbits / p.n, extra = nbits % p.n, s = begin_bit;
   for (int i = 0; i < p.n; i++) {
     p.shift[i] = s;
     p.rb[i] = lo + (i < extra ? 1 : 0);
@@ -574,7 +636,7 @@ hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32
   return hipGetLastError();
 }
 
-int dgs_sort_num_passes(int end_bit) { return plan_passes(end_bit).n; }
+int dgs_sort_num_passes(int begin_bit, int end_bit) { return plan_passes(begin_bit, end_bit).n; }
 
 size_t dgs_sort_tmp_words(uint64_t n) {
   const uint64_t nblocks = (n + SORT_TILE - 1) / SORT_TILE;
@@ -597,8 +659,8 @@ static int sort_mode() {
 }
 
 hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
-                           int end_bit, uint32_t* tmp, int* result_in_alt, hipStream_t s) {
-  const PassPlan plan = plan_passes(end_bit);
+                           int begin_bit, int end_bit, uint32_t* tmp, int* result_in_alt, hipStream_t s) {
+  const PassPlan plan = plan_passes(begin_bit, end_bit);
   *result_in_alt = plan.n & 1;
   if (n == 0) return hipSuccess;
   const uint32_t nblocks = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
@@ -682,6 +744,26 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
 hipError_t dgs_launch_duplicate(const DgsView& v, const DgsCarve& c, hipStream_t s) {
   const uint64_t n = (uint64_t)v.K * v.P;
   hipLaunchKernelGGL(duplicate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, v, c.rows, c.tiles_touched,
+                     c.point_offsets, c.keys_unsorted, c.vals_unsorted);
+  return hipGetLastError();
+}
+
+hipError_t dgs_launch_gaussian_keys(const DgsView& v, const DgsCarve& c, uint64_t* gkeys, uint32_t* gvals,
+                                    hipStream_t s) {
+  const uint64_t n = (uint64_t)v.K * v.P;
+  hipLaunchKernelGGL(gaussian_keys_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, v, c.rows,
+                     c.tiles_touched, gkeys, gvals);
+  return hipGetLastError();
+}
+
+hipError_t dgs_launch_duplicate_sorted(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* tt_sorted,
+                                       uint32_t* offs_sorted, uint32_t* scan_tmp, hipStream_t s) {
+  const uint64_t n = (uint64_t)v.K * v.P;
+  const dim3 grid((uint32_t)((n + 255) / 256));
+  hipLaunchKernelGGL(gather_u32_kernel, grid, dim3(256), 0, s, n, order, c.tiles_touched, tt_sorted);
+  hipError_t e = dgs_launch_scan(tt_sorted, offs_sorted, n, scan_tmp, nullptr, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(duplicate_sorted_kernel, grid, dim3(256), 0, s, v, c.rows, order, tt_sorted, offs_sorted,
                      c.point_offsets, c.keys_unsorted, c.vals_unsorted);
   return hipGetLastError();
 }

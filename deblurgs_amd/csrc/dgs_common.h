@@ -30,6 +30,13 @@ struct DgsCarve {  // resolved device pointers of the three blobs
   uint32_t* point_offsets;
   uint32_t* scan_tmp;
   uint32_t* num_rendered;
+  uint64_t* gsort_keys;      // (k << 32 | depth_bits) per (k, Gaussian), and its ping-pong buffer
+  uint64_t* gsort_keys_alt;
+  uint32_t* gsort_vals;      // flat (k, Gaussian) index; sorted = (k, depth, index) order
+  uint32_t* gsort_vals_alt;
+  uint32_t* tt_sorted;       // tiles_touched in that order, and its exclusive scan
+  uint32_t* offs_sorted;
+  uint32_t* gsort_tmp;
   float* final_T;
   uint32_t* n_contrib;
   uint2* ranges;
@@ -122,7 +129,11 @@ hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hi
 hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, uint32_t* total,
                            hipStream_t s);
 hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
-                           int end_bit, uint32_t* tmp, int* result_in_alt, hipStream_t s);
+                           int begin_bit, int end_bit, uint32_t* tmp, int* result_in_alt, hipStream_t s);
+hipError_t dgs_launch_gaussian_keys(const DgsView& v, const DgsCarve& c, uint64_t* gkeys, uint32_t* gvals,
+                                    hipStream_t s);
+hipError_t dgs_launch_duplicate_sorted(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* tt_sorted,
+                                       uint32_t* offs_sorted, uint32_t* scan_tmp, hipStream_t s);
 hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,
                                     float* out_depth, hipStream_t s);
 hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const float* bg, const float* dL_dpix,
@@ -134,5 +145,5 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
 
 size_t dgs_scan_tmp_words(uint64_t n);
 size_t dgs_sort_tmp_words(uint64_t n);
-int dgs_sort_num_passes(int end_bit);
+int dgs_sort_num_passes(int begin_bit, int end_bit);
 int dgs_geometry_bwd_blocks(int P);

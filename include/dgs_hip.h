@@ -10,6 +10,9 @@
  *     into sub-arrays is a pure function of (P, W, H, K, R), replayed identically by forward and backward
  *     (the reference does the same with GeometryState/ImageState/BinningState::fromChunk,
  *     rasterizer_impl.cu:155-194,389-391).
+ *   - the duplicates are generated in (k, depth, index) order (a 15 M-pair sort of the Gaussians) so that the
+ *     R-pair sort only has to order the bits(K*T) tile bits; sorted keys / point list are bit-identical to the
+ *     reference's single (tile | depth) sort.
  *   - K >= 1 subframes per call ("K-fused"): one launch chain rasterises all K poses of a blurry view
  *     (scene/motion.py:141-143 calls render() K times).  K = 1 is exactly `_C.rasterize_gaussians`.
  *   - the forward is split in two calls around the one host read of num_rendered
@@ -107,9 +110,16 @@ typedef struct DgsLayout {
   size_t cov3D;          /* f32 [P,6] */
   size_t pre_sigmoid;    /* f32 [K,P,3]  pre-activation colour (sigmoid) or 0/1 clamp mask (relu) */
   size_t tiles_touched;  /* u32 [K*P] */
-  size_t point_offsets;  /* u32 [K*P] exclusive prefix sum of tiles_touched */
+  size_t point_offsets;  /* u32 [K*P] first duplicate index of each (k, Gaussian) */
   size_t scan_tmp;       /* u32 scan block sums */
   size_t num_rendered;   /* u32 [4] device copy of R (+ spare) */
+  size_t gsort_keys;     /* u64 [K*P] (k << 32) | depth_bits: the (k, depth, index) ordering of the Gaussians */
+  size_t gsort_keys_alt; /* u64 [K*P] */
+  size_t gsort_vals;     /* u32 [K*P] flat (k, Gaussian) indices */
+  size_t gsort_vals_alt; /* u32 [K*P] */
+  size_t tt_sorted;      /* u32 [K*P] tiles_touched in (k, depth, index) order */
+  size_t offs_sorted;    /* u32 [K*P] its exclusive prefix sum */
+  size_t gsort_tmp;      /* u32 radix tables of the Gaussian sort */
   size_t geom_total;
   /* image blob */
   size_t final_T;        /* f32 [K,H*W] */
@@ -123,8 +133,8 @@ typedef struct DgsLayout {
   size_t vals_unsorted;  /* u32 [R] */
   size_t sort_tmp;       /* u32 radix histogram table */
   size_t binning_total;
-  int32_t sort_bits;     /* 32 + bits(K*T) */
-  int32_t sort_passes;
+  int32_t sort_bits;     /* 32 + bits(K*T): width of the reference-compatible key */
+  int32_t sort_passes;   /* digit passes of the duplicate sort (over the tile bits [32, sort_bits) only) */
 } DgsLayout;
 
 int dgs_abi_version(void);
@@ -155,10 +165,10 @@ size_t dgs_scan_tmp_bytes(uint64_t n);
 int dgs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, void* tmp, uint32_t* total_out,
                            dgs_stream_t stream);
 size_t dgs_sort_tmp_bytes(uint64_t n);
-/* Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [0, end_bit).  Both buffer pairs are
+/* Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [begin_bit, end_bit).  Both buffer pairs are
  * clobbered; *result_in_alt tells which pair holds the result (0: keys/vals, 1: keys_alt/vals_alt). */
 int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
-                   int32_t end_bit, void* tmp, int32_t* result_in_alt, dgs_stream_t stream);
+                   int32_t begin_bit, int32_t end_bit, void* tmp, int32_t* result_in_alt, dgs_stream_t stream);
 
 /* Fused loss-gradient image (train.py:143-165, utils/loss_utils.py:17-18,80-93): from the K rendered
  * subframes and the target, produces blur = mean_k, the L1 and temporal-smoothness loss values and
@@ -175,7 +185,8 @@ int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32
 #define DGS_STAGE_COMPOSITE_FWD 5
 #define DGS_STAGE_COMPOSITE_BWD 6
 #define DGS_STAGE_GEOMETRY_BWD 7
-#define DGS_STAGE_COUNT 8
+#define DGS_STAGE_DEPTH_ORDER 8 /* sort of the (k, Gaussian) pairs by depth that precedes the duplication */
+#define DGS_STAGE_COUNT 9
 int dgs_profile_enable(int32_t on);
 int dgs_profile_reset(void);
 /* Synchronises on the recorded events; ms[i] = summed duration of stage i, calls[i] = launches timed. */

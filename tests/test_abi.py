@@ -39,7 +39,7 @@ def test_struct_sizes_match_the_header_layout():
     assert ctypes.sizeof(_lib.DgsProblem) == 56 + 11 * 8 + 3 * 16
     assert ctypes.sizeof(_lib.DgsForwardOut) == 32
     assert ctypes.sizeof(_lib.DgsBackwardIO) == 8 + 8 * 3 + 16 + 10 * 8
-    assert ctypes.sizeof(_lib.DgsLayout) == 18 * 8 + 8
+    assert ctypes.sizeof(_lib.DgsLayout) == 25 * 8 + 8
 
 
 def test_size_queries_and_layout():
@@ -51,7 +51,7 @@ def test_size_queries_and_layout():
     assert lay.image_total == L.dgs_image_state_bytes(W, H, K)
     assert lay.binning_total == L.dgs_binning_state_bytes(R, W, H, K)
     T = 120 * 68
-    assert lay.sort_bits == 32 + 17 and lay.sort_passes == 6          # bits(15*8160) = 17
+    assert lay.sort_bits == 32 + 17 and lay.sort_passes == 2          # bits(15*8160) = 17 tile bits, 2 digit passes
     assert _lib.layout(P, W, H, 1, R).sort_bits == 45                  # the reference's key width at 1080p
     assert lay.geom_rows == 0 and lay.cov3D >= K * P * 48
     assert lay.final_T == 0 and lay.n_contrib >= K * W * H * 4 and lay.ranges >= 2 * K * W * H * 4

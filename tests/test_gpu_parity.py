@@ -61,12 +61,14 @@ def test_radix_sort_pairs_stable(gpu, n, bits):
     tmp = torch.empty(L.dgs_sort_tmp_bytes(n) + 16, dtype=torch.uint8, device=gpu)
     alt = ctypes.c_int32(0)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(L.dgs_sort_pairs(k0.data_ptr(), v0.data_ptr(), k1.data_ptr(), v1.data_ptr(), n, bits, tmp.data_ptr(),
-                                ctypes.byref(alt), st), "sort")
+    begin = 0 if n % 2 == 0 else min(5, bits - 1)      # also exercise begin_bit > 0
+    _lib.check(L.dgs_sort_pairs(k0.data_ptr(), v0.data_ptr(), k1.data_ptr(), v1.data_ptr(), n, begin, bits,
+                                tmp.data_ptr(), ctypes.byref(alt), st), "sort")
     torch.cuda.synchronize()
     ko = (k1 if alt.value else k0).cpu().numpy().view(np.uint64)
     vo = (v1 if alt.value else v0).cpu().numpy().view(np.uint32)
     mask = np.uint64((1 << bits) - 1) if bits < 64 else np.uint64(2 ** 64 - 1)
+    mask &= ~np.uint64((1 << begin) - 1)
     order = np.argsort(keys & mask, kind="stable")
     assert np.array_equal(vo, vals[order])
     assert np.array_equal(ko, keys[order])
@@ -105,9 +107,17 @@ def test_binning_bit_exact(scene_states):
     P, T = sc["P"], hip["T"]
     Rs = [o["num_rendered"] for o in ora]
     assert hip["R"] == sum(Rs)
-    # exclusive offsets over the [K,P] order
+    # duplicates are laid out in (k, depth bits, index) order: exclusive offsets over that order
     flat_tt = hip["tiles_touched"].reshape(-1).astype(np.uint64)
-    assert np.array_equal(hip["point_offsets"].reshape(-1), np.concatenate([[0], np.cumsum(flat_tt)[:-1]]).astype(np.uint32))
+    dbits = np.stack([o["depths"].view(np.uint32) for o in ora]).astype(np.uint64)
+    low = np.where(hip["tiles_touched"] > 0, dbits, np.uint64(0xFFFFFFFF))
+    gkey = (np.arange(sc["K"], dtype=np.uint64)[:, None] << np.uint64(32) | low).reshape(-1)
+    order = np.argsort(gkey, kind="stable")
+    offs = np.zeros(order.size, np.uint64)
+    offs[order] = np.concatenate([[0], np.cumsum(flat_tt[order])[:-1]])
+    vis_flat = flat_tt > 0
+    assert np.array_equal(hip["point_offsets"].reshape(-1)[vis_flat], offs[vis_flat].astype(np.uint32))
+    assert np.array_equal(hip["rows_u32"].reshape(-1, 12)[vis_flat, 10], offs[vis_flat].astype(np.uint32))
     off = 0
     for k, o in enumerate(ora):
         R = Rs[k]

@@ -17,7 +17,7 @@ def run():
     k0.copy_(keys); v0.copy_(vals)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.check(L.dgs_sort_pairs(k0.data_ptr(), v0.data_ptr(), k1.data_ptr(), v1.data_ptr(), n, bits, tmp.data_ptr(), ctypes.byref(alt), st), "sort")
+    _lib.check(L.dgs_sort_pairs(k0.data_ptr(), v0.data_ptr(), k1.data_ptr(), v1.data_ptr(), n, 0, bits, tmp.data_ptr(), ctypes.byref(alt), st), "sort")
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)
 ts = [run() for _ in range(6)]
