@@ -234,11 +234,11 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   const float qx0 = (float)(t.tx * DGS_TILE), qy0 = (float)(t.ty * DGS_TILE);
   const size_t N = (size_t)v.W * v.H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  const float ddelx_dx = 0.5f * (float)v.W, ddely_dy = 0.5f * (float)v.H;  // backward.cu:535-536
+  
 
   // per-pixel channel state kept as (r,g) and (b,depth) pairs so the channel arithmetic issues as packed fp32
-  float T[4], Tfin[4], lalpha[4], bgdot[4];
-  v2f accA[4], accB[4], lcA[4], lcB[4], gA[4], gB[4];
+  float T[4], tb[4];  // tb = -T_final * (bg . dL_dpixel + z_far * dL_ddepthpix), backward.cu:613-618
+  v2f accA[4], accB[4], gA[4], gB[4];
   uint32_t last[4];
   uint32_t maxc = 0;
 #pragma unroll
@@ -246,8 +246,8 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
     const bool inside = (px < v.W && py < v.H);
     const size_t pix = (size_t)py * v.W + px;
-    Tfin[q] = inside ? final_T[(size_t)t.k * N + pix] : 0.0f;
-    T[q] = Tfin[q];
+    const float Tfin = inside ? final_T[(size_t)t.k * N + pix] : 0.0f;
+    T[q] = Tfin;
     last[q] = inside ? n_contrib[(size_t)t.k * N + pix] : 0u;
     const float* gp = dL_dpix + (size_t)t.k * 3 * N;
     const float g0 = inside ? gp[pix] : 0.0f;
@@ -256,9 +256,8 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     const float gd = (inside && dL_ddepth != nullptr) ? dL_ddepth[(size_t)t.k * N + pix] : 0.0f;
     gA[q] = (v2f){g0, g1};
     gB[q] = (v2f){g2, gd};
-    bgdot[q] = bg0 * g0 + bg1 * g1 + bg2 * g2 + v.z_far * gd;  // backward.cu:613-617
-    accA[q] = accB[q] = lcA[q] = lcB[q] = (v2f){0.0f, 0.0f};
-    lalpha[q] = 0.0f;
+    tb[q] = -Tfin * (bg0 * g0 + bg1 * g1 + bg2 * g2 + v.z_far * gd);
+    accA[q] = accB[q] = (v2f){0.0f, 0.0f};
     maxc = max(maxc, last[q]);
   }
   // wave-wide max of n_contrib: entries at or beyond it are skipped by every pixel (backward.cu:566-568)
@@ -328,32 +327,30 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         if ((m[q] >> j) & 1ull) {  // wave-uniform
           const float dx = (q & 1) ? dx1 : dx0;
           const float dy = (q >> 1) ? dy1 : dy0;
-          // backward.cu:566-637, branch-free.  A pair that the reference skips gets alpha = 0 and G = 0: then
-          // T/(1-alpha) = T, every gradient term is an exact 0, and the accum_rec recurrence
-          //   accum = last_alpha*last_c + (1-last_alpha)*accum;  last_c = c;  last_alpha = alpha
-          // merely applies its pending update early (the next valid pair would compute 0*c + 1*accum = accum),
-          // so the results are bit-identical to skipping.
+          // backward.cu:566-637, branch-free.  A pair that the reference skips gets alpha = 0: then
+          // T/(1-alpha) = T, every gradient term is an exact 0 and the colour-behind recurrence below is the
+          // identity (0*c + 1*acc), so the results are bit-identical to skipping.  The recurrence is applied
+          // eagerly (acc <- alpha*c + (1-alpha)*acc right after the pair is used) instead of one pair late with a
+          // remembered last_alpha / last_color as in the reference: same operations in the same order, 5 fewer
+          // live registers per pixel.
           const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
           const float au = b.y * __expf(power);  // opacity * G: the unclamped alpha the backward differentiates
           const float alpha_raw = fminf(0.99f, au);
           const bool ok = (pos < last[q]) && (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
           touched = touched || ok;
           const float alpha = ok ? alpha_raw : 0.0f;
-          const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+          const float oma = 1.0f - alpha;
+          const float inv1ma = __builtin_amdgcn_rcpf(oma);
           T[q] = T[q] * inv1ma;
           const float dchannel_dcolor = alpha * T[q];
-          const float oml = 1.f - lalpha[q];
-          accA[q] = lcA[q] * lalpha[q] + accA[q] * oml;
-          accB[q] = lcB[q] * lalpha[q] + accB[q] * oml;
-          lcA[q] = colA;
-          lcB[q] = colB;
-          lalpha[q] = alpha;
           const v2f dd = (colA - accA[q]) * gA[q] + (colB - accB[q]) * gB[q];
           float dL_dalpha = dd.x + dd.y;
           sA += gA[q] * dchannel_dcolor;
           sB += gB[q] * dchannel_dcolor;
+          accA[q] = colA * alpha + accA[q] * oma;
+          accB[q] = colB * alpha + accB[q] * oma;
           dL_dalpha *= T[q];
-          dL_dalpha += (-Tfin[q] * inv1ma) * bgdot[q];
+          dL_dalpha += tb[q] * inv1ma;
           const float wgt = ok ? au * dL_dalpha : 0.0f;
           const float wx = wgt * dx, wy = wgt * dy;
           S_w += wgt;
