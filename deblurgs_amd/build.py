@@ -18,6 +18,7 @@ SOURCES = {
     # SLP packing into v_pk_*_f32 costs more v_mov shuffles than it saves here (920 vs 715 VALU instructions)
     "composite.hip": ["-fno-slp-vectorize"],
     "geometry_bwd.hip": [],
+    "pose.hip": [],
     "api.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fhip-fp32-correctly-rounded-divide-sqrt",

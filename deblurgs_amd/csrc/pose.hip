@@ -1,0 +1,258 @@
+// pose.hip -- the pose path of the blur-integration loop as ONE kernel per direction:
+//   Bezier(control points, nu) -> se(3) -> se3_exp_map -> world_view, full_proj, camera_center for all K
+//   subframes, and its backward from dL/d{world_view, full_proj} to the control points and nu.
+// Replaces ~250 micro-kernels per training step in the reference (scene/bezier.py:54-83,
+// utils/pytorch3d_functions.py:218-247,373-457,546-573, scene/motion.py:248-294, scene/cameras.py:63-74).
+//
+// Numerics follow the reference: the Bernstein powers are float32 (torch pow on float32 nu), everything after
+// the float64 binomial table is float64, the world_view matrix is rounded to float32 before full_proj = view @ P.
+// The backward differentiates the exponential map with forward-mode dual numbers (6 directions), so there is
+// no hand-derived Jacobian to get wrong; eps-clamping of the squared angle has zero gradient like torch.clamp.
+#include "dgs_common.h"
+
+namespace {
+
+constexpr int MAX_ORDER = 32;
+
+struct D6 {  // value + gradient w.r.t. the 6 se(3) coordinates (trans xyz, rot xyz)
+  double v;
+  double d[6];
+};
+__device__ __forceinline__ D6 cst(double x) {
+  D6 r;
+  r.v = x;
+#pragma unroll
+  for (int i = 0; i < 6; i++) r.d[i] = 0.0;
+  return r;
+}
+__device__ __forceinline__ D6 var(double x, int i) {
+  D6 r = cst(x);
+  r.d[i] = 1.0;
+  return r;
+}
+__device__ __forceinline__ D6 operator+(const D6& a, const D6& b) {
+  D6 r;
+  r.v = a.v + b.v;
+#pragma unroll
+  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] + b.d[i];
+  return r;
+}
+__device__ __forceinline__ D6 operator-(const D6& a, const D6& b) {
+  D6 r;
+  r.v = a.v - b.v;
+#pragma unroll
+  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] - b.d[i];
+  return r;
+}
+__device__ __forceinline__ D6 operator-(const D6& a) {
+  D6 r;
+  r.v = -a.v;
+#pragma unroll
+  for (int i = 0; i < 6; i++) r.d[i] = -a.d[i];
+  return r;
+}
+__device__ __forceinline__ D6 operator*(const D6& a, const D6& b) {
+  D6 r;
+  r.v = a.v * b.v;
+#pragma unroll
+  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  return r;
+}
+__device__ __forceinline__ D6 operator/(const D6& a, const D6& b) {
+  D6 r;
+  const double inv = 1.0 / b.v;
+  r.v = a.v * inv;
+#pragma unroll
+  for (int i = 0; i < 6; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+  return r;
+}
+__device__ __forceinline__ D6 dsqrt(const D6& a) {
+  D6 r;
+  r.v = sqrt(a.v);
+  const double k = 0.5 / r.v;
+#pragma unroll
+  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * k;
+  return r;
+}
+__device__ __forceinline__ D6 dsin(const D6& a) {
+  D6 r;
+  r.v = sin(a.v);
+  const double c = cos(a.v);
+#pragma unroll
+  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * c;
+  return r;
+}
+__device__ __forceinline__ D6 dcos(const D6& a) {
+  D6 r;
+  r.v = cos(a.v);
+  const double s = -sin(a.v);
+#pragma unroll
+  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * s;
+  return r;
+}
+__device__ __forceinline__ D6 dclamp_min(const D6& a, double lo) { return a.v < lo ? cst(lo) : a; }
+
+// scene/bezier.py:54-64: coeff_c = binom(C,c) * t^(C-c) * (1-t)^c with float32 powers; also d coeff / dt
+__device__ __forceinline__ void bernstein(int C, float t, double* coeff, double* dcoeff) {
+  double binom = 1.0;
+  const float u = 1.0f - t;
+  for (int c = 0; c <= C; c++) {
+    if (c > 0) binom = binom * (double)(C - c + 1) / (double)c;
+    const float pa = powf(t, (float)(C - c));
+    const float pb = powf(u, (float)c);
+    coeff[c] = (double)(pa * pb) * binom;
+    if (dcoeff != nullptr) {
+      const double da = (C - c) > 0 ? (double)(C - c) * pow((double)t, (double)(C - c - 1)) : 0.0;
+      const double db = c > 0 ? -(double)c * pow((double)u, (double)(c - 1)) : 0.0;
+      dcoeff[c] = binom * (da * (double)pb + (double)pa * db);
+    }
+  }
+}
+
+// utils/pytorch3d_functions.py:218-247,373-457,546-573 on dual numbers: R (row-major 3x3) and T = V @ trans
+__device__ void se3_exp(const D6 se3[6], D6 R[9], D6 T[3]) {
+  const double eps = 1e-4;
+  const D6 &wx = se3[3], &wy = se3[4], &wz = se3[5];
+  const D6 nrm = wx * wx + wy * wy + wz * wz;
+  const D6 ang = dsqrt(dclamp_min(nrm, eps));
+  const D6 inv = cst(1.0) / ang;
+  const D6 sn = dsin(ang), cs = dcos(ang);
+  const D6 fac1 = inv * sn;
+  const D6 fac2 = inv * inv * (cst(1.0) - cs);
+  const D6 z = cst(0.0);
+  // hat(w) (pytorch3d_functions.py:337-372) and its square
+  const D6 S[9] = {z, -wz, wy, wz, z, -wx, -wy, wx, z};
+  D6 S2[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) S2[3 * r + c] = S[3 * r] * S[c] + S[3 * r + 1] * S[3 + c] + S[3 * r + 2] * S[6 + c];
+  const D6 va = (cst(1.0) - cs) / (ang * ang);
+  const D6 vb = (ang - sn) / (ang * ang * ang);
+  D6 V[9];
+  for (int i = 0; i < 9; i++) {
+    const D6 eye = cst((i % 4 == 0) ? 1.0 : 0.0);
+    R[i] = fac1 * S[i] + fac2 * S2[i] + eye;
+    V[i] = eye + S[i] * va + S2[i] * vb;
+  }
+  for (int r = 0; r < 3; r++) T[r] = V[3 * r] * se3[0] + V[3 * r + 1] * se3[1] + V[3 * r + 2] * se3[2];
+}
+
+// One thread per subframe.  MODE 0: forward outputs.  MODE 1: dL_dse3[k][6] and dL_dnu[k].
+template <int MODE>
+__global__ void pose_kernel(int C, int K, const float* __restrict__ ctrl_trans, const float* __restrict__ ctrl_rot,
+                            const float* __restrict__ nu, const float* __restrict__ proj, float* __restrict__ view,
+                            float* __restrict__ full, float* __restrict__ campos, const float* __restrict__ dL_dview,
+                            const float* __restrict__ dL_dfull, double* __restrict__ dL_dse3,
+                            float* __restrict__ dL_dnu, double* __restrict__ coeff_out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  double coeff[MAX_ORDER + 1], dcoeff[MAX_ORDER + 1];
+  bernstein(C, nu[k], coeff, MODE == 1 ? dcoeff : nullptr);
+  double s[6] = {0, 0, 0, 0, 0, 0}, ds[6] = {0, 0, 0, 0, 0, 0};
+  for (int c = 0; c <= C; c++)
+    for (int d = 0; d < 3; d++) {
+      s[d] += coeff[c] * (double)ctrl_trans[3 * c + d];
+      s[3 + d] += coeff[c] * (double)ctrl_rot[3 * c + d];
+      if (MODE == 1) {
+        ds[d] += dcoeff[c] * (double)ctrl_trans[3 * c + d];
+        ds[3 + d] += dcoeff[c] * (double)ctrl_rot[3 * c + d];
+      }
+    }
+  D6 se3[6];
+  for (int i = 0; i < 6; i++) se3[i] = var(s[i], i);
+  D6 R[9], T[3];
+  se3_exp(se3, R, T);
+  // scene/motion.py:277-279 (c2w rotation = R, translation = T in the row-vector convention):
+  //   world_view[:3,:3] = R, world_view[3,:3] = -T @ R, rounded to float32
+  if (MODE == 0) {
+    float wv[16];
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) wv[4 * r + c] = (float)R[3 * r + c].v;
+      wv[4 * r + 3] = 0.0f;
+    }
+    for (int c = 0; c < 3; c++) wv[12 + c] = (float)(-(T[0].v * R[c].v + T[1].v * R[3 + c].v + T[2].v * R[6 + c].v));
+    wv[15] = 1.0f;
+    for (int i = 0; i < 16; i++) view[16 * k + i] = wv[i];
+    for (int r = 0; r < 4; r++)
+      for (int c = 0; c < 4; c++) {
+        float acc = 0.0f;
+        for (int j = 0; j < 4; j++) acc += wv[4 * r + j] * proj[4 * j + c];
+        full[16 * k + 4 * r + c] = acc;
+      }
+    // camera_center = inverse(world_view)[3,:3] (scene/cameras.py:73-74) == T for a rigid transform
+    for (int d = 0; d < 3; d++) campos[3 * k + d] = (float)T[d].v;
+    if (coeff_out != nullptr)
+      for (int c = 0; c <= C; c++) coeff_out[(size_t)k * (MAX_ORDER + 1) + c] = coeff[c];
+  } else {
+    // G = dL/dworld_view = dL_dview + dL_dfull @ P^T
+    double G[16];
+    for (int r = 0; r < 4; r++)
+      for (int c = 0; c < 4; c++) {
+        double acc = (double)dL_dview[16 * k + 4 * r + c];
+        for (int j = 0; j < 4; j++) acc += (double)dL_dfull[16 * k + 4 * r + j] * (double)proj[4 * c + j];
+        G[4 * r + c] = acc;
+      }
+    double g[6] = {0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        const double gR = G[4 * r + c] - G[12 + c] * T[r].v;  // through world_view[r][c] and world_view[3][c]
+        const double gT = -G[12 + c] * R[3 * r + c].v;        // dL/dT[r] contribution
+        for (int i = 0; i < 6; i++) g[i] += gR * R[3 * r + c].d[i] + gT * T[r].d[i];
+      }
+    double gn = 0.0;
+    for (int i = 0; i < 6; i++) {
+      dL_dse3[6 * k + i] = g[i];
+      gn += g[i] * ds[i];
+    }
+    dL_dnu[k] = (float)gn;
+    for (int c = 0; c <= C; c++) coeff_out[(size_t)k * (MAX_ORDER + 1) + c] = coeff[c];
+  }
+}
+
+// dL/dctrl[c][d] = sum_k coeff[k][c] * dL_dse3[k][d], summed in k order (deterministic)
+__global__ void pose_ctrl_grad_kernel(int C, int K, const double* __restrict__ coeff, const double* __restrict__ dL_dse3,
+                                      float* __restrict__ dL_dctrl_trans, float* __restrict__ dL_dctrl_rot) {
+  const int i = threadIdx.x;  // (c, d) pair, d in 0..5
+  if (i >= (C + 1) * 6) return;
+  const int c = i / 6, d = i % 6;
+  double acc = 0.0;
+  for (int k = 0; k < K; k++) acc += coeff[(size_t)k * (MAX_ORDER + 1) + c] * dL_dse3[6 * k + d];
+  if (d < 3)
+    dL_dctrl_trans[3 * c + d] = (float)acc;
+  else
+    dL_dctrl_rot[3 * c + d - 3] = (float)acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dgs_pose_scratch_bytes(int32_t K) { return (size_t)K * (6 + MAX_ORDER + 1) * sizeof(double) + 256; }
+
+int dgs_pose_forward(const float* ctrl_trans, const float* ctrl_rot, const float* nu, const float* proj, int32_t C,
+                     int32_t K, float* view, float* full, float* campos, dgs_stream_t stream) {
+  if (C < 0 || C > MAX_ORDER || K < 1 || ctrl_trans == nullptr || ctrl_rot == nullptr || nu == nullptr ||
+      proj == nullptr || view == nullptr || full == nullptr || campos == nullptr)
+    return DGS_E_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(pose_kernel<0>, dim3((K + 63) / 64), dim3(64), 0, s, C, K, ctrl_trans, ctrl_rot, nu, proj, view,
+                     full, campos, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return hipGetLastError() == hipSuccess ? DGS_OK : DGS_E_HIP;
+}
+
+int dgs_pose_backward(const float* ctrl_trans, const float* ctrl_rot, const float* nu, const float* proj, int32_t C,
+                      int32_t K, const float* dL_dview, const float* dL_dfull, void* scratch, float* dL_dctrl_trans,
+                      float* dL_dctrl_rot, float* dL_dnu, dgs_stream_t stream) {
+  if (C < 0 || C > MAX_ORDER || K < 1 || (C + 1) * 6 > 1024 || ctrl_trans == nullptr || ctrl_rot == nullptr ||
+      nu == nullptr || proj == nullptr || dL_dview == nullptr || dL_dfull == nullptr || scratch == nullptr ||
+      dL_dctrl_trans == nullptr || dL_dctrl_rot == nullptr || dL_dnu == nullptr)
+    return DGS_E_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  double* dse3 = reinterpret_cast<double*>(scratch);
+  double* coeff = dse3 + (size_t)6 * K;
+  hipLaunchKernelGGL(pose_kernel<1>, dim3((K + 63) / 64), dim3(64), 0, s, C, K, ctrl_trans, ctrl_rot, nu, proj, nullptr,
+                     nullptr, nullptr, dL_dview, dL_dfull, dse3, dL_dnu, coeff);
+  hipLaunchKernelGGL(pose_ctrl_grad_kernel, dim3(1), dim3(256), 0, s, C, K, coeff, dse3, dL_dctrl_trans, dL_dctrl_rot);
+  return hipGetLastError() == hipSuccess ? DGS_OK : DGS_E_HIP;
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import gaussian_renderer
-from .pose import BezierModel, MiniCam, get_projection_matrix, se3_exp_map, c2w_to_view_proj
+from .pose import BezierModel, MiniCam, get_projection_matrix, se3_exp_map, c2w_to_view_proj, fused_trajectory
 
 
 def inverse_sigmoid(x):
@@ -97,8 +97,18 @@ class CameraMotionModule:
         c2w = se3_exp_map(se3)
         return c2w[:, :3, :3].transpose(-2, -1), c2w[:, 3, :3]
 
-    def get_trajectory_matrices(self, idx, t=None):
-        """Batched _c2w_to_minicam: (world_view [K,4,4], full_proj [K,4,4], camera_center [K,3])."""
+    def get_trajectory_matrices(self, idx, t=None, fused=None):
+        """Batched _c2w_to_minicam: (world_view [K,4,4], full_proj [K,4,4], camera_center [K,3]).
+        On device tensors the whole chain nu -> Bezier -> se3_exp_map -> cameras runs as one HIP kernel
+        (pose.fused_trajectory); `fused=False` forces the torch-op reference implementation."""
+        use_fused = self.device.type == "cuda" if fused is None else fused
+        if use_fused:
+            nu = self._sample_nu_from_alignment(idx) if t is None else t.to(self.device)
+            if isinstance(idx, int):
+                ct, cr = self._trans._control_points[idx], self._rot._control_points[idx]
+            else:
+                ct, cr = self._trans._control_points[idx][0], self._rot._control_points[idx][0]
+            return fused_trajectory(ct, cr, nu, self.ref_cam.projection_matrix)
         rots, transes = self._sample_c2w_from_nu(idx, t)
         return c2w_to_view_proj(rots, transes, self.ref_cam.projection_matrix)
 

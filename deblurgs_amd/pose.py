@@ -156,6 +156,57 @@ class MiniCam:
         self.camera_center = camera_center
 
 
+class _FusedTrajectory(torch.autograd.Function):
+    """(ctrl_trans [C+1,3], ctrl_rot [C+1,3], nu [K], proj_T [4,4]) -> (world_view, full_proj, camera_center) through
+    the single-kernel pose path of libdgs_hip.so (csrc/pose.hip); same math as BezierModel + se3_exp_map +
+    c2w_to_view_proj, which stay as the torch reference implementation (and the CPU path of the tests)."""
+
+    @staticmethod
+    def forward(ctx, ctrl_trans, ctrl_rot, nu, proj_T):
+        import ctypes
+        from . import _lib
+        L = _lib.lib()
+        dev = ctrl_trans.device
+        ct = ctrl_trans.detach().float().contiguous()
+        cr = ctrl_rot.detach().float().contiguous()
+        t = nu.detach().float().contiguous()
+        pj = proj_T.detach().float().contiguous()
+        C, K = ct.shape[0] - 1, t.shape[0]
+        view = torch.empty((K, 4, 4), dtype=torch.float32, device=dev)
+        full = torch.empty((K, 4, 4), dtype=torch.float32, device=dev)
+        cam = torch.empty((K, 3), dtype=torch.float32, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(L.dgs_pose_forward(ct.data_ptr(), cr.data_ptr(), t.data_ptr(), pj.data_ptr(), C, K,
+                                      view.data_ptr(), full.data_ptr(), cam.data_ptr(), st), "dgs_pose_forward")
+        ctx.save_for_backward(ct, cr, t, pj)
+        ctx.mark_non_differentiable(cam)
+        return view, full, cam
+
+    @staticmethod
+    def backward(ctx, g_view, g_full, _g_cam):
+        import ctypes
+        from . import _lib
+        L = _lib.lib()
+        ct, cr, t, pj = ctx.saved_tensors
+        dev = ct.device
+        C, K = ct.shape[0] - 1, t.shape[0]
+        gv = torch.zeros((K, 4, 4), dtype=torch.float32, device=dev) if g_view is None else g_view.float().contiguous()
+        gf = torch.zeros((K, 4, 4), dtype=torch.float32, device=dev) if g_full is None else g_full.float().contiguous()
+        d_ct, d_cr = torch.empty_like(ct), torch.empty_like(cr)
+        d_nu = torch.empty_like(t)
+        scratch = torch.empty(L.dgs_pose_scratch_bytes(K), dtype=torch.uint8, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(L.dgs_pose_backward(ct.data_ptr(), cr.data_ptr(), t.data_ptr(), pj.data_ptr(), C, K, gv.data_ptr(),
+                                       gf.data_ptr(), scratch.data_ptr(), d_ct.data_ptr(), d_cr.data_ptr(),
+                                       d_nu.data_ptr(), st), "dgs_pose_backward")
+        return d_ct, d_cr, d_nu, None
+
+
+def fused_trajectory(ctrl_trans, ctrl_rot, nu, projection_matrix):
+    """Single-kernel pose path (device tensors only)."""
+    return _FusedTrajectory.apply(ctrl_trans, ctrl_rot, nu, projection_matrix)
+
+
 def c2w_to_view_proj(rots, transes, projection_matrix):
     """Batched core of scene/motion.py:258-294: c2w rotations [K,3,3] + translations [K,3] ->
     (world_view [K,4,4], full_proj [K,4,4], camera_center [K,3]), differentiable w.r.t. rots/transes."""

@@ -176,6 +176,18 @@ int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t*
 int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW,
                        float lambda_t, float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream);
 
+/* Pose path of the blur-integration loop on device: Bezier curves in se(3) evaluated at the K
+ * subframe times nu, se3_exp_map, and the three camera tensors render() reads -- scene/bezier.py:54-83,
+ * utils/pytorch3d_functions.py:373-457, scene/motion.py:248-294, scene/cameras.py:63-74 -- as one kernel, and its
+ * backward from dL/d{world_view, full_proj} to the control points and nu.  ctrl_* are [C+1,3] (one curve),
+ * proj is the transposed projection matrix [4,4] (row-vector convention), outputs are [K,4,4], [K,4,4], [K,3]. */
+size_t dgs_pose_scratch_bytes(int32_t K);
+int dgs_pose_forward(const float* ctrl_trans, const float* ctrl_rot, const float* nu, const float* proj, int32_t C,
+                     int32_t K, float* view, float* full, float* campos, dgs_stream_t stream);
+int dgs_pose_backward(const float* ctrl_trans, const float* ctrl_rot, const float* nu, const float* proj, int32_t C,
+                      int32_t K, const float* dL_dview, const float* dL_dfull, void* scratch, float* dL_dctrl_trans,
+                      float* dL_dctrl_rot, float* dL_dnu, dgs_stream_t stream);
+
 /* Stage timing with HIP events recorded on the caller's stream (bench.py's roofline leg). */
 #define DGS_STAGE_PREPROCESS 0
 #define DGS_STAGE_SCAN 1

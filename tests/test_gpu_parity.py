@@ -384,3 +384,38 @@ def test_metric_config_forward_vs_oracle(gpu):
         assert (st["n_contrib"][k] != o["n_contrib"]).mean() < 2e-4
         off += R
     assert st["R"] == off
+
+
+@pytest.mark.parametrize("K,C", [(15, 3), (21, 9), (1, 3), (31, 5)])
+def test_fused_pose_kernel_matches_torch_path(gpu, K, C):
+    """csrc/pose.hip (one kernel) against the torch-op pose path, which tests/test_oracle_golden.py pins to the
+    reference's se3_exp_map / Bezier / MiniCam recipe."""
+    import torch
+    from deblurgs_amd.motion import CameraMotionModule, RefCamera
+    torch.manual_seed(K * 100 + C)
+    ref = RefCamera(320, 200, 1.0, 0.7, device="cuda")
+    m = CameraMotionModule(ref, torch.rand(2, 3, 8, 8, device="cuda"), curve_order=C, num_subframes=max(K, 1),
+                           init_se3=torch.randn(2, 6) * 0.2, device="cuda")
+    with torch.no_grad():
+        m._trans._control_points.add_(torch.randn_like(m._trans._control_points) * 0.05)
+        m._rot._control_points.add_(torch.randn_like(m._rot._control_points) * 0.05)
+        if m._nu.numel():
+            m._nu.add_(torch.randn_like(m._nu) * 0.3)
+    gW = torch.randn(max(K, 1) if K > 1 else 2, 4, 4, device="cuda")
+    res = {}
+    for fused in (False, True):
+        for p in m.parameters():
+            p.grad = None
+        wv, fp, cc = m.get_trajectory_matrices(1, fused=fused)
+        gw = torch.randn(wv.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+        gf = torch.randn(fp.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(8))
+        ((wv * gw).sum() + (fp * gf).sum()).backward()
+        res[fused] = [t.detach().cpu().double().numpy() for t in (wv, fp, cc)] + \
+                     [(p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().double().numpy().copy()
+                      for p in m.parameters()]
+    names = ["world_view", "full_proj", "campos", "d_rot_ctrl", "d_trans_ctrl", "d_nu"]
+    for n, a, b in zip(names, res[True], res[False]):
+        if a.size == 0:
+            continue
+        tol = 2e-6 if n in ("world_view", "full_proj", "campos") else 2e-5 * (np.abs(b).max() + 1e-12)
+        assert np.abs(a - b).max() <= tol, f"{n}: {np.abs(a - b).max()} vs tol {tol}"
