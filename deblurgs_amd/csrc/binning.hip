@@ -197,38 +197,79 @@ gather_u32_kernel(uint64_t n, const uint32_t* __restrict__ idx, const uint32_t* 
   if (j < n) dst[j] = src[idx[j]];
 }
 
-// thread j handles the j-th (k, Gaussian) pair in (k, depth, index) order
+// Load-balanced expansion: a wave takes 64 consecutive (k, Gaussian) pairs of the (k, depth, index) order, whose
+// duplicate segments are contiguous (offs_sorted is an exclusive scan in that order), and its lanes emit the
+// wave's duplicates cooperatively -- duplicate d of the wave is produced by lane d % 64, which finds its source
+// pair by a binary search over the 64 segment starts held in LDS.  Every key/value store instruction therefore
+// writes 64 consecutive elements (the thread-per-pair loop of the reference, rasterizer_impl.cu:92-108, writes
+// 64 scattered 8-byte words per instruction and idles the lanes with small rectangles).
 __global__ void __launch_bounds__(256)
 duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __restrict__ order,
                         const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ offs_sorted,
                         uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
                         uint32_t* __restrict__ vals) {
+  __shared__ uint32_t s_off[4][64];    // segment start relative to the wave's first duplicate
+  __shared__ uint32_t s_rect[4][64];   // minx | miny << 12 | width << 24  (grid <= 4095 tiles per side, width <= 255)
+  __shared__ uint32_t s_wide[4][64];   // full width for rectangles wider than 255 tiles
+  __shared__ uint32_t s_tb[4][64];     // k * T
+  __shared__ uint32_t s_db[4][64];     // depth bits
+  __shared__ uint32_t s_g[4][64];      // Gaussian index
+  const int lane = dgs_lane(), w = threadIdx.x >> 6;
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t n = (uint64_t)v.K * v.P;
-  if (j >= n) return;
-  const uint32_t i = order[j];
-  uint32_t off = offs_sorted[j];
-  point_offsets[i] = off;
-  if (tt_sorted[j] == 0) return;
-  const uint32_t k = i / (uint32_t)v.P;
-  const uint32_t g = i - k * (uint32_t)v.P;
-  DgsRow* row = rows + i;
-  const float x = row->x, y = row->y;
-  const int radius = row->radius;
-  row->dup_offset = off;
-  int minx, miny, maxx, maxy;
-  dgs_get_rect(x, y, radius, v.gx, v.gy, minx, miny, maxx, maxy);
-  const uint32_t dbits = __float_as_uint(row->depth);
-  const uint32_t tbase = k * (uint32_t)v.T;
-  for (int ty = miny; ty < maxy; ty++)
-    for (int tx = minx; tx < maxx; tx++) {
-      uint64_t key = (uint64_t)(tbase + (uint32_t)ty * (uint32_t)v.gx + (uint32_t)tx);
-      key <<= 32;
-      key |= dbits;
-      keys[off] = key;
-      vals[off] = g;
-      off++;
+  const bool in = j < n;
+  uint32_t off = 0, nt = 0;
+  if (in) {
+    const uint32_t i = order[j];
+    off = offs_sorted[j];
+    nt = tt_sorted[j];
+    point_offsets[i] = off;
+    uint32_t rect = 0, wide = 0, tb = 0, db = 0, g = 0;
+    if (nt != 0) {
+      const uint32_t k = i / (uint32_t)v.P;
+      g = i - k * (uint32_t)v.P;
+      DgsRow* row = rows + i;
+      row->dup_offset = off;
+      int minx, miny, maxx, maxy;
+      dgs_get_rect(row->x, row->y, row->radius, v.gx, v.gy, minx, miny, maxx, maxy);
+      wide = (uint32_t)(maxx - minx);
+      rect = (uint32_t)minx | ((uint32_t)miny << 12);
+      tb = k * (uint32_t)v.T;
+      db = __float_as_uint(row->depth);
     }
+    s_rect[w][lane] = rect;
+    s_wide[w][lane] = wide;
+    s_tb[w][lane] = tb;
+    s_db[w][lane] = db;
+    s_g[w][lane] = g;
+  }
+  // offsets are contiguous across the wave's valid lanes: base = first lane's offset, total = last end - base
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+  s_off[w][lane] = in ? off - base : 0xFFFFFFFFu;
+  const uint64_t valid = __ballot(in);
+  if (valid == 0ull) return;                      // wave entirely past the end (wave-uniform)
+  const int last = 63 - __builtin_clzll(valid);
+  const uint32_t total =
+      (uint32_t)__builtin_amdgcn_readlane((int)(off + nt), last) - base;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (uint32_t d = (uint32_t)lane; d < total; d += 64) {
+    // largest s with s_off[s] <= d (segments of pairs without tiles are empty and are skipped by the search)
+    int lo = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) {
+      const int mid = lo + step;
+      if (mid < 64 && s_off[w][mid] <= d) lo = mid;
+    }
+    const uint32_t local = d - s_off[w][lo];
+    const uint32_t width = s_wide[w][lo];
+    const uint32_t rect = s_rect[w][lo];
+    const uint32_t ry = local / width, rx = local - ry * width;
+    const uint32_t tile = s_tb[w][lo] + ((rect >> 12) + ry) * (uint32_t)v.gx + (rect & 0xFFFu) + rx;
+    keys[base + d] = ((uint64_t)tile << 32) | s_db[w][lo];
+    vals[base + d] = s_g[w][lo];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- ranges
