@@ -187,9 +187,13 @@ struct StageTimer {
 // traffic between the fused forward and backward.
 __device__ __forceinline__ float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 
+// MODE 0: blur + loss values (forward).  MODE 1: dL/dsubframes, multiplied by the upstream scalar *scale read
+// from device memory (backward; no host sync, no extra elementwise pass over [K,3,H,W]).  MODE 2: both at once.
+template <int MODE>
 __global__ void __launch_bounds__(256)
 blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, int K, size_t E, float lambda_t,
-                 float* __restrict__ blur, float* __restrict__ dsub, float* __restrict__ losses) {
+                 const float* __restrict__ scale, float* __restrict__ blur, float* __restrict__ dsub,
+                 float* __restrict__ losses) {
   __shared__ float red[2][4];
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   float l1 = 0.0f, sm = 0.0f;
@@ -197,11 +201,12 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
     float acc = 0.0f;
     for (int k = 0; k < K; k++) acc += sub[(size_t)k * E + e];
     const float b = acc / (float)K;
-    blur[e] = b;
+    if (MODE != 1) blur[e] = b;
     const float d = b - gt[e];
     l1 = fabsf(d);
-    const float g_l1 = sgn(d) / ((float)E * (float)K);
-    const float ws = (K > 1) ? lambda_t / ((float)E * (float)(K - 1)) : 0.0f;
+    const float up = (MODE != 0 && scale != nullptr) ? scale[0] : 1.0f;
+    const float g_l1 = up * sgn(d) / ((float)E * (float)K);
+    const float ws = (K > 1) ? up * lambda_t / ((float)E * (float)(K - 1)) : 0.0f;
     float prev = sub[e];
     float s_prev = 0.0f;  // sign(x_k - x_{k-1})
     for (int k = 0; k < K; k++) {
@@ -213,11 +218,12 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
         sm += fabsf(dd);
         s_next = sgn(dd);
       }
-      dsub[(size_t)k * E + e] = g_l1 + ws * (s_prev - s_next);
+      if (MODE != 0) dsub[(size_t)k * E + e] = g_l1 + ws * (s_prev - s_next);
       s_prev = s_next;
       prev = nxt;
     }
   }
+  if (MODE == 1) return;
   l1 = dgs_wave_sum63(l1);
   sm = dgs_wave_sum63(sm);
   const int lane = dgs_lane(), w = threadIdx.x >> 6;
@@ -236,13 +242,20 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
 
 }  // namespace
 
-hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t, float* blur,
-                                float* dsub, float* losses, hipStream_t s) {
+hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t,
+                                const float* scale, float* blur, float* dsub, float* losses, hipStream_t s) {
   const size_t E = (size_t)C * HW;
-  hipError_t e = hipMemsetAsync(losses, 0, 2 * sizeof(float), s);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(blur_loss_kernel, dim3((uint32_t)((E + 255) / 256)), dim3(256), 0, s, sub, gt, K, E, lambda_t,
-                     blur, dsub, losses);
+  const dim3 grid((uint32_t)((E + 255) / 256));
+  if (losses != nullptr) {
+    hipError_t e = hipMemsetAsync(losses, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return e;
+  }
+  if (dsub == nullptr)
+    hipLaunchKernelGGL(blur_loss_kernel<0>, grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, dsub, losses);
+  else if (losses == nullptr)
+    hipLaunchKernelGGL(blur_loss_kernel<1>, grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, dsub, losses);
+  else
+    hipLaunchKernelGGL(blur_loss_kernel<2>, grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, dsub, losses);
   return hipGetLastError();
 }
 
@@ -430,11 +443,12 @@ int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t*
 }
 
 int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW, float lambda_t,
-                       float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream) {
-  if (subframes == nullptr || gt == nullptr || blur == nullptr || dL_dsubframes == nullptr || losses == nullptr ||
-      K < 1 || C < 1 || HW < 1)
+                       const float* upstream, float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream) {
+  const bool fwd = (blur != nullptr && losses != nullptr);
+  if (subframes == nullptr || gt == nullptr || K < 1 || C < 1 || HW < 1 || (!fwd && dL_dsubframes == nullptr) ||
+      ((blur == nullptr) != (losses == nullptr)))
     return fail(DGS_E_ARG, "blur_loss_grad: bad argument");
-  hipError_t e = dgs_launch_blur_loss(subframes, gt, K, C, HW, lambda_t, blur, dL_dsubframes, losses,
+  hipError_t e = dgs_launch_blur_loss(subframes, gt, K, C, HW, lambda_t, upstream, blur, dL_dsubframes, losses,
                                       reinterpret_cast<hipStream_t>(stream));
   return e == hipSuccess ? DGS_OK : fail_hip(e, "blur_loss_grad");
 }

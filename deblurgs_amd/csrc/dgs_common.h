@@ -140,8 +140,8 @@ hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const f
                                     const float* dL_ddepth, float* contrib, hipStream_t s);
 hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const DgsCarve& c, const DgsBackwardIO& io,
                                    const float* contrib, float* partials, hipStream_t s);
-hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t, float* blur,
-                                float* dsub, float* losses, hipStream_t s);
+hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t,
+                                const float* scale, float* blur, float* dsub, float* losses, hipStream_t s);
 
 size_t dgs_scan_tmp_words(uint64_t n);
 size_t dgs_sort_tmp_words(uint64_t n);

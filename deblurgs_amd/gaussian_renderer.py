@@ -77,12 +77,9 @@ def render_subframes(world_views, full_projs, camera_centers, ref_camera, pc, bg
       radii [K,P]."""
     xyz = pc.get_xyz
     K = world_views.shape[0]
-    screenspace_points = torch.zeros((K,) + tuple(xyz.shape), dtype=xyz.dtype, requires_grad=True,
-                                     device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # a leaf whose .grad receives the per-subframe screen-space gradients (the reference's `zeros + 0` +
+    # retain_grad() idiom costs an extra elementwise pass over [K,P,3] for the same effect)
+    screenspace_points = torch.zeros((K,) + tuple(xyz.shape), dtype=xyz.dtype, requires_grad=True, device=xyz.device)
     raster_settings = GaussianRasterizationSettings(
         image_height=int(ref_camera.image_height),
         image_width=int(ref_camera.image_width),

@@ -83,21 +83,27 @@ class _BlurL1Smooth(torch.autograd.Function):
         K, C = sub.shape[0], sub.shape[1]
         HW = sub[0, 0].numel()
         blur = torch.empty_like(g)
-        dsub = torch.empty_like(sub)
         losses = torch.empty(2, dtype=torch.float32, device=sub.device)
         st = ctypes.c_void_p(torch.cuda.current_stream(sub.device).cuda_stream)
-        _lib.check(_lib.lib().dgs_blur_loss_grad(sub.data_ptr(), g.data_ptr(), K, C, HW, float(lambda_t),
-                                                 blur.data_ptr(), dsub.data_ptr(), losses.data_ptr(), st),
-                   "dgs_blur_loss_grad")
-        ctx.save_for_backward(dsub)
+        _lib.check(_lib.lib().dgs_blur_loss_grad(sub.data_ptr(), g.data_ptr(), K, C, HW, float(lambda_t), None,
+                                                 blur.data_ptr(), None, losses.data_ptr(), st), "dgs_blur_loss_grad")
+        ctx.save_for_backward(sub, g)
+        ctx.lambda_t = float(lambda_t)
         total = losses[0] + float(lambda_t) * losses[1]
         ctx.mark_non_differentiable(blur, losses)
         return total, blur, losses
 
     @staticmethod
     def backward(ctx, g_total, _g_blur, _g_losses):
-        (dsub,) = ctx.saved_tensors
-        return dsub * g_total, None, None
+        sub, g = ctx.saved_tensors
+        K, C = sub.shape[0], sub.shape[1]
+        HW = sub[0, 0].numel()
+        dsub = torch.empty_like(sub)
+        up = g_total.detach().float().reshape(1).contiguous()     # device scalar: read by the kernel, no sync
+        st = ctypes.c_void_p(torch.cuda.current_stream(sub.device).cuda_stream)
+        _lib.check(_lib.lib().dgs_blur_loss_grad(sub.data_ptr(), g.data_ptr(), K, C, HW, ctx.lambda_t, up.data_ptr(),
+                                                 None, dsub.data_ptr(), None, st), "dgs_blur_loss_grad")
+        return dsub, None, None
 
 
 def blur_l1_smooth(subframes, gt, lambda_t):

@@ -170,11 +170,13 @@ size_t dgs_sort_tmp_bytes(uint64_t n);
 int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
                    int32_t begin_bit, int32_t end_bit, void* tmp, int32_t* result_in_alt, dgs_stream_t stream);
 
-/* Fused loss-gradient image (train.py:143-165, utils/loss_utils.py:17-18,80-93): from the K rendered
- * subframes and the target, produces blur = mean_k, the L1 and temporal-smoothness loss values and
- * dL/dsubframes in one pass.  losses = {l1, smooth}. */
-int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW,
-                       float lambda_t, float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream);
+/* Fused loss-gradient image (train.py:143-165, utils/loss_utils.py:17-18,80-93): from the K rendered subframes
+ * and the target, produces blur = mean_k, the L1 and temporal-smoothness loss values (losses = {l1, smooth}) and/or
+ * dL/dsubframes in one pass.  Forward call: blur + losses non-null, dL_dsubframes NULL.  Backward call: blur and
+ * losses NULL, dL_dsubframes non-null, `upstream` = device pointer to the scalar dL/d(l1 + lambda_t*smooth) (NULL = 1).
+ * All three outputs non-null computes everything at once. */
+int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW, float lambda_t,
+                       const float* upstream, float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream);
 
 /* Pose path of the blur-integration loop on device: Bezier curves in se(3) evaluated at the K
  * subframe times nu, se3_exp_map, and the three camera tensors render() reads -- scene/bezier.py:54-83,
