@@ -189,36 +189,46 @@ __device__ __forceinline__ float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x <
 
 // MODE 0: blur + loss values (forward).  MODE 1: dL/dsubframes, multiplied by the upstream scalar *scale read
 // from device memory (backward; no host sync, no extra elementwise pass over [K,3,H,W]).  MODE 2: both at once.
-template <int MODE>
+template <int MODE, int V>  // V = elements per thread (4 -> 16-byte loads/stores when E % 4 == 0, else 1)
 __global__ void __launch_bounds__(256)
 blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, int K, size_t E, float lambda_t,
                  const float* __restrict__ scale, float* __restrict__ blur, float* __restrict__ dsub,
                  float* __restrict__ losses) {
   __shared__ float red[2][4];
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  typedef float vec __attribute__((ext_vector_type(V)));
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
   float l1 = 0.0f, sm = 0.0f;
   if (e < E) {
-    float acc = 0.0f;
-    for (int k = 0; k < K; k++) acc += sub[(size_t)k * E + e];
-    const float b = acc / (float)K;
-    if (MODE != 1) blur[e] = b;
-    const float d = b - gt[e];
-    l1 = fabsf(d);
+    auto ld = [](const float* p) { return *reinterpret_cast<const vec*>(p); };
+    vec acc = ld(sub + e);
+    for (int k = 1; k < K; k++) acc += ld(sub + (size_t)k * E + e);
+    const vec b = acc / (float)K;
+    if (MODE != 1) *reinterpret_cast<vec*>(blur + e) = b;
+    const vec d = b - ld(gt + e);
     const float up = (MODE != 0 && scale != nullptr) ? scale[0] : 1.0f;
-    const float g_l1 = up * sgn(d) / ((float)E * (float)K);
+    const float c_l1 = up / ((float)E * (float)K);
     const float ws = (K > 1) ? up * lambda_t / ((float)E * (float)(K - 1)) : 0.0f;
-    float prev = sub[e];
-    float s_prev = 0.0f;  // sign(x_k - x_{k-1})
+    vec g_l1;
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+      l1 += fabsf(d[i]);
+      g_l1[i] = c_l1 * sgn(d[i]);
+    }
+    vec prev = ld(sub + e);
+    vec s_prev = (vec)(0.0f);  // sign(x_k - x_{k-1})
     for (int k = 0; k < K; k++) {
-      float s_next = 0.0f;
-      float nxt = prev;
+      vec s_next = (vec)(0.0f);
+      vec nxt = prev;
       if (k + 1 < K) {
-        nxt = sub[(size_t)(k + 1) * E + e];
-        const float dd = nxt - prev;
-        sm += fabsf(dd);
-        s_next = sgn(dd);
+        nxt = ld(sub + (size_t)(k + 1) * E + e);
+        const vec dd = nxt - prev;
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+          sm += fabsf(dd[i]);
+          s_next[i] = sgn(dd[i]);
+        }
       }
-      if (MODE != 0) dsub[(size_t)k * E + e] = g_l1 + ws * (s_prev - s_next);
+      if (MODE != 0) *reinterpret_cast<vec*>(dsub + (size_t)k * E + e) = g_l1 + ws * (s_prev - s_next);
       s_prev = s_next;
       prev = nxt;
     }
@@ -245,17 +255,30 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
 hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t,
                                 const float* scale, float* blur, float* dsub, float* losses, hipStream_t s) {
   const size_t E = (size_t)C * HW;
-  const dim3 grid((uint32_t)((E + 255) / 256));
   if (losses != nullptr) {
     hipError_t e = hipMemsetAsync(losses, 0, 2 * sizeof(float), s);
     if (e != hipSuccess) return e;
   }
+  const bool v4 = (E % 4 == 0) && ((reinterpret_cast<uintptr_t>(sub) | reinterpret_cast<uintptr_t>(gt) |
+                                    reinterpret_cast<uintptr_t>(blur) | reinterpret_cast<uintptr_t>(dsub)) % 16 == 0);
+  const size_t per = v4 ? 4 : 1;
+  const dim3 grid((uint32_t)((E / per + 255) / 256));
+#define DGS_BL(MODE)                                                                                              \
+  do {                                                                                                            \
+    if (v4)                                                                                                       \
+      hipLaunchKernelGGL((blur_loss_kernel<MODE, 4>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, \
+                         dsub, losses);                                                                           \
+    else                                                                                                          \
+      hipLaunchKernelGGL((blur_loss_kernel<MODE, 1>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, \
+                         dsub, losses);                                                                           \
+  } while (0)
   if (dsub == nullptr)
-    hipLaunchKernelGGL(blur_loss_kernel<0>, grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, dsub, losses);
+    DGS_BL(0);
   else if (losses == nullptr)
-    hipLaunchKernelGGL(blur_loss_kernel<1>, grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, dsub, losses);
+    DGS_BL(1);
   else
-    hipLaunchKernelGGL(blur_loss_kernel<2>, grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, dsub, losses);
+    DGS_BL(2);
+#undef DGS_BL
   return hipGetLastError();
 }
 

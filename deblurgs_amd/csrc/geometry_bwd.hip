@@ -63,7 +63,22 @@ contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ tiles_touched, co
   if (nt < 2) return;  // nothing to add
   float4* cp = reinterpret_cast<float4*>(contrib + (size_t)offsets[i] * DGS_CONTRIB_F);
   float4 a0 = cp[0], a1 = cp[1], a2 = cp[2];
-  for (uint32_t r = 1; r < nt; r++) {
+  // rows are added strictly in duplicate order (deterministic), but four rows are requested before the first
+  // add so that the dependent-load chain of the plain loop does not serialise the HBM latency
+  uint32_t r = 1;
+  for (; r + 4 <= nt; r += 4) {
+    float4 q[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) q[i] = cp[3 * r + i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float4 r0 = q[3 * i], r1 = q[3 * i + 1], r2 = q[3 * i + 2];
+      a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w;
+      a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
+      a2.x += r2.x; a2.y += r2.y;
+    }
+  }
+  for (; r < nt; r++) {
     const float4 r0 = cp[3 * r], r1 = cp[3 * r + 1], r2 = cp[3 * r + 2];
     a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w;
     a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
