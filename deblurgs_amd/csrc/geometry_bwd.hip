@@ -485,8 +485,12 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
   const size_t lds = (size_t)(GB_THREADS / 64) * v.K * NMAT * sizeof(float);
   const int ncoef = (p.shs != nullptr) ? (v.D + 1) * (v.D + 1) : 1;
   const uint64_t kp = (uint64_t)v.K * v.P;
-  hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((kp + 255) / 256)), dim3(256), 0, s, kp, c.tiles_touched,
-                     c.point_offsets, const_cast<float*>(contrib));
+  // walk the (k, Gaussian) pairs in (k, depth, index) order: their row segments are then consecutive in memory
+  // (that is the order the duplicates were laid out in), so a wave streams one contiguous span of rows
+  // (tt_sorted / offs_sorted only exist when the forward produced duplicates)
+  if (io.num_rendered > 0)
+    hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((kp + 255) / 256)), dim3(256), 0, s, kp, c.tt_sorted,
+                       c.offs_sorted, const_cast<float*>(contrib));
 #define DGS_GB_LAUNCH(MAXC)                                                                                          \
   hipLaunchKernelGGL(geometry_bwd_kernel<MAXC>, dim3(blocks), dim3(GB_THREADS), lds, s, v, p.means3D, p.shs,         \
                      p.scales, p.rotations, p.cov3D_precomp, p.viewmatrix, p.projmatrix, p.campos, c.point_offsets, c.rows,       \
