@@ -250,6 +250,29 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
   }
 }
 
+// train.py:188-193 + scene/gaussian_model.py:456-458 for the K subframes of one step, in subframe order
+__global__ void __launch_bounds__(256)
+densify_stats_kernel(const float* __restrict__ vgrad, const int32_t* __restrict__ radii, int K, int P,
+                     float* __restrict__ max_radii2D, float* __restrict__ accum, float* __restrict__ denom) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= P) return;
+  float mr = max_radii2D[g], ac = accum[g], dn = denom[g];
+  const float inc = (float)(1.0 / (double)K);
+  for (int k = 0; k < K; k++) {
+    const size_t o = (size_t)k * P + g;
+    const int r = radii[o];
+    if (r > 0) {
+      mr = fmaxf(mr, (float)r);
+      const float gx = vgrad[3 * o], gy = vgrad[3 * o + 1];
+      ac += sqrtf(gx * gx + gy * gy);
+      dn += inc;
+    }
+  }
+  max_radii2D[g] = mr;
+  accum[g] = ac;
+  denom[g] = dn;
+}
+
 }  // namespace
 
 hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t,
@@ -474,6 +497,18 @@ int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32
   hipError_t e = dgs_launch_blur_loss(subframes, gt, K, C, HW, lambda_t, upstream, blur, dL_dsubframes, losses,
                                       reinterpret_cast<hipStream_t>(stream));
   return e == hipSuccess ? DGS_OK : fail_hip(e, "blur_loss_grad");
+}
+
+int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t P, float* max_radii2D,
+                      float* xyz_gradient_accum, float* denom, dgs_stream_t stream) {
+  if (K < 1 || P < 0 || (P > 0 && (viewspace_grad == nullptr || radii == nullptr || max_radii2D == nullptr ||
+                                   xyz_gradient_accum == nullptr || denom == nullptr)))
+    return fail(DGS_E_ARG, "densify_stats: bad argument");
+  if (P == 0) return DGS_OK;
+  hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     viewspace_grad, radii, K, P, max_radii2D, xyz_gradient_accum, denom);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DGS_OK : fail_hip(e, "densify_stats");
 }
 
 int dgs_profile_enable(int32_t on) {

@@ -223,7 +223,6 @@ duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __
     const uint32_t i = order[j];
     off = offs_sorted[j];
     nt = tt_sorted[j];
-    point_offsets[i] = off;
     uint32_t rect = 0, wide = 0, tb = 0, db = 0, g = 0;
     if (nt != 0) {
       const uint32_t k = i / (uint32_t)v.P;

@@ -134,14 +134,16 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     const uint32_t ntiles = valid ? tiles_touched[o] : 0u;
     if (ntiles > 0) {
       // ---- the (subframe, Gaussian) total left by contrib_reduce_kernel in the first row of the segment
-      const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)offsets[o] * DGS_CONTRIB_F);
+      const float4* rowp = reinterpret_cast<const float4*>(rows + o);
+      const float4 ga = rowp[0];   // x, y, cx, cy
+      const float4 gb = rowp[1];   // cz, op, r, g
+      const uint32_t dup_off = __float_as_uint(rowp[2].z);
+      const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)dup_off * DGS_CONTRIB_F);
       const float4 r0 = cp[0], r1 = cp[1], r2 = cp[2];
       const float s[10] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
       // raw sums -> the reference's per-Gaussian sinks (backward.cu:620-637; see composite.hip):
       //   dL_dmean2D = -(0.5 W, 0.5 H) * (cx*Swx + cy*Swy, cz*Swy + cy*Swx),  dL_dconic = -0.5 * (Sxx, Sxy, Syy),
       //   dL_dopacity = Sw / opacity
-      const float4 ga = reinterpret_cast<const float4*>(rows + o)[0];   // x, y, cx, cy
-      const float4 gb = reinterpret_cast<const float4*>(rows + o)[1];   // cz, op, r, g
       g2x = -(0.5f * (float)v.W) * (ga.z * s[0] + ga.w * s[1]);
       g2y = -(0.5f * (float)v.H) * (gb.x * s[1] + ga.w * s[0]);
       const float dcon_x = -0.5f * s[2], dcon_y = -0.5f * s[3], dcon_w = -0.5f * s[4];

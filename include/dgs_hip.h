@@ -110,7 +110,8 @@ typedef struct DgsLayout {
   size_t cov3D;          /* f32 [P,6] */
   size_t pre_sigmoid;    /* f32 [K,P,3]  pre-activation colour (sigmoid) or 0/1 clamp mask (relu) */
   size_t tiles_touched;  /* u32 [K*P] */
-  size_t point_offsets;  /* u32 [K*P] first duplicate index of each (k, Gaussian) */
+  size_t point_offsets;  /* u32 [K*P] exclusive prefix sum of tiles_touched in [K,P] order (its total is R); the
+                          * duplicate offsets actually used live in the geometry rows (depth order) */
   size_t scan_tmp;       /* u32 scan block sums */
   size_t num_rendered;   /* u32 [4] device copy of R (+ spare) */
   size_t gsort_keys;     /* u64 [K*P] (k << 32) | depth_bits: the (k, depth, index) ordering of the Gaussians */
@@ -177,6 +178,14 @@ int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t*
  * All three outputs non-null computes everything at once. */
 int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW, float lambda_t,
                        const float* upstream, float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream);
+
+/* Densification-statistic consumers of the rasteriser's per-subframe outputs (train.py:188-193 with
+ * scene/gaussian_model.py:456-458), for all K subframes in one pass and in subframe order:
+ *   visible = radii[k] > 0;  max_radii2D = max(max_radii2D, radii[k]);
+ *   xyz_gradient_accum += || viewspace_grad[k][:, :2] ||;  denom += 1/K.
+ * viewspace_grad is the [K,P,3] gradient of the means2D carrier, radii is [K,P]; the three accumulators are [P]. */
+int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t P, float* max_radii2D,
+                      float* xyz_gradient_accum, float* denom, dgs_stream_t stream);
 
 /* Pose path of the blur-integration loop on device: Bezier curves in se(3) evaluated at the K
  * subframe times nu, se3_exp_map, and the three camera tensors render() reads -- scene/bezier.py:54-83,
