@@ -52,8 +52,16 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
                       const float* __restrict__ projm, const float* __restrict__ campos, DgsRow* __restrict__ rows,
                       float* __restrict__ cov3Ds, float* __restrict__ pre_sigmoid,
                       uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= v.P) return;
+  // Row and colour-mask stores are transposed through LDS per wave: a lane's 48-byte row becomes three
+  // wave-wide 1 KB stores (64 consecutive float4) instead of three 16-byte stores at a 48-byte lane stride.
+  __shared__ float4 s_row[4][3 * 64];
+  __shared__ float s_pre[4][3 * 64];
+  const int lane = dgs_lane(), wv_ = threadIdx.x >> 6;
+  const int idx_raw = blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx_raw < v.P;
+  const int idx = live ? idx_raw : v.P - 1;   // out-of-range lanes shadow the last Gaussian and store nothing
+  const int wave_first = blockIdx.x * 256 + wv_ * 64;          // first Gaussian of this wave
+  const int wave_count = min(64, v.P - wave_first);           // > 0 for every launched wave that has live lanes
   const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
   const float opacity = opacities[idx];
 
@@ -80,9 +88,12 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
     c3[3] = Sigma.m[1][1];
     c3[4] = Sigma.m[1][2];
     c3[5] = Sigma.m[2][2];
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) cov3Ds[6 * (size_t)idx + i] = c3[i];
+      for (int i = 0; i < 6; i++) cov3Ds[6 * (size_t)idx + i] = c3[i];
+    }
   }
+  if (wave_count <= 0) return;  // wave-uniform
 
   for (int k = 0; k < v.K; k++) {
     const float* V = viewm + 16 * k;
@@ -90,6 +101,11 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
     const size_t o = (size_t)k * v.P + idx;
     int out_radius = 0;
     uint32_t out_tiles = 0;
+    float pre_out[3] = {0.0f, 0.0f, 0.0f};
+    DgsRow row;
+    row.x = row.y = row.cx = row.cy = row.cz = row.op = row.r = row.g = row.b = row.depth = 0.0f;
+    row.dup_offset = 0;
+    row.radius = 0;
     // in_frustum (auxiliary.h:144-169): near-plane cull only
     const float vz = V[2] * px + V[6] * py + V[10] * pz + V[14];
     if (vz > 0.2f) {
@@ -175,14 +191,13 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
                 pre = (r_ >= 0.0f) ? 1.0f : 0.0f;
                 r_ = fmaxf(r_, 0.0f);
               }
-              pre_sigmoid[3 * o + ch] = pre;
+              pre_out[ch] = pre;
               res[ch] = r_;
             }
             cr = res[0];
             cg = res[1];
             cbl = res[2];
           }
-          DgsRow row;
           row.x = pixx;
           row.y = pixy;
           row.cx = cc * det_inv;
@@ -195,11 +210,6 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
           row.depth = vz;
           row.dup_offset = 0;
           row.radius = (int)my_radius;
-          float4* dst = reinterpret_cast<float4*>(rows + o);
-          const float4* src = reinterpret_cast<const float4*>(&row);
-          dst[0] = src[0];
-          dst[1] = src[1];
-          dst[2] = src[2];
           out_radius = (int)my_radius;
           out_tiles = area;
         }
@@ -208,8 +218,35 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
       // auxiliary.h:161-165: the reference traps when a "prefiltered" point is culled
       __builtin_trap();
     }
-    radii[o] = out_radius;
-    tiles_touched[o] = out_tiles;
+    if (live) {
+      radii[o] = out_radius;
+      tiles_touched[o] = out_tiles;
+    }
+    // wave-transposed stores of the 64 rows / colour masks of this (wave, k); invisible pairs store zeros
+    {
+      const float4* src = reinterpret_cast<const float4*>(&row);
+      s_row[wv_][3 * lane + 0] = src[0];
+      s_row[wv_][3 * lane + 1] = src[1];
+      s_row[wv_][3 * lane + 2] = src[2];
+      s_pre[wv_][3 * lane + 0] = pre_out[0];
+      s_pre[wv_][3 * lane + 1] = pre_out[1];
+      s_pre[wv_][3 * lane + 2] = pre_out[2];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const size_t wbase = (size_t)k * v.P + wave_first;
+      float4* dst = reinterpret_cast<float4*>(rows + wbase);
+      float* dpre = pre_sigmoid + 3 * wbase;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int e = i * 64 + lane;
+        if (e < 3 * wave_count) {
+          dst[e] = s_row[wv_][e];
+          dpre[e] = s_pre[wv_][e];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
