@@ -44,6 +44,7 @@ __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+template <int DEG>  // active SH degree: the (DEG+1)^2 coefficients are read ONCE per Gaussian and kept in registers
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ opacities,
@@ -94,6 +95,13 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
     }
   }
   if (wave_count <= 0) return;  // wave-uniform
+  constexpr int NC = (DEG + 1) * (DEG + 1);
+  float sh[NC * 3];
+  if (colors_precomp == nullptr) {
+    const float* shp = shs + (size_t)idx * v.M * 3;
+#pragma unroll
+    for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+  }
 
   for (int k = 0; k < v.K; k++) {
     const float* V = viewm + 16 * k;
@@ -159,21 +167,20 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
             dx = dx / len;
             dy = dy / len;
             dz = dz / len;
-            const float* sh = shs + (size_t)idx * v.M * 3;
             float res[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
               float r_ = SH_C0 * sh[ch];
-              if (v.D > 0) {
+              if (DEG > 0) {
                 const float x = dx, y = dy, z = dz;
                 r_ = r_ - SH_C1 * y * sh[3 + ch] + SH_C1 * z * sh[6 + ch] - SH_C1 * x * sh[9 + ch];
-                if (v.D > 1) {
+                if (DEG > 1) {
                   const float xx = x * x, yy = y * y, zz = z * z;
                   const float xy = x * y, yz = y * z, xz = x * z;
                   r_ = r_ + SH_C2[0] * xy * sh[12 + ch] + SH_C2[1] * yz * sh[15 + ch] +
                        SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + SH_C2[3] * xz * sh[21 + ch] +
                        SH_C2[4] * (xx - yy) * sh[24 + ch];
-                  if (v.D > 2) {
+                  if (DEG > 2) {
                     r_ = r_ + SH_C3[0] * y * (3.0f * xx - yy) * sh[27 + ch] + SH_C3[1] * xy * z * sh[30 + ch] +
                          SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
                          SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
@@ -263,9 +270,20 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 hipError_t dgs_launch_preprocess(const DgsProblem& p, const DgsView& v, const DgsCarve& c, int32_t* radii,
                                  hipStream_t s) {
   const int blocks = (v.P + 255) / 256;
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, s, v, p.means3D, p.scales, p.rotations,
-                     p.opacities, p.shs, p.cov3D_precomp, p.colors_precomp, p.viewmatrix, p.projmatrix, p.campos,
-                     c.rows, c.cov3D, c.pre_sigmoid, c.tiles_touched, radii);
+#define DGS_PRE(DEG)                                                                                                  \
+  hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, dim3(blocks), dim3(256), 0, s, v, p.means3D, p.scales, p.rotations, \
+                     p.opacities, p.shs, p.cov3D_precomp, p.colors_precomp, p.viewmatrix, p.projmatrix, p.campos,     \
+                     c.rows, c.cov3D, c.pre_sigmoid, c.tiles_touched, radii)
+  const int deg = (p.colors_precomp != nullptr) ? 0 : v.D;
+  if (deg <= 0)
+    DGS_PRE(0);
+  else if (deg == 1)
+    DGS_PRE(1);
+  else if (deg == 2)
+    DGS_PRE(2);
+  else
+    DGS_PRE(3);
+#undef DGS_PRE
   return hipGetLastError();
 }
 
