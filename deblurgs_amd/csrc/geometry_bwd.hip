@@ -122,6 +122,14 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
   float a_sh[MAXC * 3];
 #pragma unroll
   for (int i = 0; i < MAXC * 3; i++) a_sh[i] = 0.0f;
+  // SH coefficients are read once per Gaussian and stay in registers across the K subframes (only the first
+  // (D+1)^2 are touched, MAXC >= (D+1)^2 by construction of the launch)
+  float sh[MAXC * 3];
+  if (shs != nullptr) {
+    const float* shp = shs + (size_t)gi * v.M * 3;
+#pragma unroll
+    for (int i = 0; i < MAXC * 3; i++) sh[i] = (i < ncoef * 3) ? shp[i] : 0.0f;
+  }
 
   for (int k = 0; k < v.K; k++) {
     const float* V = viewm + 16 * k;
@@ -240,7 +248,6 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
         const float dox = mx - cam[0], doy = my - cam[1], doz = mz - cam[2];
         const float len = sqrtf(dox * dox + doy * doy + doz * doz);
         const float x = dox / len, y = doy / len, z = doz / len;
-        const float* sh = shs + (size_t)gi * v.M * 3;
         float dRGB[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
