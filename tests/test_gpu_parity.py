@@ -442,3 +442,54 @@ def test_densification_stats_match_reference_loop(gpu):
     torch.cuda.synchronize()
     assert torch.equal(mr, mr_r)
     assert torch.allclose(acc, acc_r, rtol=1e-6, atol=1e-9) and torch.allclose(den, den_r, rtol=1e-6)
+
+
+def test_end_to_end_training_reduces_blur_loss(gpu):
+    """The reference's training block (train.py:126-165,203-208) on the fused path: query() -> fused blur loss ->
+    backward -> Adam on the Gaussians AND the trajectory.  Ground truth = blurry render of the unperturbed
+    scene; the perturbed scene must fit it again."""
+    import torch
+    from deblurgs_amd import losses
+    from deblurgs_amd.cloud import GaussianCloud
+    from deblurgs_amd.motion import CameraMotionModule, RefCamera
+    torch.manual_seed(0)
+    sc = synthetic.make_scene(4000, 160, 112, K=5, seed=21, sigma_px=3.0)
+    ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device="cuda")
+    bg = torch.tensor([0.2, 0.3, 0.4], device="cuda")
+
+    def make(perturb):
+        cloud = GaussianCloud.from_scene(sc, "cuda")
+        m = CameraMotionModule(ref, torch.zeros(1, 3, sc["H"], sc["W"], device="cuda"), curve_order=3, num_subframes=5,
+                               device="cuda")
+        with torch.no_grad():
+            m._trans._control_points.copy_(torch.from_numpy(sc["ctrl_trans"])[None].cuda())
+            m._rot._control_points.copy_(torch.from_numpy(sc["ctrl_rot"])[None].cuda())
+            if perturb:
+                cloud._features_dc.add_(torch.randn_like(cloud._features_dc) * 0.3)
+                cloud._opacity.mul_(0.7)
+                cloud._xyz.add_(torch.randn_like(cloud._xyz) * 0.01)
+                m._trans._control_points.add_(torch.randn_like(m._trans._control_points) * 0.01)
+        m.link_gaussian(cloud)
+        return cloud, m
+
+    with torch.no_grad():
+        cloud_gt, m_gt = make(False)
+        gt = m_gt.query(0, "all", background=bg)["blurred"].clone()
+    cloud, m = make(True)
+    m.gt_images = gt[None]
+    opt = torch.optim.Adam([{"params": [cloud._xyz], "lr": 2e-4}, {"params": [cloud._features_dc], "lr": 2e-2},
+                            {"params": [cloud._features_rest], "lr": 1e-3}, {"params": [cloud._opacity], "lr": 2e-2},
+                            {"params": [cloud._scaling], "lr": 2e-3}, {"params": [cloud._rotation], "lr": 1e-3},
+                            {"params": m.parameters(), "lr": 1e-4}], eps=1e-15)
+    hist = []
+    for it in range(40):
+        out = m.query(0, "all", background=bg)
+        loss, blur, ls = losses.blur_l1_smooth(out["subframes"], out["gt"], 1e-4)
+        loss = loss + 0.1 * losses.hinge_l2(cloud._opacity)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        assert out["viewspace_points_all"].grad.shape == (5, sc["P"], 3)
+        assert m._trans._control_points.grad is not None and torch.isfinite(cloud._xyz.grad).all()
+        opt.step()
+        hist.append(float(ls[0]))
+    assert hist[-1] < 0.5 * hist[0], (hist[0], hist[-1])
