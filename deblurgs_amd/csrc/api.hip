@@ -341,7 +341,8 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
   if (out == nullptr || out->num_rendered_host == nullptr)
     return fail(DGS_E_ARG, "DgsForwardOut: num_rendered_host is null");
   if (p->P == 0) {  // rasterize_points.cu:85 -- nothing to launch
-    *out->num_rendered_host = 0;
+    out->num_rendered_host[0] = 0;
+    out->num_rendered_host[1] = 0;
     return DGS_OK;
   }
   if (out->radii == nullptr) return fail(DGS_E_ARG, "DgsForwardOut: radii is null");
@@ -354,7 +355,8 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
   DGS_STAGE(DGS_STAGE_PREPROCESS, "preprocess", dgs_launch_preprocess(*p, v, c, out->radii, s));
   DGS_STAGE(DGS_STAGE_SCAN, "scan",
             dgs_launch_scan(c.tiles_touched, c.point_offsets, (uint64_t)p->K * p->P, c.scan_tmp, c.num_rendered, s));
-  hipError_t e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  // two words: R and the high half of the 64-bit total (non-zero = the u32 duplicate offsets overflowed)
+  hipError_t e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   if (e != hipSuccess) return fail_hip(e, "copy num_rendered");
   return DGS_OK;
 }

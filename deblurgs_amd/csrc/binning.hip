@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(SCAN_THREADS)
 scan_top_kernel(uint32_t* __restrict__ block_sums, uint64_t nb, uint32_t* __restrict__ total) {
   __shared__ uint32_t lds[8];
   uint32_t carry = 0;
+  uint64_t wide = 0;  // the grand total in 64 bits: total[1] != 0 tells the caller that the u32 offsets wrapped
   for (uint64_t start = 0; start < nb; start += SCAN_TILE) {
     const uint64_t base = start + (uint64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t vals[SCAN_ITEMS];
@@ -86,8 +87,12 @@ scan_top_kernel(uint32_t* __restrict__ block_sums, uint64_t nb, uint32_t* __rest
       pre += vals[i];
     }
     carry += tot;
+    wide += tot;
   }
-  if (threadIdx.x == 0 && total != nullptr) *total = carry;
+  if (threadIdx.x == 0 && total != nullptr) {
+    total[0] = carry;
+    total[1] = (uint32_t)(wide >> 32);
+  }
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
@@ -666,7 +671,7 @@ size_t dgs_scan_tmp_words(uint64_t n) { return (size_t)((n + SCAN_TILE - 1) / SC
 hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, uint32_t* total,
                            hipStream_t s) {
   if (n == 0) {
-    if (total) return hipMemsetAsync(total, 0, sizeof(uint32_t), s);
+    if (total) return hipMemsetAsync(total, 0, 2 * sizeof(uint32_t), s);
     return hipSuccess;
   }
   const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;

@@ -147,6 +147,9 @@ def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, 
                          campos, rs, geom, image, None)
     _lib.check(L.dgs_forward_geometry(ctypes.byref(prob), ctypes.byref(out), stream), "dgs_forward_geometry")
     torch.cuda.current_stream(device).synchronize()   # the one host read of num_rendered (rasterizer_impl.cu:287)
+    if int(host_R[1].item()) != 0:
+        raise RuntimeError("num_rendered exceeds 32 bits: too many (tile, Gaussian) duplicates for one fused call; "
+                           "render fewer subframes per call")
     R = int(host_R[0].item()) & 0xFFFFFFFF
     binning = torch.empty(L.dgs_binning_state_bytes(R, W, H, K), dtype=torch.uint8, device=device)
     prob.binning_state = _ptr(binning)

@@ -77,7 +77,8 @@ typedef struct DgsForwardOut {
   float* out_color;   /* [K,3,H,W] */
   float* out_depth;   /* [K,1,H,W] */
   int32_t* radii;     /* [K,P] */
-  uint32_t* num_rendered_host; /* pinned host word: dgs_forward_geometry enqueues an async copy of R into it */
+  uint32_t* num_rendered_host; /* pinned host uint32[2]: dgs_forward_geometry enqueues an async copy of
+                                * {R, overflow}; overflow != 0 means the duplicate count exceeded 32 bits */
 } DgsForwardOut;
 
 typedef struct DgsBackwardIO {
@@ -163,6 +164,7 @@ int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
  * (cub::DeviceScan::InclusiveSum / cub::DeviceRadixSort::SortPairs call sites,
  * rasterizer_impl.cu:166,188-191,283,309-314). */
 size_t dgs_scan_tmp_bytes(uint64_t n);
+/* total_out (optional) receives uint32[2] = {sum mod 2^32, high 32 bits of the 64-bit sum} */
 int dgs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, void* tmp, uint32_t* total_out,
                            dgs_stream_t stream);
 size_t dgs_sort_tmp_bytes(uint64_t n);

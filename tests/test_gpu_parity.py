@@ -32,13 +32,13 @@ def test_exclusive_scan(gpu, n):
     x = torch.from_numpy(a.astype(np.int64)).to(torch.int32).to(gpu)   # values < 2^31
     out = torch.empty_like(x)
     tmp = torch.empty(L.dgs_scan_tmp_bytes(n) + 16, dtype=torch.uint8, device=gpu)
-    total = torch.zeros(1, dtype=torch.int32, device=gpu)
+    total = torch.zeros(2, dtype=torch.int32, device=gpu)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     _lib.check(L.dgs_exclusive_scan_u32(x.data_ptr(), out.data_ptr(), n, tmp.data_ptr(), total.data_ptr(), st), "scan")
     torch.cuda.synchronize()
     ref = np.concatenate([[0], np.cumsum(a, dtype=np.uint64)[:-1]]).astype(np.uint32) if n else a
     assert np.array_equal(out.cpu().numpy().view(np.uint32), ref)
-    assert int(total.item()) == int(a.sum())
+    assert int(total[0].item()) == int(a.sum()) and int(total[1].item()) == 0
 
 
 @pytest.mark.parametrize("n,bits", [(0, 40), (1, 33), (777, 41), (4096, 45), (50_001, 49), (1_000_003, 45),
@@ -595,3 +595,32 @@ def test_debug_mode_and_render_adapter(gpu):
                                      scales=_t(sc["scales"]), rotations=_t(sc["rotations"]),
                                      viewmatrix=_t(sc["viewmatrix"][0]), projmatrix=_t(sc["projmatrix"][0]))
     assert np.array_equal(r.cpu().numpy(), oracle_forward(sc, 0)["radii"])
+
+
+def test_query_subframe_selection(gpu):
+    """CameraMotionModule.query subframe_indice semantics (scene/motion.py:124-135): "all", an int n
+    (linspace(0, f-1, n).long(), so 1 selects index 0), or an explicit index list."""
+    import torch
+    from deblurgs_amd.cloud import GaussianCloud
+    from deblurgs_amd.motion import CameraMotionModule, RefCamera
+    sc = small_scene(P=600, W=64, H=48, K=5, seed=14)
+    ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device="cuda")
+    m = CameraMotionModule(ref, torch.rand(1, 3, sc["H"], sc["W"], device="cuda"), curve_order=3, num_subframes=5,
+                           device="cuda")
+    with torch.no_grad():
+        m._trans._control_points.copy_(torch.from_numpy(sc["ctrl_trans"])[None].cuda() * 5)
+    m.link_gaussian(GaussianCloud.from_scene(sc, "cuda"))
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    with torch.no_grad():
+        full = m.query(0, "all", background=bg)
+        one = m.query(0, 1, background=bg)
+        three = m.query(0, 3, background=bg)
+        lst = m.query(0, [4, 1], background=bg)
+    assert full["subframes"].shape[0] == 5 and one["subframes"].shape[0] == 1 and three["subframes"].shape[0] == 3
+    assert torch.equal(one["subframes"][0], full["subframes"][0])
+    assert torch.equal(three["subframes"], full["subframes"][[0, 2, 4]])
+    assert torch.equal(lst["subframes"], full["subframes"][[4, 1]])
+    assert torch.allclose(full["blurred"], full["subframes"].mean(0))
+    assert len(full["render_pkgs"]) == 5 and full["depths"].shape == (5, 1, sc["H"], sc["W"])
+    pp = m.query(0, "all", background=bg, post_process=lambda x: x * 2)
+    assert torch.allclose(pp["blurred"], pp["subframes"].mean(0) * 2)
