@@ -397,9 +397,7 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t R
       hipError_t e__;
       {
         StageTimer tm__(DGS_STAGE_DEPTH_ORDER, s);
-        e__ = dgs_launch_gaussian_keys(v, c, c.gsort_keys, c.gsort_vals, s);
-        if (e__ == hipSuccess)
-          e__ = dgs_launch_sort(c.gsort_keys, c.gsort_vals, c.gsort_keys_alt, c.gsort_vals_alt,
+        e__ = dgs_launch_sort(c.gsort_keys, c.gsort_vals, c.gsort_keys_alt, c.gsort_vals_alt,
                                 (uint64_t)p->K * p->P, 0, gbits, c.gsort_tmp, &g_in_alt, s);
       }
       if (e__ != hipSuccess) return fail_hip(e__, "depth order");

@@ -179,22 +179,10 @@ duplicate_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __restric
 // ------------------------------------------------------------------------------ depth-ordered duplication
 // The duplicates only need a STABLE sort by (k, tile) if they are generated in (k, depth, index) order: the
 // low 32 key bits (depth) are then already in order inside every (k, tile) group, exactly as if the LSD passes
-// over the depth bits had run.  So the K*P Gaussians are sorted by (k, depth_bits) first (15 M pairs instead of
+// over the depth bits had run.  So the K*P Gaussians are sorted by (k, depth_bits) first (their (k << 32 | depth)
+// keys are written by the preprocess kernel itself) (15 M pairs instead of
 // R = 63 M, 4 digit passes) and the big sort shrinks from 6 passes over all 49 bits to 2 passes over the
 // bits(K*T) = 17 tile bits.  Sorted keys and point list are bit-identical to the one-big-sort result.
-__global__ void __launch_bounds__(256)
-gaussian_keys_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restrict__ tiles_touched,
-                     uint64_t* __restrict__ gkeys, uint32_t* __restrict__ gvals) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint64_t n = (uint64_t)v.K * v.P;
-  if (i >= n) return;
-  const uint64_t k = i / (uint64_t)v.P;
-  // invisible (k, Gaussian) pairs sort to the end of their subframe and emit nothing
-  const uint32_t low = tiles_touched[i] ? __float_as_uint(rows[i].depth) : 0xFFFFFFFFu;
-  gkeys[i] = (k << 32) | low;
-  gvals[i] = (uint32_t)i;
-}
-
 __global__ void __launch_bounds__(256)
 gather_u32_kernel(uint64_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ src,
                   uint32_t* __restrict__ dst) {
@@ -430,27 +418,55 @@ colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nblocks, uint32_t* _
   ctot[(size_t)blockIdx.x * SORT_MAX_BINS + threadIdx.x + 256] = run1;
 }
 
-// one block: chunk totals -> exclusive chunk bases per digit, plus the exclusive base of each digit
+// one block: chunk totals -> exclusive chunk bases per digit, plus the exclusive base of each digit.
+// The chunk loop is latency-bound (one block, dependent only through the running sums), so rows are fetched
+// eight at a time before the serial prefix is applied.
 __global__ void __launch_bounds__(256)
 colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nchunks) {
   __shared__ uint32_t lds[8];
+  constexpr int U = 8;
   uint32_t run0 = 0, run1 = 0;
-  for (uint32_t c = 0; c < nchunks; c++) {
-    uint32_t* row = ctot + (size_t)c * SORT_MAX_BINS;
-    const uint32_t a = row[threadIdx.x], b = row[threadIdx.x + 256];
-    row[threadIdx.x] = run0;
-    row[threadIdx.x + 256] = run1;
-    run0 += a;
-    run1 += b;
+  for (uint32_t c0 = 0; c0 < nchunks; c0 += U) {
+    uint32_t a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const bool ok = c0 + u < nchunks;
+      const uint32_t* row = ctot + (size_t)(ok ? c0 + u : c0) * SORT_MAX_BINS;
+      a[u] = ok ? row[threadIdx.x] : 0u;
+      b[u] = ok ? row[threadIdx.x + 256] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (c0 + u < nchunks) {
+        uint32_t* row = ctot + (size_t)(c0 + u) * SORT_MAX_BINS;
+        row[threadIdx.x] = run0;
+        row[threadIdx.x + 256] = run1;
+      }
+      run0 += a[u];
+      run1 += b[u];
+    }
   }
   // digit order is 0..255 (run0 of thread t) then 256..511 (run1 of thread t)
   uint32_t tot0, tot1;
   const uint32_t pre0 = block_excl_scan(run0, &tot0, lds);
   const uint32_t pre1 = block_excl_scan(run1, &tot1, lds) + tot0;
-  for (uint32_t c = 0; c < nchunks; c++) {
-    uint32_t* row = ctot + (size_t)c * SORT_MAX_BINS;
-    row[threadIdx.x] += pre0;
-    row[threadIdx.x + 256] += pre1;
+  for (uint32_t c0 = 0; c0 < nchunks; c0 += U) {
+    uint32_t a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const bool ok = c0 + u < nchunks;
+      const uint32_t* row = ctot + (size_t)(ok ? c0 + u : c0) * SORT_MAX_BINS;
+      a[u] = row[threadIdx.x];
+      b[u] = row[threadIdx.x + 256];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (c0 + u < nchunks) {
+        uint32_t* row = ctot + (size_t)(c0 + u) * SORT_MAX_BINS;
+        row[threadIdx.x] = a[u] + pre0;
+        row[threadIdx.x + 256] = b[u] + pre1;
+      }
+    }
   }
 }
 
@@ -790,14 +806,6 @@ hipError_t dgs_launch_duplicate(const DgsView& v, const DgsCarve& c, hipStream_t
   const uint64_t n = (uint64_t)v.K * v.P;
   hipLaunchKernelGGL(duplicate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, v, c.rows, c.tiles_touched,
                      c.point_offsets, c.keys_unsorted, c.vals_unsorted);
-  return hipGetLastError();
-}
-
-hipError_t dgs_launch_gaussian_keys(const DgsView& v, const DgsCarve& c, uint64_t* gkeys, uint32_t* gvals,
-                                    hipStream_t s) {
-  const uint64_t n = (uint64_t)v.K * v.P;
-  hipLaunchKernelGGL(gaussian_keys_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, v, c.rows,
-                     c.tiles_touched, gkeys, gvals);
   return hipGetLastError();
 }
 

@@ -130,8 +130,6 @@ hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32
                            hipStream_t s);
 hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
                            int begin_bit, int end_bit, uint32_t* tmp, int* result_in_alt, hipStream_t s);
-hipError_t dgs_launch_gaussian_keys(const DgsView& v, const DgsCarve& c, uint64_t* gkeys, uint32_t* gvals,
-                                    hipStream_t s);
 hipError_t dgs_launch_duplicate_sorted(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* tt_sorted,
                                        uint32_t* offs_sorted, uint32_t* scan_tmp, hipStream_t s);
 hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,

@@ -446,14 +446,34 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
 }
 
 // Sums the per-block partials and scatters them into the two [K,4,4] outputs.  Deterministic: thread t adds
-// blocks t, t+256, ... in order, then a fixed-shape tree combines the 256 partial sums.
+// blocks t, t+256, ... in order for all 21 values at once (one 84-byte row per block), then a fixed-shape tree
+// over the 256 threads combines them.
 __global__ void __launch_bounds__(256)
 pose_grad_reduce_kernel(int K, int nblocks, const float* __restrict__ partials, float* __restrict__ dL_dview,
                         float* __restrict__ dL_dproj) {
-  __shared__ float red[256];
+  __shared__ float red[256][21 + 1];
   const int k = blockIdx.x;
   const size_t stride = (size_t)K * NMAT;
-  for (int i = 0; i < 32; i++) {  // output slot i: 0..15 view entry i, 16..31 proj entry i-16
+  float acc[21];
+#pragma unroll
+  for (int i = 0; i < 21; i++) acc[i] = 0.0f;
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    const float* p = partials + (size_t)b * stride + (size_t)k * NMAT;
+#pragma unroll
+    for (int i = 0; i < 21; i++) acc[i] += p[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 21; i++) red[threadIdx.x][i] = acc[i];
+  __syncthreads();
+  for (int h = 128; h >= 1; h >>= 1) {
+    if ((int)threadIdx.x < h) {
+#pragma unroll
+      for (int i = 0; i < 21; i++) red[threadIdx.x][i] += red[threadIdx.x + h][i];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 32) {
+    const int i = threadIdx.x;  // output slot: 0..15 view entry i, 16..31 proj entry i-16
     int src = -1;
     if (i < 16) {
       const int r = i >> 2, c = i & 3;
@@ -463,24 +483,11 @@ pose_grad_reduce_kernel(int K, int nblocks, const float* __restrict__ partials, 
       if (c < 2) src = 12 + r * 2 + c;  // proj[4r+c], c in {0,1}
       if (c == 3) src = 20;             // proj[3], [7], [11], [15]
     }
-    float acc = 0.0f;
-    if (src >= 0) {
-      const float* p = partials + (size_t)k * NMAT + src;
-      for (int b = threadIdx.x; b < nblocks; b += 256) acc += p[(size_t)b * stride];
-    }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int h = 128; h >= 1; h >>= 1) {
-      if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      if (i < 16)
-        dL_dview[16 * k + i] = red[0];
-      else
-        dL_dproj[16 * k + (i - 16)] = red[0];
-    }
-    __syncthreads();
+    const float v = src >= 0 ? red[0][src] : 0.0f;
+    if (i < 16)
+      dL_dview[16 * k + i] = v;
+    else
+      dL_dproj[16 * k + (i - 16)] = v;
   }
 }
 
