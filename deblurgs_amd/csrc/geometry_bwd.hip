@@ -57,36 +57,39 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 __global__ void __launch_bounds__(256)
 contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ offsets,
                       float* __restrict__ contrib) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  // four lanes per (subframe, Gaussian): lane part p in {0,1,2} owns the p-th float4 of every row of the segment
+  // (part 3 idles), so a quad reads each 48-byte row with one contiguous access and no cross-lane sum is needed
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t i = t >> 2;
+  const uint32_t part = (uint32_t)t & 3u;
+  if (i >= n || part == 3u) return;
   const uint32_t nt = tiles_touched[i];
   if (nt < 2) return;  // nothing to add
-  float4* cp = reinterpret_cast<float4*>(contrib + (size_t)offsets[i] * DGS_CONTRIB_F);
-  float4 a0 = cp[0], a1 = cp[1], a2 = cp[2];
-  // rows are added strictly in duplicate order (deterministic), but four rows are requested before the first
-  // add so that the dependent-load chain of the plain loop does not serialise the HBM latency
+  float4* cp = reinterpret_cast<float4*>(contrib + (size_t)offsets[i] * DGS_CONTRIB_F) + part;
+  float4 a = cp[0];
+  // rows are added strictly in duplicate order (deterministic); eight rows are requested before the first add so
+  // that the loop is not a chain of dependent HBM round trips
   uint32_t r = 1;
-  for (; r + 4 <= nt; r += 4) {
-    float4 q[12];
+  for (; r + 8 <= nt; r += 8) {
+    float4 q[8];
 #pragma unroll
-    for (int i = 0; i < 12; i++) q[i] = cp[3 * r + i];
+    for (int j = 0; j < 8; j++) q[j] = cp[3 * (r + j)];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const float4 r0 = q[3 * i], r1 = q[3 * i + 1], r2 = q[3 * i + 2];
-      a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w;
-      a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
-      a2.x += r2.x; a2.y += r2.y;
+    for (int j = 0; j < 8; j++) {
+      a.x += q[j].x;
+      a.y += q[j].y;
+      a.z += q[j].z;
+      a.w += q[j].w;
     }
   }
   for (; r < nt; r++) {
-    const float4 r0 = cp[3 * r], r1 = cp[3 * r + 1], r2 = cp[3 * r + 2];
-    a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w;
-    a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
-    a2.x += r2.x; a2.y += r2.y;
+    const float4 q = cp[3 * r];
+    a.x += q.x;
+    a.y += q.y;
+    a.z += q.z;
+    a.w += q.w;
   }
-  cp[0] = a0;
-  cp[1] = a1;
-  cp[2] = a2;
+  cp[0] = a;
 }
 
 template <int MAXC>  // MAXC = SH coefficients held in registers: 1, 4, 9 or 16
@@ -505,7 +508,7 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
   // (that is the order the duplicates were laid out in), so a wave streams one contiguous span of rows
   // (tt_sorted / offs_sorted only exist when the forward produced duplicates)
   if (io.num_rendered > 0)
-    hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((kp + 255) / 256)), dim3(256), 0, s, kp, c.tt_sorted,
+    hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((4 * kp + 255) / 256)), dim3(256), 0, s, kp, c.tt_sorted,
                        c.offs_sorted, const_cast<float*>(contrib));
 #define DGS_GB_LAUNCH(MAXC)                                                                                          \
   hipLaunchKernelGGL(geometry_bwd_kernel<MAXC>, dim3(blocks), dim3(GB_THREADS), lds, s, v, p.means3D, p.shs,         \
