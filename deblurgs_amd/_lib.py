@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libdgs_hip.so")
 
 DGS_MAX_K = 128
 STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "composite_fwd", "composite_bwd", "geometry_bwd",
-          "depth_order"]
+          "depth_order", "tile_cull"]
 
 _c_f32p = ctypes.c_void_p  # device pointers are passed as integers
 
@@ -24,6 +24,7 @@ class DgsProblem(ctypes.Structure):
         ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
         ("z_near", ctypes.c_float), ("z_far", ctypes.c_float),
         ("use_sigmoid", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
+        ("tile_cull", ctypes.c_int32),
         ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p), ("colors_precomp", ctypes.c_void_p),
         ("opacities", ctypes.c_void_p), ("scales", ctypes.c_void_p), ("rotations", ctypes.c_void_p),
         ("cov3D_precomp", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p), ("projmatrix", ctypes.c_void_p),
@@ -53,7 +54,7 @@ class DgsBackwardIO(ctypes.Structure):
 class DgsLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in (
         "geom_rows", "cov3D", "pre_sigmoid", "tiles_touched", "point_offsets", "scan_tmp", "num_rendered",
-        "gsort_keys", "gsort_keys_alt", "gsort_vals", "gsort_vals_alt", "tt_sorted", "offs_sorted", "gsort_tmp",
+        "gsort_keys", "gsort_keys_alt", "gsort_vals", "gsort_vals_alt", "tt_sorted", "offs_sorted", "tt_tight", "offs_tight", "gsort_tmp",
         "geom_total", "final_T", "n_contrib", "ranges", "image_total", "keys_sorted", "point_list",
         "keys_unsorted", "vals_unsorted", "sort_tmp", "binning_total")] + [
         ("sort_bits", ctypes.c_int32), ("sort_passes", ctypes.c_int32)]
@@ -114,7 +115,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.dgs_abi_version() != 1:
+        if L.dgs_abi_version() != 2:
             raise RuntimeError("libdgs_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -14,7 +14,8 @@ ARCH = "gfx950"
 # per-file extra flags: the forward preprocess must not contract mul+add into FMA (bit-exact tile keys)
 SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
-    "binning.hip": [],
+    # tile_cull: the count and emit instantiations of the per-slot test must round identically
+    "binning.hip": ["-ffp-contract=off"],
     # SLP packing into v_pk_*_f32 costs more v_mov shuffles than it saves here (920 vs 715 VALU instructions)
     "composite.hip": ["-fno-slp-vectorize"],
     "geometry_bwd.hip": [],

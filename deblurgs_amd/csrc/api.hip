@@ -47,6 +47,8 @@ void make_layout(int P, int W, int H, int K, uint64_t R, DgsLayout* L) {
   L->gsort_vals_alt = o; o += up(KP * 4);
   L->tt_sorted = o;      o += up(KP * 4);
   L->offs_sorted = o;    o += up(KP * 4);
+  L->tt_tight = o;       o += up(KP * 4);
+  L->offs_tight = o;     o += up(KP * 4);
   L->gsort_tmp = o;      o += up(dgs_sort_tmp_words(KP) * 4);
   L->geom_total = o;
   o = 0;
@@ -98,6 +100,7 @@ DgsView make_view(const DgsProblem* p) {
   v.scale_modifier = p->scale_modifier;
   v.z_far = p->z_far;
   v.use_sigmoid = p->use_sigmoid; v.prefiltered = p->prefiltered;
+  v.tile_cull = p->tile_cull != 0;
   return v;
 }
 
@@ -118,6 +121,8 @@ void carve(const DgsProblem* p, const DgsLayout& L, DgsCarve* c) {
   c->gsort_vals_alt = reinterpret_cast<uint32_t*>(g + L.gsort_vals_alt);
   c->tt_sorted = reinterpret_cast<uint32_t*>(g + L.tt_sorted);
   c->offs_sorted = reinterpret_cast<uint32_t*>(g + L.offs_sorted);
+  c->tt_tight = reinterpret_cast<uint32_t*>(g + L.tt_tight);
+  c->offs_tight = reinterpret_cast<uint32_t*>(g + L.offs_tight);
   c->gsort_tmp = reinterpret_cast<uint32_t*>(g + L.gsort_tmp);
   c->final_T = reinterpret_cast<float*>(im + L.final_T);
   c->n_contrib = reinterpret_cast<uint32_t*>(im + L.n_contrib);
@@ -334,6 +339,15 @@ int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, DgsLayout
   return DGS_OK;
 }
 
+static int depth_order_bits(const DgsProblem* p) {
+  return 32 + (p->K > 1 ? (int)dgs_higher_msb((uint32_t)p->K) : 0);
+}
+// order the (k, Gaussian) pairs by (k, depth bits, index): stable sort of the keys preprocess wrote
+static hipError_t launch_depth_order(const DgsProblem* p, const DgsCarve& c, int* in_alt, hipStream_t s) {
+  return dgs_launch_sort(c.gsort_keys, c.gsort_vals, c.gsort_keys_alt, c.gsort_vals_alt, (uint64_t)p->K * p->P, 0,
+                         depth_order_bits(p), c.gsort_tmp, in_alt, s);
+}
+
 int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = check_problem(p);
@@ -353,10 +367,24 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
   carve(p, L, &c);
   const DgsView v = make_view(p);
   DGS_STAGE(DGS_STAGE_PREPROCESS, "preprocess", dgs_launch_preprocess(*p, v, c, out->radii, s));
-  DGS_STAGE(DGS_STAGE_SCAN, "scan",
-            dgs_launch_scan(c.tiles_touched, c.point_offsets, (uint64_t)p->K * p->P, c.scan_tmp, c.num_rendered, s));
-  // two words: R and the high half of the 64-bit total (non-zero = the u32 duplicate offsets overflowed)
-  hipError_t e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  hipError_t e;
+  if (!v.tile_cull) {
+    DGS_STAGE(DGS_STAGE_SCAN, "scan",
+              dgs_launch_scan(c.tiles_touched, c.point_offsets, (uint64_t)p->K * p->P, c.scan_tmp, c.num_rendered, s));
+    // two words: R and the high half of the 64-bit total (non-zero = the u32 duplicate offsets overflowed)
+    e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  } else {
+    // tile_cull: R is the number of surviving duplicates, known only after the depth ordering and the per-slot
+    // test; the overflow word still comes from the rectangle total, whose u32 offsets drive the expansion
+    int g_in_alt = 0;
+    DGS_STAGE(DGS_STAGE_DEPTH_ORDER, "depth order", launch_depth_order(p, c, &g_in_alt, s));
+    const uint32_t* order = g_in_alt ? c.gsort_vals_alt : c.gsort_vals;
+    DGS_STAGE(DGS_STAGE_TILE_CULL, "tile cull count",
+              dgs_launch_tight_count(v, c, order, c.num_rendered, c.num_rendered + 2, s));
+    e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(out->num_rendered_host + 1, c.num_rendered + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  }
   if (e != hipSuccess) return fail_hip(e, "copy num_rendered");
   return DGS_OK;
 }
@@ -382,7 +410,7 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t R
   DgsCarve c;
   carve(p, L, &c);
   const DgsView v = make_view(p);
-  if (R > 0) {
+  if (R > 0 || v.tile_cull) {  // tile_cull with R == 0 still marks the visible pairs as "no surviving tile"
     // choose the sort's input pair so that the result always lands in keys_sorted / point_list
     DgsCarve cd = c;
     const bool even = (L.sort_passes % 2) == 0;
@@ -390,23 +418,19 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t R
       cd.keys_unsorted = c.keys_sorted;
       cd.vals_unsorted = c.point_list;
     }
-    // (1) order the (k, Gaussian) pairs by (k, depth bits, index)
-    const int gbits = 32 + (p->K > 1 ? (int)dgs_higher_msb((uint32_t)p->K) : 0);
-    int g_in_alt = 0;
-    {
-      hipError_t e__;
-      {
-        StageTimer tm__(DGS_STAGE_DEPTH_ORDER, s);
-        e__ = dgs_launch_sort(c.gsort_keys, c.gsort_vals, c.gsort_keys_alt, c.gsort_vals_alt,
-                                (uint64_t)p->K * p->P, 0, gbits, c.gsort_tmp, &g_in_alt, s);
-      }
-      if (e__ != hipSuccess) return fail_hip(e__, "depth order");
-      if (p->debug && (e__ = hipStreamSynchronize(s)) != hipSuccess) return fail_hip(e__, "depth order (debug sync)");
+    if (!v.tile_cull) {
+      // (1) order the (k, Gaussian) pairs by (k, depth bits, index)
+      int g_in_alt = 0;
+      DGS_STAGE(DGS_STAGE_DEPTH_ORDER, "depth order", launch_depth_order(p, c, &g_in_alt, s));
+      const uint32_t* order = g_in_alt ? c.gsort_vals_alt : c.gsort_vals;
+      // (2) duplicate in that order, (3) stable sort on the tile bits only
+      DGS_STAGE(DGS_STAGE_DUPLICATE, "duplicateWithKeys",
+                dgs_launch_duplicate_sorted(v, cd, order, c.tt_sorted, c.offs_sorted, c.scan_tmp, s));
+    } else {
+      // the ordering and the surviving-tile offsets were produced by dgs_forward_geometry
+      const uint32_t* order = (dgs_sort_num_passes(0, depth_order_bits(p)) & 1) ? c.gsort_vals_alt : c.gsort_vals;
+      DGS_STAGE(DGS_STAGE_DUPLICATE, "duplicateWithKeys", dgs_launch_duplicate_tight(v, cd, order, s));
     }
-    const uint32_t* order = g_in_alt ? c.gsort_vals_alt : c.gsort_vals;
-    // (2) duplicate in that order, (3) stable sort on the tile bits only
-    DGS_STAGE(DGS_STAGE_DUPLICATE, "duplicateWithKeys",
-              dgs_launch_duplicate_sorted(v, cd, order, c.tt_sorted, c.offs_sorted, c.scan_tmp, s));
     int in_alt = 0;
     uint64_t* kalt = even ? c.keys_unsorted : c.keys_sorted;
     uint32_t* valt = even ? c.vals_unsorted : c.point_list;

@@ -264,6 +264,147 @@ duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __
   }
 }
 
+// ------------------------------------------------------------------------------- tile_cull duplication
+// The reference emits one duplicate per tile of the 3-sigma bounding rectangle (rasterizer_impl.cu:76-108), but
+// on the metric scene 42 % of those can never reach alpha >= 1/255 inside their tile: the compositing kernels
+// skip them at every pixel (forward.cu:356-358), after they have been sorted, range-marked, gathered and tested.
+// With tile_cull the same cooperative expansion walks the rectangle slots, evaluates the exact ellipse-vs-tile
+// test (dgs_cull_hit, conservative) per slot and keeps only the hits.  COUNT pass: per (k, Gaussian) number of
+// hits.  EMIT pass (after the scan of those counts): recomputes the identical test -- this file is built with
+// -ffp-contract=off so both instantiations round identically -- and writes the compacted keys/values; the low key
+// word carries the duplicate's own index u (its contribution-row slot for the backward) instead of the depth
+// bits, which the tile-bits-only stable sort never looks at.
+template <bool EMIT>
+__global__ void __launch_bounds__(256)
+tight_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __restrict__ order,
+             const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ offs_sorted,
+             uint32_t* __restrict__ tt_tight, const uint32_t* __restrict__ offs_tight,
+             const uint32_t* __restrict__ total_full, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  // the rectangle total overflowed 32 bits: the offsets are meaningless (the host raises on the overflow word)
+  if (total_full[1] != 0u) {
+    const uint64_t jj = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (!EMIT && jj < (uint64_t)v.K * v.P) tt_tight[jj] = 0;
+    return;
+  }
+  __shared__ uint32_t s_off[4][64];
+  __shared__ uint32_t s_rect[4][64];
+  __shared__ uint32_t s_wide[4][64];
+  __shared__ uint32_t s_tb[4][64];
+  __shared__ uint32_t s_g[4][64];
+  __shared__ uint32_t s_cnt[4][64];
+  __shared__ float4 s_q[4][64];   // x, y, a, b
+  __shared__ float4 s_r[4][64];   // c, 1/a, 1/c, r2
+  __shared__ uint32_t s_fl[4][64];  // 1 = always, 2 = never
+  const int lane = dgs_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t n = (uint64_t)v.K * v.P;
+  const bool in = j < n;
+  uint32_t off = 0, nt = 0, otight = 0;
+  if (in) {
+    const uint32_t i = order[j];
+    off = offs_sorted[j];
+    nt = tt_sorted[j];
+    uint32_t rect = 0, wide = 0, tb = 0, g = 0, fl = 0;
+    float4 q = make_float4(0, 0, 0, 0), r = q;
+    if (nt != 0) {
+      const uint32_t k = i / (uint32_t)v.P;
+      g = i - k * (uint32_t)v.P;
+      DgsRow* row = rows + i;
+      const float4 A = reinterpret_cast<const float4*>(row)[0];  // x, y, cx, cy
+      const float4 B = reinterpret_cast<const float4*>(row)[1];  // cz, op, ...
+      int minx, miny, maxx, maxy;
+      dgs_get_rect(A.x, A.y, row->radius, v.gx, v.gy, minx, miny, maxx, maxy);
+      wide = (uint32_t)(maxx - minx);
+      rect = (uint32_t)minx | ((uint32_t)miny << 12);
+      tb = k * (uint32_t)v.T;
+      const DgsCull cg = dgs_make_cull(A.z, A.w, B.x, B.y);
+      q = make_float4(A.x, A.y, cg.a, cg.b);
+      r = make_float4(cg.c, cg.inv_a, cg.inv_c, cg.r2);
+      fl = (cg.always ? 1u : 0u) | (cg.never ? 2u : 0u);
+      if (EMIT) {
+        otight = offs_tight[j];
+        row->dup_offset = tt_tight[j] != 0 ? otight : 0xFFFFFFFFu;  // no surviving tile: geometry_bwd reads zeros
+      }
+    } else if (EMIT) {
+      otight = offs_tight[j];
+    }
+    s_rect[w][lane] = rect;
+    s_wide[w][lane] = wide;
+    s_tb[w][lane] = tb;
+    s_g[w][lane] = g;
+    s_q[w][lane] = q;
+    s_r[w][lane] = r;
+    s_fl[w][lane] = fl;
+  }
+  s_cnt[w][lane] = 0;
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+  const uint32_t obase = (uint32_t)__builtin_amdgcn_readfirstlane((int)otight);
+  s_off[w][lane] = in ? off - base : 0xFFFFFFFFu;
+  const uint64_t valid = __ballot(in);
+  if (valid == 0ull) return;
+  const int last = 63 - __builtin_clzll(valid);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)(off + nt), last) - base;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint32_t run = 0;  // hits emitted by earlier rounds (wave-uniform)
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (uint32_t d0 = 0; d0 < total; d0 += 64) {
+    const uint32_t d = d0 + (uint32_t)lane;
+    const bool act = d < total;
+    int lo = 0;
+    bool hit = false;
+    uint32_t tile = 0;
+    if (act) {
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1) {
+        const int mid = lo + step;
+        if (mid < 64 && s_off[w][mid] <= d) lo = mid;
+      }
+      const uint32_t local = d - s_off[w][lo];
+      const uint32_t width = s_wide[w][lo];
+      const uint32_t rect = s_rect[w][lo];
+      const uint32_t ry = local / width, rx = local - ry * width;
+      const uint32_t tx = (rect & 0xFFFu) + rx, ty = (rect >> 12) + ry;
+      tile = s_tb[w][lo] + ty * (uint32_t)v.gx + tx;
+      const float4 q = s_q[w][lo], r = s_r[w][lo];
+      const uint32_t fl = s_fl[w][lo];
+      DgsCull cg;
+      cg.a = q.z; cg.b = q.w; cg.c = r.x; cg.inv_a = r.y; cg.inv_c = r.z; cg.r2 = r.w;
+      cg.always = (fl & 1u) != 0; cg.never = (fl & 2u) != 0;
+      // d = mean - pixel over the tile's pixel centres [16 t, 16 t + 15]
+      const float ex = q.x - (float)(tx * DGS_TILE), ey = q.y - (float)(ty * DGS_TILE);
+      hit = dgs_cull_hit(cg, ex - (float)(DGS_TILE - 1), ex, ey - (float)(DGS_TILE - 1), ey);
+    }
+    const uint64_t hm = __ballot(hit);
+    if (EMIT) {
+      if (hit) {
+        const uint32_t pos = obase + run + (uint32_t)__builtin_popcountll(hm & lt);
+        keys[pos] = ((uint64_t)tile << 32) | pos;
+        vals[pos] = s_g[w][lo];
+      }
+      run += (uint32_t)__builtin_popcountll(hm);
+    } else {
+      // one lane per segment of this round (the first slot of the segment in the round) adds the segment's hits
+      const int prev = __shfl_up(lo, 1, 64);
+      const bool first = act && (lane == 0 || prev != lo);
+      const uint64_t fm = __ballot(first);
+      if (first) {
+        const uint64_t rest = (lane == 63) ? 0ull : (fm >> (lane + 1));
+        const int len = rest ? (__builtin_ctzll(rest) + 1) : (64 - lane);
+        const uint64_t seg = ((len == 64) ? ~0ull : ((1ull << len) - 1ull)) << lane;
+        s_cnt[w][lo] += (uint32_t)__builtin_popcountll(hm & seg);
+      }
+    }
+  }
+  if (!EMIT) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (in) tt_tight[j] = s_cnt[w][lane];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- ranges
 __global__ void __launch_bounds__(256)
 ranges_kernel(uint32_t L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
@@ -818,6 +959,26 @@ hipError_t dgs_launch_duplicate_sorted(const DgsView& v, const DgsCarve& c, cons
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(duplicate_sorted_kernel, grid, dim3(256), 0, s, v, c.rows, order, tt_sorted, offs_sorted,
                      c.point_offsets, c.keys_unsorted, c.vals_unsorted);
+  return hipGetLastError();
+}
+
+hipError_t dgs_launch_tight_count(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* total_full,
+                                  uint32_t* total_tight, hipStream_t s) {
+  const uint64_t n = (uint64_t)v.K * v.P;
+  const dim3 grid((uint32_t)((n + 255) / 256));
+  hipLaunchKernelGGL(gather_u32_kernel, grid, dim3(256), 0, s, n, order, c.tiles_touched, c.tt_sorted);
+  hipError_t e = dgs_launch_scan(c.tt_sorted, c.offs_sorted, n, c.scan_tmp, total_full, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(tight_kernel<false>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
+                     c.tt_tight, c.offs_tight, total_full, (uint64_t*)nullptr, (uint32_t*)nullptr);
+  return dgs_launch_scan(c.tt_tight, c.offs_tight, n, c.scan_tmp, total_tight, s);
+}
+
+hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const uint32_t* order, hipStream_t s) {
+  const uint64_t n = (uint64_t)v.K * v.P;
+  const dim3 grid((uint32_t)((n + 255) / 256));
+  hipLaunchKernelGGL(tight_kernel<true>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
+                     c.tt_tight, c.offs_tight, c.num_rendered, c.keys_unsorted, c.vals_unsorted);
   return hipGetLastError();
 }
 

@@ -57,44 +57,9 @@ __device__ __forceinline__ bool load_tile_ctx(const DgsView& v, const uint2* __r
 // origin, otherwise it sits on one of the four edges, where q is a 1-D quadratic with a closed-form clamped
 // minimiser.  A slack on r2 and a relative slack on q keep it conservative under fp32 rounding, so the exact
 // per-pixel tests of the reference still decide every pair that survives.
-struct CullGauss {
-  float a, b, c, inv_a, inv_c, r2;
-  bool always;  // degenerate conic: never cull
-  bool never;   // opacity too small to ever reach 1/255
-};
-__device__ __forceinline__ CullGauss make_cull(float cx, float cy, float cz, float op) {
-  CullGauss g;
-  g.a = cx;
-  g.b = cy;
-  g.c = cz;
-  g.r2 = 2.0f * __logf(255.0f * op) + 0.02f;  // slack >> fp32 error of `power`
-  const float det = cx * cz - cy * cy;
-  g.always = !(det > 0.0f && cx > 0.0f && cz > 0.0f);  // also catches NaN
-  g.never = (g.r2 < 0.0f);
-  g.inv_a = 1.0f / cx;
-  g.inv_c = 1.0f / cz;
-  return g;
-}
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
-// min over dy in [lo, hi] of q(e, dy)
-__device__ __forceinline__ float edge_min_x(const CullGauss& g, float e, float lo, float hi) {
-  const float t = clampf(-g.b * e * g.inv_c, lo, hi);
-  return g.a * e * e + (2.0f * g.b * e + g.c * t) * t;
-}
-// min over dx in [lo, hi] of q(dx, e)
-__device__ __forceinline__ float edge_min_y(const CullGauss& g, float e, float lo, float hi) {
-  const float t = clampf(-g.b * e * g.inv_a, lo, hi);
-  return g.c * e * e + (2.0f * g.b * e + g.a * t) * t;
-}
-__device__ __forceinline__ bool cull_hit(const CullGauss& g, float dx_lo, float dx_hi, float dy_lo, float dy_hi) {
-  if (g.always) return true;
-  if (g.never) return false;
-  const bool inside = (dx_lo <= 0.0f) && (dx_hi >= 0.0f) && (dy_lo <= 0.0f) && (dy_hi >= 0.0f);
-  float qm = fminf(fminf(edge_min_x(g, dx_lo, dy_lo, dy_hi), edge_min_x(g, dx_hi, dy_lo, dy_hi)),
-                   fminf(edge_min_y(g, dy_lo, dx_lo, dx_hi), edge_min_y(g, dy_hi, dx_lo, dx_hi)));
-  qm = inside ? 0.0f : qm;
-  return !(qm * 0.9999f > g.r2);  // NaN -> keep
-}
+using CullGauss = DgsCull;
+#define make_cull dgs_make_cull
+#define cull_hit dgs_cull_hit
 
 // ------------------------------------------------------------------------------------------------ forward
 __global__ void __launch_bounds__(64 * CW)
@@ -215,9 +180,11 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
 }
 
 // ----------------------------------------------------------------------------------------------- backward
+template <bool TIGHT>  // TIGHT: the duplicate index travels in the low key word (tile_cull emission)
 __global__ void __launch_bounds__(64 * CW)
 composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
-                     const uint32_t* __restrict__ point_list, const DgsRow* __restrict__ rows,
+                     const uint32_t* __restrict__ point_list, const uint64_t* __restrict__ keys,
+                     const DgsRow* __restrict__ rows,
                      const float* __restrict__ bg, const float* __restrict__ final_T,
                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                      const float* __restrict__ dL_ddepth, float* __restrict__ contrib) {
@@ -279,10 +246,14 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       A = rp[0];
       B = rp[1];
       Cc = rp[2];
-      // index of this (tile, Gaussian) duplicate in duplicate order: row-major inside the Gaussian's tile rect
-      int minx, miny, maxx, maxy;
-      dgs_get_rect(A.x, A.y, __float_as_int(Cc.w), v.gx, v.gy, minx, miny, maxx, maxy);
-      u = __float_as_uint(Cc.z) + (uint32_t)((t.ty - miny) * (maxx - minx) + (t.tx - minx));
+      if (TIGHT) {
+        u = reinterpret_cast<const uint32_t*>(keys)[2 * (size_t)(t.r0 + base + lane)];
+      } else {
+        // index of this (tile, Gaussian) duplicate in duplicate order: row-major inside the Gaussian's tile rect
+        int minx, miny, maxx, maxy;
+        dgs_get_rect(A.x, A.y, __float_as_int(Cc.w), v.gx, v.gy, minx, miny, maxx, maxy);
+        u = __float_as_uint(Cc.z) + (uint32_t)((t.ty - miny) * (maxx - minx) + (t.tx - minx));
+      }
     }
     uint64_t m[4] = {0, 0, 0, 0};
     if (base < maxc) {
@@ -416,7 +387,11 @@ hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const f
                                     const float* dL_ddepth, float* contrib, hipStream_t s) {
   const uint32_t per = per_xcd_blocks(v);
   if (per == 0) return hipSuccess;
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
-                     c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth, contrib);
+  if (v.tile_cull)
+    hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
+                       c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth, contrib);
+  else
+    hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges,
+                       c.point_list, c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth, contrib);
   return hipGetLastError();
 }

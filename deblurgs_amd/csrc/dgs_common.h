@@ -36,6 +36,8 @@ struct DgsCarve {  // resolved device pointers of the three blobs
   uint32_t* gsort_vals_alt;
   uint32_t* tt_sorted;       // tiles_touched in that order, and its exclusive scan
   uint32_t* offs_sorted;
+  uint32_t* tt_tight;        // tile_cull: per (k, Gaussian) count of tiles that can reach alpha >= 1/255, same order,
+  uint32_t* offs_tight;      //            and its exclusive scan (= duplicate / contribution-row offsets)
   uint32_t* gsort_tmp;
   float* final_T;
   uint32_t* n_contrib;
@@ -119,7 +121,53 @@ struct DgsView {  // per-launch scalars shared by the kernels
   int gx, gy, T;  // tile grid and tiles per subframe
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier, z_far;
   int use_sigmoid, prefiltered;
+  int tile_cull;
 };
+
+// ---- exact "can this Gaussian reach alpha >= 1/255 anywhere in this pixel box" test -----------------------------
+// alpha = op * exp(-q/2), q(d) = a dx^2 + 2 b dx dy + c dy^2 with d = mean - pixel (forward.cu:346-358), so a pair
+// contributes only where q <= 2 ln(255 op).  The minimum of the convex q over an axis-aligned box of pixel centres
+// is 0 if the mean is inside, else it lies on an edge where it has a closed form.  Used per 8x8 quadrant by the
+// compositing kernels and per 16x16 tile by the tile_cull duplicate emission; always conservative (slack >> the
+// fp32 error of `power`), so a culled pair is one the reference would have skipped at every pixel of the box.
+struct DgsCull {
+  float a, b, c, inv_a, inv_c, r2;
+  bool always;  // degenerate conic: never cull
+  bool never;   // opacity too small to ever reach 1/255
+};
+__device__ __forceinline__ DgsCull dgs_make_cull(float cx, float cy, float cz, float op) {
+  DgsCull g;
+  g.a = cx;
+  g.b = cy;
+  g.c = cz;
+  g.r2 = 2.0f * __logf(255.0f * op) + 0.02f;
+  const float det = cx * cz - cy * cy;
+  g.always = !(det > 0.0f && cx > 0.0f && cz > 0.0f);  // also catches NaN
+  g.never = (g.r2 < 0.0f);
+  g.inv_a = 1.0f / cx;
+  g.inv_c = 1.0f / cz;
+  return g;
+}
+__device__ __forceinline__ float dgs_clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
+// min over dy in [lo, hi] of q(e, dy)
+__device__ __forceinline__ float dgs_edge_min_x(const DgsCull& g, float e, float lo, float hi) {
+  const float t = dgs_clampf(-g.b * e * g.inv_c, lo, hi);
+  return g.a * e * e + (2.0f * g.b * e + g.c * t) * t;
+}
+// min over dx in [lo, hi] of q(dx, e)
+__device__ __forceinline__ float dgs_edge_min_y(const DgsCull& g, float e, float lo, float hi) {
+  const float t = dgs_clampf(-g.b * e * g.inv_a, lo, hi);
+  return g.c * e * e + (2.0f * g.b * e + g.a * t) * t;
+}
+__device__ __forceinline__ bool dgs_cull_hit(const DgsCull& g, float dx_lo, float dx_hi, float dy_lo, float dy_hi) {
+  if (g.always) return true;
+  if (g.never) return false;
+  const bool inside = (dx_lo <= 0.0f) && (dx_hi >= 0.0f) && (dy_lo <= 0.0f) && (dy_hi >= 0.0f);
+  float qm = fminf(fminf(dgs_edge_min_x(g, dx_lo, dy_lo, dy_hi), dgs_edge_min_x(g, dx_hi, dy_lo, dy_hi)),
+                   fminf(dgs_edge_min_y(g, dy_lo, dx_lo, dx_hi), dgs_edge_min_y(g, dy_hi, dx_lo, dx_hi)));
+  qm = inside ? 0.0f : qm;
+  return !(qm * 0.9999f > g.r2);  // NaN -> keep
+}
 
 hipError_t dgs_launch_preprocess(const DgsProblem& p, const DgsView& v, const DgsCarve& c, int32_t* radii,
                                  hipStream_t s);
@@ -132,6 +180,9 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
                            int begin_bit, int end_bit, uint32_t* tmp, int* result_in_alt, hipStream_t s);
 hipError_t dgs_launch_duplicate_sorted(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* tt_sorted,
                                        uint32_t* offs_sorted, uint32_t* scan_tmp, hipStream_t s);
+hipError_t dgs_launch_tight_count(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* total_full,
+                                  uint32_t* total_tight, hipStream_t s);
+hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const uint32_t* order, hipStream_t s);
 hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,
                                     float* out_depth, hipStream_t s);
 hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const float* bg, const float* dL_dpix,

@@ -149,8 +149,11 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
       const float4 ga = rowp[0];   // x, y, cx, cy
       const float4 gb = rowp[1];   // cz, op, r, g
       const uint32_t dup_off = __float_as_uint(rowp[2].z);
-      const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)dup_off * DGS_CONTRIB_F);
-      const float4 r0 = cp[0], r1 = cp[1], r2 = cp[2];
+      // tile_cull leaves dup_off = ~0 for a visible pair whose every tile was culled: all its sums are zero
+      const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)(dup_off == 0xFFFFFFFFu ? 0u : dup_off) * DGS_CONTRIB_F);
+      const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      const bool none = dup_off == 0xFFFFFFFFu;
+      const float4 r0 = none ? z4 : cp[0], r1 = none ? z4 : cp[1], r2 = none ? z4 : cp[2];
       const float s[10] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
       // raw sums -> the reference's per-Gaussian sinks (backward.cu:620-637; see composite.hip):
       //   dL_dmean2D = -(0.5 W, 0.5 H) * (cx*Swx + cy*Swy, cz*Swy + cy*Swx),  dL_dconic = -0.5 * (Sxx, Sxy, Syy),
@@ -508,8 +511,9 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
   // (that is the order the duplicates were laid out in), so a wave streams one contiguous span of rows
   // (tt_sorted / offs_sorted only exist when the forward produced duplicates)
   if (io.num_rendered > 0)
-    hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((4 * kp + 255) / 256)), dim3(256), 0, s, kp, c.tt_sorted,
-                       c.offs_sorted, const_cast<float*>(contrib));
+    hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((4 * kp + 255) / 256)), dim3(256), 0, s, kp,
+                       v.tile_cull ? c.tt_tight : c.tt_sorted, v.tile_cull ? c.offs_tight : c.offs_sorted,
+                       const_cast<float*>(contrib));
 #define DGS_GB_LAUNCH(MAXC)                                                                                          \
   hipLaunchKernelGGL(geometry_bwd_kernel<MAXC>, dim3(blocks), dim3(GB_THREADS), lds, s, v, p.means3D, p.shs,         \
                      p.scales, p.rotations, p.cov3D_precomp, p.viewmatrix, p.projmatrix, p.campos, c.point_offsets, c.rows,       \

@@ -8,6 +8,7 @@ Additions for the blur-integration loop: `_RasterizeGaussiansK` / `rasterize_gau
 chain (the reference calls the K=1 operator K times from scene/motion.py:141-143).
 """
 import ctypes
+import os
 from typing import NamedTuple
 
 import torch
@@ -35,6 +36,17 @@ class GaussianRasterizationSettings(NamedTuple):
     campos: torch.Tensor      # [3]; [K,3] for the fused K-subframe operator
     prefiltered: bool
     debug: bool
+
+
+# Tile culling (DgsProblem.tile_cull, include/dgs_hip.h): drop, at duplication time, the (tile, Gaussian) pairs the
+# reference would skip at every pixel of the tile.  Outputs are unchanged; TILE_CULL = False (or DGS_TILE_CULL=0)
+# reproduces the reference's rectangle lists bit for bit.
+TILE_CULL = os.environ.get("DGS_TILE_CULL", "1") != "0"
+
+
+class _NumRendered(int):
+    """num_rendered as the reference returns it, remembering which duplicate rule produced the state blobs."""
+    tile_cull = False
 
 
 # ---------------------------------------------------------------------------------------------- plumbing
@@ -77,8 +89,9 @@ class _State:
 
 
 def _make_problem(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm, campos,
-                  rs, geom, image, binning):
+                  rs, geom, image, binning, tile_cull):
     p = _lib.DgsProblem()
+    p.tile_cull = int(bool(tile_cull))
     p.P = means3D.shape[0]
     p.D = int(rs.sh_degree)
     p.M = 0 if sh is None else sh.shape[1]
@@ -143,14 +156,16 @@ def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, 
     out.radii = _ptr(radii)
     out.num_rendered_host = ctypes.c_void_p(host_R.data_ptr())
     stream = _stream(device)
+    tile_cull = bool(TILE_CULL)
     prob = _make_problem(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm,
-                         campos, rs, geom, image, None)
+                         campos, rs, geom, image, None, tile_cull)
     _lib.check(L.dgs_forward_geometry(ctypes.byref(prob), ctypes.byref(out), stream), "dgs_forward_geometry")
     torch.cuda.current_stream(device).synchronize()   # the one host read of num_rendered (rasterizer_impl.cu:287)
     if int(host_R[1].item()) != 0:
         raise RuntimeError("num_rendered exceeds 32 bits: too many (tile, Gaussian) duplicates for one fused call; "
                            "render fewer subframes per call")
-    R = int(host_R[0].item()) & 0xFFFFFFFF
+    R = _NumRendered(int(host_R[0].item()) & 0xFFFFFFFF)
+    R.tile_cull = tile_cull
     binning = torch.empty(L.dgs_binning_state_bytes(R, W, H, K), dtype=torch.uint8, device=device)
     prob.binning_state = _ptr(binning)
     prob.binning_bytes = binning.numel()
@@ -195,7 +210,7 @@ def _backward_impl(K, R, means3D, sh, colors_precomp, opacities_shape, scales, r
     io.dL_dviewmatrix = _ptr(g_view)
     io.dL_dprojmatrix = _ptr(g_proj)
     prob = _make_problem(K, means3D, sh, colors_precomp, None, scales, rotations, cov3D_precomp, viewm, projm, campos,
-                         rs, geom, image, binning)
+                         rs, geom, image, binning, getattr(R, "tile_cull", False))
     prob.opacities = _ptr(means3D)   # not read by the backward; must be non-null for the argument check
     _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), _stream(device)), "dgs_backward")
     if P == 0:

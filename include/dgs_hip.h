@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 1
+#define DGS_ABI_VERSION 2
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -55,6 +55,11 @@ typedef struct DgsProblem {
   int32_t use_sigmoid; /* colour activation: 0 = relu(x+0.5), 1 = sigmoid (forward.cu:63-80) */
   int32_t prefiltered;
   int32_t debug;       /* sync + check after every stage (auxiliary.h:179-186) */
+  int32_t tile_cull;   /* 0: one duplicate per tile of the 3-sigma rectangle, the reference's exact lists
+                        *    (rasterizer_impl.cu:76-108); 1: drop the duplicates whose Gaussian cannot reach
+                        *    alpha >= 1/255 at any pixel of the tile (pairs the reference skips at every pixel,
+                        *    forward.cu:356-358), so R is smaller and the outputs are unchanged.  Must be the same
+                        *    in the forward and backward calls of one problem. */
   /* inputs, device pointers, fp32 contiguous */
   const float* means3D;        /* [P,3] */
   const float* shs;            /* [P,M,3] or NULL */
@@ -121,6 +126,8 @@ typedef struct DgsLayout {
   size_t gsort_vals_alt; /* u32 [K*P] */
   size_t tt_sorted;      /* u32 [K*P] tiles_touched in (k, depth, index) order */
   size_t offs_sorted;    /* u32 [K*P] its exclusive prefix sum */
+  size_t tt_tight;       /* u32 [K*P] tile_cull: surviving tiles per (k, Gaussian), same order */
+  size_t offs_tight;     /* u32 [K*P] its exclusive prefix sum (its total is R under tile_cull) */
   size_t gsort_tmp;      /* u32 radix tables of the Gaussian sort */
   size_t geom_total;
   /* image blob */
@@ -211,7 +218,8 @@ int dgs_pose_backward(const float* ctrl_trans, const float* ctrl_rot, const floa
 #define DGS_STAGE_COMPOSITE_BWD 6
 #define DGS_STAGE_GEOMETRY_BWD 7
 #define DGS_STAGE_DEPTH_ORDER 8 /* sort of the (k, Gaussian) pairs by depth that precedes the duplication */
-#define DGS_STAGE_COUNT 9
+#define DGS_STAGE_TILE_CULL 9   /* tile_cull: per-slot ellipse test + count, and the scan of the counts */
+#define DGS_STAGE_COUNT 10
 int dgs_profile_enable(int32_t on);
 int dgs_profile_reset(void);
 /* Synchronises on the recorded events; ms[i] = summed duration of stage i, calls[i] = launches timed. */

@@ -84,9 +84,31 @@ def hip_settings(scene, K, sh_degree=None, use_sigmoid=False, scale_modifier=1.0
         campos=_t(cam if K > 1 else cam[0]), prefiltered=False, debug=debug)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def tile_cull(flag):
+    """Selects the duplicate rule of the HIP path for the calls inside: False = the reference's rectangle lists."""
+    from deblurgs_amd import diff_gaussian_rasterization as dgr
+    old = dgr.TILE_CULL
+    dgr.TILE_CULL = bool(flag)
+    try:
+        yield
+    finally:
+        dgr.TILE_CULL = old
+
+
 def hip_forward_state(scene, K, sh_degree=None, use_sigmoid=False, colors_precomp=None, cov3D_precomp=None,
-                      scale_modifier=1.0):
-    """Runs the fused forward through the C ABI and returns outputs + every saved sub-array as numpy."""
+                      scale_modifier=1.0, cull=False):
+    """Runs the fused forward through the C ABI and returns outputs + every saved sub-array as numpy.  cull=False
+    (default) keeps the reference's duplicate lists so that keys / point_list / ranges compare bit for bit; with
+    cull=True the low key word is the duplicate's emission index instead of the depth bits."""
+    with tile_cull(cull):
+        return _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_precomp, scale_modifier)
+
+
+def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_precomp, scale_modifier):
     import torch
     from deblurgs_amd import _lib
     from deblurgs_amd import diff_gaussian_rasterization as dgr
@@ -117,6 +139,8 @@ def hip_forward_state(scene, K, sh_degree=None, use_sigmoid=False, colors_precom
         pre_sigmoid=view(geom, L.pre_sigmoid, K * P * 12, np.float32, (K, P, 3)),
         tiles_touched=view(geom, L.tiles_touched, K * P * 4, np.uint32, (K, P)),
         point_offsets=view(geom, L.point_offsets, K * P * 4, np.uint32, (K, P)),
+        tt_tight=view(geom, L.tt_tight, K * P * 4, np.uint32, (K * P,)),
+        offs_tight=view(geom, L.offs_tight, K * P * 4, np.uint32, (K * P,)),
         final_T=view(image, L.final_T, K * N * 4, np.float32, (K, N)),
         n_contrib=view(image, L.n_contrib, K * N * 4, np.uint32, (K, N)),
         ranges=view(image, L.ranges, K * T * 8, np.uint32, (K, T, 2)),

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"libdgs_hip.so does not export {s}"
     assert set(syms) == set(_lib.EXPORTS), "ctypes binding and header disagree"
-    assert L.dgs_abi_version() == 1
+    assert L.dgs_abi_version() == 2
 
 
 def test_no_torch_types_in_the_abi():
@@ -35,11 +35,11 @@ def test_no_torch_types_in_the_abi():
 
 def test_struct_sizes_match_the_header_layout():
     from deblurgs_amd import _lib
-    # 6 ints + 5 floats + 3 ints = 56 bytes, then 11 pointers, then 3 x (pointer + size_t)
-    assert ctypes.sizeof(_lib.DgsProblem) == 56 + 11 * 8 + 3 * 16
+    # 6 ints + 5 floats + 4 ints = 60 bytes (+4 padding), then 11 pointers, then 3 x (pointer + size_t)
+    assert ctypes.sizeof(_lib.DgsProblem) == 64 + 11 * 8 + 3 * 16
     assert ctypes.sizeof(_lib.DgsForwardOut) == 32
     assert ctypes.sizeof(_lib.DgsBackwardIO) == 8 + 8 * 3 + 16 + 10 * 8
-    assert ctypes.sizeof(_lib.DgsLayout) == 25 * 8 + 8
+    assert ctypes.sizeof(_lib.DgsLayout) == 27 * 8 + 8
 
 
 def test_size_queries_and_layout():

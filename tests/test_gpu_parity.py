@@ -6,7 +6,7 @@ scale is arbitrary)."""
 import numpy as np
 import pytest
 
-from helpers import (hip_forward_backward, hip_forward_state, oracle_forward, oracle_forward_backward, relerr,
+from helpers import (tile_cull, hip_forward_backward, hip_forward_state, oracle_forward, oracle_forward_backward, relerr,
                      synthetic, unstable_pixels)
 
 pytestmark = pytest.mark.gpu
@@ -231,6 +231,74 @@ def test_variants(gpu, variant):
 
 
 # ------------------------------------------------------------------------------------------------ edge cases
+# ------------------------------------------------------------------------------------------------ tile culling
+def _pair_can_contribute(sc, st, margin):
+    """For every duplicate of the rectangle lists: does alpha reach margin/255 (with power <= 0) at some in-image
+    pixel of its tile?  float64 restatement of forward.cu:346-358."""
+    W, H, T = sc["W"], sc["H"], st["T"]
+    gx = (W + 15) // 16
+    kt = (st["keys"] >> np.uint64(32)).astype(np.int64)
+    k, tile = kt // T, kt % T
+    rows = st["rows"][k, st["point_list"].astype(np.int64)].astype(np.float64)
+    x, y, a, b, c, op = (rows[:, i][:, None] for i in range(6))
+    lx, ly = np.meshgrid(np.arange(16), np.arange(16))
+    px = (tile % gx)[:, None] * 16 + lx.reshape(1, -1)
+    py = (tile // gx)[:, None] * 16 + ly.reshape(1, -1)
+    dx, dy = x - px, y - py
+    power = -0.5 * (a * dx * dx + c * dy * dy) - b * dx * dy
+    alpha = op * np.exp(np.minimum(power, 0.0))
+    ok = (power <= 0) & (alpha >= margin / 255.0) & (px < W) & (py < H)
+    return ok.any(axis=1)
+
+
+@pytest.mark.parametrize("seed,sigma", [(0, None), (31, 9.0)])
+def test_tile_cull_lists_are_the_contributing_subset(gpu, seed, sigma):
+    """tile_cull drops only duplicates that the reference skips at every pixel (forward.cu:356-358) and keeps the
+    surviving ones in the reference's order; images, radii and per-pixel transmittance do not change by one bit."""
+    kw = {} if sigma is None else dict(sigma_px=sigma)
+    sc = small_scene(seed=seed, **kw)
+    K, P = sc["K"], sc["P"]
+    ref = hip_forward_state(sc, K, cull=False)
+    cul = hip_forward_state(sc, K, cull=True)
+    for key in ["color", "depth", "radii", "final_T", "tiles_touched"]:
+        assert np.array_equal(ref[key].view(np.uint32), cul[key].view(np.uint32)), key
+    rid = (ref["keys"] >> np.uint64(32)).astype(np.int64) * P + ref["point_list"]
+    cid = (cul["keys"] >> np.uint64(32)).astype(np.int64) * P + cul["point_list"]
+    assert np.unique(rid).size == rid.size
+    kept = np.isin(rid, cid)
+    assert np.array_equal(rid[kept], cid), "surviving duplicates keep the reference's (tile, depth) order"
+    assert 0.3 < cul["R"] / ref["R"] < 0.9
+    # nothing that clearly contributes was dropped, and (almost) nothing that clearly cannot was kept
+    assert not np.any(_pair_can_contribute(sc, ref, 1.001) & ~kept), "dropped a contributing duplicate"
+    cannot = ~_pair_can_contribute(sc, ref, 0.5)
+    assert (cannot & kept).sum() <= 0.35 * kept.sum()     # the tile test is exact; 0.5/255 leaves a thin shell
+    # the low key word is the duplicate's emission index: a permutation of [0, R), segment by segment
+    u = (cul["keys"] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert np.array_equal(np.sort(u), np.arange(cul["R"]))
+    flat = cul["rows_u32"].reshape(-1, 12)
+    gi = (cul["keys"] >> np.uint64(32)).astype(np.int64) // cul["T"] * P + cul["point_list"]
+    doff = flat[gi, 10].astype(np.int64)
+    cnt = np.bincount(gi, minlength=K * P)
+    assert np.all((u >= doff) & (u < doff + cnt[gi])), "contribution-row slot inside the pair's segment"
+    vis = cul["tiles_touched"].reshape(-1) > 0
+    assert np.all(flat[vis & (cnt == 0), 10] == 0xFFFFFFFF)
+    rng = cul["ranges"].reshape(-1, 2).astype(np.int64)
+    assert np.array_equal(rng[:, 1] - rng[:, 0], np.bincount((cul["keys"] >> np.uint64(32)).astype(np.int64),
+                                                             minlength=rng.shape[0]))
+
+
+@pytest.mark.parametrize("depth", [False, True])
+def test_tile_cull_gradients_bitwise_equal(gpu, depth):
+    sc = small_scene()
+    gC, gD = _grads(sc, sc["K"], depth=depth)
+    with tile_cull(False):
+        a = hip_forward_backward(sc, sc["K"], gC, gD)
+    with tile_cull(True):
+        b = hip_forward_backward(sc, sc["K"], gC, gD)
+    for key in GRAD_KEYS:
+        assert np.array_equal(a[key], b[key]), key
+
+
 def test_ragged_image_and_empty_tiles(gpu):
     """W, H not multiples of 16 (partial tiles, partial quadrants) and many empty tiles."""
     sc = small_scene(P=300, W=75, H=41, K=2, seed=7)
