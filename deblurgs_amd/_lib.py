@@ -60,6 +60,18 @@ class DgsLayout(ctypes.Structure):
         ("sort_bits", ctypes.c_int32), ("sort_passes", ctypes.c_int32)]
 
 
+class DgsAdamGroup(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("numel", ctypes.c_uint64), ("lr", ctypes.c_double),
+                ("step", ctypes.c_int32)]
+
+
+class DgsCloudArrays(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p * 6), ("exp_avg", ctypes.c_void_p * 6), ("exp_avg_sq", ctypes.c_void_p * 6)]
+
+
+ADAM_MAX_GROUPS = 8
+
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {
     "dgs_abi_version": (ctypes.c_int, []),
@@ -89,6 +101,14 @@ EXPORTS = {
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dgs_densify_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "dgs_adam_step": (ctypes.c_int, [ctypes.POINTER(DgsAdamGroup), ctypes.c_int32, ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),
+    "dgs_densify_tmp_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
+    "dgs_densify_plan": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_float] * 4 +
+                         [ctypes.c_void_p] * 6),
+    "dgs_densify_apply": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 3 +
+                          [ctypes.POINTER(DgsCloudArrays), ctypes.POINTER(DgsCloudArrays), ctypes.c_void_p,
+                           ctypes.c_float, ctypes.c_void_p]),
     "dgs_pose_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dgs_pose_forward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 4),
     "dgs_pose_backward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32]

@@ -20,6 +20,8 @@ SOURCES = {
     "composite.hip": ["-fno-slp-vectorize"],
     "geometry_bwd.hip": [],
     "pose.hip": [],
+    # Adam / densification restate torch elementwise ops one rounding per statement
+    "optim.hip": ["-ffp-contract=off"],
     "api.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fhip-fp32-correctly-rounded-divide-sqrt",

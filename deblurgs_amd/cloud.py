@@ -1,8 +1,11 @@
 """Parameter container exposing exactly the getters the rasteriser adapter reads from the reference's
 GaussianModel (scene/gaussian_model.py:114-137) with the reference's activations
 (scene/gaussian_activation.py:29-52, scene/gaussian_model.py:36-50): opacity clamp(0,1), scale exp(x)+lb,
-rotation F.normalize, SH = cat(dc, rest).  The optimiser / densifier around it are out of scope.
+rotation F.normalize, SH = cat(dc, rest), plus the training-side methods of GaussianModel that follow the hot path
+in an iteration: training_setup / update_learning_rate (:170-204), densify_and_prune (:436-448),
+prune_points (:336-349), reset_opacity (:247-253), backed by the fused kernels of deblurgs_amd.optim.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -24,7 +27,7 @@ class LowerBoundExponent(nn.Module):
 
 class GaussianCloud(nn.Module):
     def __init__(self, xyz, features_dc, features_rest, scaling, rotation, opacity, sh_degree=2, active_sh_degree=None,
-                 z_near=0.2, z_far=100.0, use_sigmoid=False, scale_lb=0.0):
+                 z_near=0.2, z_far=100.0, use_sigmoid=False, scale_lb=0.0, alpha_lower_bound=0.0):
         super().__init__()
         self.max_sh_degree = sh_degree
         self.active_sh_degree = sh_degree if active_sh_degree is None else active_sh_degree
@@ -38,6 +41,14 @@ class GaussianCloud(nn.Module):
         self._rotation = nn.Parameter(rotation)
         self._opacity = nn.Parameter(opacity)              # identity-with-clamp activation
         self.scaling_activation = LowerBoundExponent(scale_lb)
+        self.scale_lower_bound = scale_lb
+        self.alpha_lower_bound = alpha_lower_bound
+        self.optimizer = None
+        self.percent_dense = 0.0
+        self.spatial_lr_scale = 1.0
+        self.max_radii2D = torch.empty(0)
+        self.xyz_gradient_accum = torch.empty(0)
+        self.denom = torch.empty(0)
         self.opacity_activation = Clamp()
         self.rotation_activation = F.normalize
 
@@ -77,3 +88,160 @@ class GaussianCloud(nn.Module):
     def hot_parameters(self):
         """The per-Gaussian tensors whose gradients the sharded loop all-reduces."""
         return [self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation]
+
+    # ------------------------------------------------------------------ training side (SURVEY 8f, f3)
+    def _named(self):
+        return dict(zip(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"), self.hot_parameters()))
+
+    def _set_named(self, tensors):
+        (self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling,
+         self._rotation) = (tensors[n] for n in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"))
+
+    def training_setup(self, training_args, spatial_lr_scale=1.0, fused=True):
+        """scene/gaussian_model.py:170-195.  training_args needs percent_dense, position_lr_init/final, feature_lr,
+        opacity_lr, scaling_lr, rotation_lr, iterations (and optionally clip_grad)."""
+        from .optim import FusedAdam
+        self.spatial_lr_scale = spatial_lr_scale
+        self.percent_dense = training_args.percent_dense
+        dev = self._xyz.device
+        P = self._xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
+        self.denom = torch.zeros((P, 1), device=dev)
+        self.max_radii2D = torch.zeros((P,), device=dev)
+        a = training_args
+        l = [
+            {'params': [self._xyz], 'lr': a.position_lr_init * self.spatial_lr_scale, "name": "xyz"},
+            {'params': [self._features_dc], 'lr': a.feature_lr, "name": "f_dc"},
+            {'params': [self._features_rest], 'lr': a.feature_lr / 20.0, "name": "f_rest"},
+            {'params': [self._opacity], 'lr': a.opacity_lr, "name": "opacity"},
+            {'params': [self._scaling], 'lr': a.scaling_lr, "name": "scaling"},
+            {'params': [self._rotation], 'lr': a.rotation_lr, "name": "rotation"},
+        ]
+        if fused:
+            self.optimizer = FusedAdam(l, lr=0.0, eps=1e-15, clip_value=getattr(a, "clip_grad", 0.0))
+        else:
+            self.optimizer = torch.optim.Adam(l, lr=0.0, eps=1e-15)
+        self.xyz_scheduler_args = get_expon_lr_func(lr_init=a.position_lr_init * self.spatial_lr_scale,
+                                                    lr_final=a.position_lr_final * self.spatial_lr_scale,
+                                                    max_steps=a.iterations)
+
+    def update_learning_rate(self, iteration):
+        for group in self.optimizer.param_groups:
+            if group["name"] == "xyz":
+                group["lr"] = self.xyz_scheduler_args(iteration)
+
+    def _moments(self):
+        m, v, steps = [], [], []
+        named = self._named()
+        for n, p in named.items():
+            st = self.optimizer.state.get(p, None) if self.optimizer is not None else None
+            st = st if st else None
+            m.append(None if st is None else st["exp_avg"])
+            v.append(None if st is None else st["exp_avg_sq"])
+            steps.append(st)
+        return m, v, steps
+
+    def _install(self, new_p, new_m, new_v, old_states):
+        """Swap the parameters (and their optimiser state) for new tensors, as _prune_optimizer /
+        cat_tensors_to_optimizer do (:315-334, :359-387): the state dict object, hence `step`, is kept."""
+        names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+        old = self._named()
+        tensors = {}
+        for i, n in enumerate(names):
+            tensors[n] = nn.Parameter(new_p[i].requires_grad_(True))
+        if self.optimizer is not None:
+            for group in self.optimizer.param_groups:
+                n = group.get("name")
+                if n not in tensors:
+                    continue
+                i = names.index(n)
+                st = old_states[i]
+                if old[n] in self.optimizer.state:
+                    del self.optimizer.state[old[n]]
+                group["params"][0] = tensors[n]
+                if st is not None:
+                    st["exp_avg"], st["exp_avg_sq"] = new_m[i], new_v[i]
+                    self.optimizer.state[tensors[n]] = st
+        self._set_named(tensors)
+
+    @torch.no_grad()
+    def densify_and_prune(self, max_grad, extent, noise=None):
+        """scene/gaussian_model.py:436-448 in three kernels + four scans.  `noise` ([2 m, 3] standard normals for
+        the m split-selected Gaussians x 2 copies) is drawn here when absent (the reference's torch.normal)."""
+        from . import optim
+        min_opacity = self.alpha_lower_bound + (1 - self.alpha_lower_bound) * 0.005
+        counts, flags, offs = optim.densify_plan(self.xyz_gradient_accum, self.denom, self._scaling.detach(),
+                                                 self._opacity.detach(), max_grad, self.percent_dense * extent,
+                                                 min_opacity, self.scale_lower_bound)
+        if noise is None:
+            noise = torch.randn((2 * counts[3], 3), device=self._xyz.device)
+        m, v, states = self._moments()
+        params = [p.detach().contiguous() for p in self.hot_parameters()]
+        new_p, new_m, new_v = optim.densify_apply(counts, flags, offs, params, m, v, noise, self.scale_lower_bound)
+        self._install(new_p, new_m, new_v, states)
+        dev = self._xyz.device
+        Pn = self._xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((Pn, 1), device=dev)
+        self.denom = torch.zeros((Pn, 1), device=dev)
+        self.max_radii2D = torch.zeros((Pn,), device=dev)
+        return counts
+
+    @torch.no_grad()
+    def prune_points(self, mask):
+        """scene/gaussian_model.py:336-349 (plain torch indexing: used outside the training loop)."""
+        valid = ~mask
+        m, v, states = self._moments()
+        new_p = [p.detach()[valid].contiguous() for p in self.hot_parameters()]
+        new_m = [None if t is None else t[valid].contiguous() for t in m]
+        new_v = [None if t is None else t[valid].contiguous() for t in v]
+        self._install(new_p, new_m, new_v, states)
+        self.xyz_gradient_accum = self.xyz_gradient_accum[valid]
+        self.denom = self.denom[valid]
+        self.max_radii2D = self.max_radii2D[valid]
+
+    @torch.no_grad()
+    def reset_opacity(self, new_opacity=None):
+        """scene/gaussian_model.py:247-253 + replace_tensor_to_optimizer (:301-313): moments are zeroed."""
+        if new_opacity is None:
+            lb = self.alpha_lower_bound
+            new_opacity = lb + (1 - lb) * float(self.opacity_activation(torch.ones(1) * 0.1))
+        opacities_new = torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * new_opacity).clamp(0.0, 1.0)
+        old = self._opacity
+        new = nn.Parameter(opacities_new.detach().clone().requires_grad_(True))
+        if self.optimizer is not None:
+            for group in self.optimizer.param_groups:
+                if group.get("name") == "opacity":
+                    st = self.optimizer.state.get(old, None)
+                    if old in self.optimizer.state:
+                        del self.optimizer.state[old]
+                    group["params"][0] = new
+                    if st:
+                        st["exp_avg"] = torch.zeros_like(new)
+                        st["exp_avg_sq"] = torch.zeros_like(new)
+                        self.optimizer.state[new] = st
+        self._opacity = new
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, max_steps=1000000):
+    """utils/general_utils.py:31-71 (the fork's variant: clamps outside [0, max_steps], constant when
+    lr_init <= lr_final, log-linear interpolation otherwise).  Also drives the densification-threshold annealing
+    (train.py:79-81,110)."""
+    state = dict(lr_final=lr_final)
+
+    def helper(step):
+        s = step - lr_delay_steps
+        ms = max_steps - lr_delay_steps
+        if s < 0:
+            return lr_init
+        if s > ms:
+            return state["lr_final"]
+        if lr_init <= 0.0:
+            return 0.0
+        if lr_init <= state["lr_final"]:
+            return lr_init
+        if state["lr_final"] <= 0.0:
+            state["lr_final"] = 1e-6
+        t = np.clip(s / ms, 0, 1)
+        return float(np.exp(np.log(lr_init) * (1 - t) + np.log(state["lr_final"]) * t))
+
+    return helper

@@ -310,6 +310,10 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
   return hipGetLastError();
 }
 
+// error reporting for the other translation units of the library (optim.hip)
+int dgs_fail_arg(const char* msg) { return fail(DGS_E_ARG, "%s", msg); }
+int dgs_fail_hip(hipError_t e, const char* where) { return fail_hip(e, where); }
+
 extern "C" {
 
 int dgs_abi_version(void) { return DGS_ABI_VERSION; }

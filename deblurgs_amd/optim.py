@@ -1,0 +1,129 @@
+"""Optimiser step and densification of the Gaussian cloud on device.
+
+`FusedAdam` is a torch.optim.Optimizer with torch.optim.Adam's state layout (state[p] = {"step", "exp_avg",
+"exp_avg_sq"}, one parameter per named group as the reference builds them, scene/gaussian_model.py:182-193), so
+the reference's optimiser surgery (replace_tensor_to_optimizer / _prune_optimizer / cat_tensors_to_optimizer,
+scene/gaussian_model.py:301-387) keeps working on it; step() updates every group with ONE kernel
+(dgs_adam_step) instead of ~10 elementwise launches per tensor.
+
+`densify_and_prune` restates GaussianModel.densify_and_prune (scene/gaussian_model.py:436-448) as plan + apply
+over the whole cloud and both Adam moments (dgs_densify_plan / dgs_densify_apply).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+FIELDS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")   # group names of the reference
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clip_value=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.clip_value = float(clip_value)   # > 0: fused torch.nn.utils.clip_grad_value_ (train.py:204-205)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        batches = {}
+        keep = []
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("FusedAdam needs contiguous float32 HIP tensors (no CPU fallback)")
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = torch.tensor(0.0)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                keep.append(grad)
+                g = _lib.DgsAdamGroup(p.data_ptr(), grad.data_ptr(), state["exp_avg"].data_ptr(),
+                                      state["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]),
+                                      int(state["step"].item()))
+                batches.setdefault((p.device, float(beta1), float(beta2), float(group["eps"])), []).append(g)
+        L = _lib.lib()
+        for (device, beta1, beta2, eps), gs in batches.items():
+            for i in range(0, len(gs), _lib.ADAM_MAX_GROUPS):
+                chunk = gs[i:i + _lib.ADAM_MAX_GROUPS]
+                arr = (_lib.DgsAdamGroup * len(chunk))(*chunk)
+                _lib.check(L.dgs_adam_step(arr, len(chunk), beta1, beta2, eps, self.clip_value, _stream(device)),
+                           "dgs_adam_step")
+        return loss
+
+
+_pinned_counts = {}
+
+
+def _counts_buffer(device):
+    key = (device.type, device.index)
+    if key not in _pinned_counts:
+        _pinned_counts[key] = torch.zeros(4, dtype=torch.int32).pin_memory()
+    return _pinned_counts[key]
+
+
+@torch.no_grad()
+def densify_plan(xyz_gradient_accum, denom, scaling, opacity, grad_threshold, size_threshold, min_opacity, scale_lb):
+    """Returns (counts [n_keep, n_clone, n_split, m_all], flags u32 [4,P], offsets u32 [4,P])."""
+    device = scaling.device
+    P = scaling.shape[0]
+    L = _lib.lib()
+    flags = torch.empty((4, P), dtype=torch.int32, device=device)
+    offs = torch.empty((4, P), dtype=torch.int32, device=device)
+    counts_dev = torch.empty(8, dtype=torch.int32, device=device)
+    tmp = torch.empty(L.dgs_densify_tmp_bytes(P), dtype=torch.uint8, device=device)
+    host = _counts_buffer(device)
+    c = lambda t: t.contiguous().float()
+    acc, den, sc, op = c(xyz_gradient_accum), c(denom), c(scaling), c(opacity)
+    _lib.check(L.dgs_densify_plan(P, acc.data_ptr(), den.data_ptr(), sc.data_ptr(), op.data_ptr(),
+                                  float(grad_threshold), float(size_threshold), float(min_opacity), float(scale_lb),
+                                  flags.data_ptr(), offs.data_ptr(), counts_dev.data_ptr(), host.data_ptr(),
+                                  tmp.data_ptr(), _stream(device)), "dgs_densify_plan")
+    torch.cuda.current_stream(device).synchronize()
+    return [int(x) & 0xFFFFFFFF for x in host.tolist()], flags, offs
+
+
+@torch.no_grad()
+def densify_apply(counts, flags, offs, params, exp_avgs, exp_avg_sqs, noise, scale_lb):
+    """params: the six raw tensors in FIELDS order; exp_avgs / exp_avg_sqs: their moments (None = no state).
+    Returns (new_params, new_exp_avgs, new_exp_avg_sqs) with n_keep + n_clone + 2 n_split rows."""
+    device = params[0].device
+    P = params[0].shape[0]
+    n_keep, n_clone, n_split, m_all = counts
+    Pn = n_keep + n_clone + 2 * n_split
+    n_rest = params[2][0].numel() if P > 0 else 0
+    src, dst = _lib.DgsCloudArrays(), _lib.DgsCloudArrays()
+    new_p, new_m, new_v, keep = [], [], [], []
+    for f, p in enumerate(params):
+        assert p.is_contiguous() and p.dtype == torch.float32 and p.shape[0] == P
+        shape = (Pn,) + tuple(p.shape[1:])
+        np_, nm, nv = (torch.empty(shape, dtype=torch.float32, device=device) for _ in range(3))
+        new_p.append(np_); new_m.append(nm); new_v.append(nv)
+        m = None if exp_avgs[f] is None else exp_avgs[f].contiguous()
+        v = None if exp_avg_sqs[f] is None else exp_avg_sqs[f].contiguous()
+        keep += [m, v]
+        src.param[f] = p.data_ptr()
+        src.exp_avg[f] = None if m is None else m.data_ptr()
+        src.exp_avg_sq[f] = None if v is None else v.data_ptr()
+        dst.param[f], dst.exp_avg[f], dst.exp_avg_sq[f] = np_.data_ptr(), nm.data_ptr(), nv.data_ptr()
+    if noise is not None:
+        noise = noise.contiguous().float()
+        assert noise.shape == (2 * m_all, 3)
+    carr = (ctypes.c_uint32 * 4)(*counts)
+    _lib.check(_lib.lib().dgs_densify_apply(P, n_rest, ctypes.cast(carr, ctypes.c_void_p), flags.data_ptr(),
+                                            offs.data_ptr(), ctypes.byref(src), ctypes.byref(dst),
+                                            None if noise is None else noise.data_ptr(), float(scale_lb),
+                                            _stream(device)), "dgs_densify_apply")
+    return new_p, new_m, new_v

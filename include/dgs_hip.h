@@ -196,6 +196,56 @@ int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32
 int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t P, float* max_radii2D,
                       float* xyz_gradient_accum, float* denom, dgs_stream_t stream);
 
+/* ---- optimiser step and densification of the Gaussian cloud ----------------------------------
+ * Multi-tensor Adam: all parameter groups in one launch.  Replaces torch.optim.Adam(l, lr=0.0, eps=1e-15).step()
+ * over the six per-Gaussian groups (scene/gaussian_model.py:170-195, train.py:203-208) with the same arithmetic
+ * (torch/optim/adam.py, single-tensor path: lerp, mul+addcmul, sqrt/div/add, addcdiv; bias corrections in double).
+ * `step` is the 1-based count of THIS update (state["step"] after its increment).  A group whose grad is NULL is
+ * skipped, like a parameter whose .grad is None.  clip_value > 0 clamps the gradient first
+ * (torch.nn.utils.clip_grad_value_, train.py:204-205); the gradient buffer itself is left untouched. */
+#define DGS_ADAM_MAX_GROUPS 8
+typedef struct DgsAdamGroup {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  uint64_t numel;
+  double lr;      /* python floats stay double up to the point where torch casts them (step_size, 1 - beta) */
+  int32_t step;
+} DgsAdamGroup;
+int dgs_adam_step(const DgsAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps,
+                  double clip_value, dgs_stream_t stream);
+
+/* densify_and_prune (scene/gaussian_model.py:436-448 = densify_and_clone :419-434, densify_and_split :389-417,
+ * prune_points :336-349 with the optimiser-state surgery of :315-334 / :359-387) as plan + apply.
+ * Arrays of the cloud, in the order xyz[P,3], f_dc[P,3], f_rest[P,n_rest], opacity[P,1], scaling[P,3],
+ * rotation[P,4] (raw parameters), with the two Adam moments of each (exp_avg / exp_avg_sq may be NULL in the
+ * source = no optimiser state yet = zeros). */
+typedef struct DgsCloudArrays {
+  float* param[6];
+  float* exp_avg[6];
+  float* exp_avg_sq[6];
+} DgsCloudArrays;
+size_t dgs_densify_tmp_bytes(int32_t P);
+/* plan: per Gaussian, grads = xyz_gradient_accum / denom (NaN -> 0); clone if |grads| >= grad_threshold and
+ * max(exp(scaling)+scale_lb) <= size_threshold (= percent_dense * extent); split if grads >= grad_threshold and
+ * max(...) > size_threshold; every Gaussian whose clamp(opacity, 0, 1) < min_opacity is pruned together with its
+ * clone / children (they inherit its opacity).  flags and offsets are u32 [4,P] (keep, clone, split, split-selected
+ * before the opacity prune) and their exclusive scans; counts_host (pinned, u32[4]) receives the four totals by an
+ * async copy: {n_keep, n_clone, n_split, m_all}.  The new cloud has n_keep + n_clone + 2 n_split Gaussians. */
+int dgs_densify_plan(int32_t P, const float* xyz_gradient_accum, const float* denom, const float* scaling,
+                     const float* opacity, float grad_threshold, float size_threshold, float min_opacity,
+                     float scale_lb, uint32_t* flags, uint32_t* offsets, uint32_t* counts_dev, uint32_t* counts_host,
+                     void* tmp, dgs_stream_t stream);
+/* apply: writes the new cloud in the reference's order [surviving originals | clones | children copy 0 | children
+ * copy 1]; clones and children get zero Adam moments; a child is xyz + R(rotation) (std * z), scaling
+ * log(max(std / 1.6 - scale_lb, 0.001)) with std = exp(scaling) + scale_lb, and z = noise[c * m_all + rank] the
+ * caller's standard-normal samples [2 m_all, 3] (the reference draws torch.normal(0, stds) for every selected
+ * Gaussian and copy before the opacity prune).  counts = the host copy {n_keep, n_clone, n_split, m_all}. */
+int dgs_densify_apply(int32_t P, int32_t n_rest, const uint32_t* counts, const uint32_t* flags, const uint32_t* offsets,
+                      const DgsCloudArrays* src, const DgsCloudArrays* dst, const float* noise, float scale_lb,
+                      dgs_stream_t stream);
+
 /* Pose path of the blur-integration loop on device: Bezier curves in se(3) evaluated at the K
  * subframe times nu, se3_exp_map, and the three camera tensors render() reads -- scene/bezier.py:54-83,
  * utils/pytorch3d_functions.py:373-457, scene/motion.py:248-294, scene/cameras.py:63-74 -- as one kernel, and its

@@ -1,0 +1,158 @@
+"""GPU parity of the training-side step that follows the hot path: fused multi-tensor Adam
+against torch.optim.Adam on the same device, fused densify_and_prune against the vectors the reference's own
+GaussianModel produced (tests/golden/densify_golden.npz) and against the numpy oracle at a larger size."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+from oracle import train_oracle as to
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "densify_golden.npz"))
+ADAM_RTOL = 2e-6   # float32 statement-by-statement restatement; torch's kernels may contract differently
+
+
+def _targs(**kw):
+    d = dict(iterations=150_000, position_lr_init=0.00016, position_lr_final=0.0000016, feature_lr=0.0025,
+             opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, percent_dense=0.01)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def _cloud_from(arrs, scale_lb=0.0, alpha_lb=0.0):
+    import torch
+    from deblurgs_amd.cloud import GaussianCloud
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    return GaussianCloud(t(arrs["xyz"]), t(arrs["f_dc"]), t(arrs["f_rest"]), t(arrs["scaling"]), t(arrs["rotation"]),
+                         t(arrs["opacity"]), sh_degree=2, scale_lb=scale_lb, alpha_lower_bound=alpha_lb)
+
+
+@pytest.mark.parametrize("clip", [0.0, 0.004])
+def test_fused_adam_matches_torch_adam(gpu, clip):
+    import torch
+    from deblurgs_amd.optim import FusedAdam
+    rng = np.random.default_rng(3)
+    shapes = dict(xyz=(1003, 3), f_dc=(1003, 1, 3), f_rest=(1003, 8, 3), opacity=(1003, 1), scaling=(1003, 3),
+                  rotation=(1003, 4), odd=(4097,), one=(1,), curve=(10, 3))     # > DGS_ADAM_MAX_GROUPS tensors
+    lrs = {n: 10.0 ** rng.uniform(-4, -1) for n in shapes}
+    init = {n: rng.normal(0, 1, s).astype(np.float32) for n, s in shapes.items()}
+    mk = lambda: {n: torch.nn.Parameter(torch.tensor(a, device="cuda")) for n, a in init.items()}
+    pa, pb = mk(), mk()
+    groups = lambda ps: [{"params": [p], "lr": lrs[n], "name": n} for n, p in ps.items()]
+    ref = torch.optim.Adam(groups(pa), lr=0.0, eps=1e-15)
+    fus = FusedAdam(groups(pb), lr=0.0, eps=1e-15, clip_value=clip)
+    for it in range(6):
+        for n in shapes:
+            g = torch.tensor(rng.normal(0, 1e-2, shapes[n]).astype(np.float32), device="cuda")
+            if n == "opacity" and it == 2:
+                g.zero_()
+            skip = (n == "curve" and it < 2)           # a parameter without gradient is left alone (and its step)
+            pa[n].grad = None if skip else g.clone()
+            pb[n].grad = None if skip else g.clone()
+        if it == 3:                                    # the xyz learning rate follows a schedule
+            for o in (ref, fus):
+                o.param_groups[0]["lr"] *= 0.37
+        if clip > 0:
+            torch.nn.utils.clip_grad_value_([p for p in pa.values() if p.grad is not None], clip)
+        ref.step()
+        fus.step()
+    for n in shapes:
+        a, b = pa[n].detach().cpu().numpy(), pb[n].detach().cpu().numpy()
+        assert np.allclose(a, b, rtol=ADAM_RTOL, atol=1e-7), n
+        sa, sb = ref.state[pa[n]], fus.state[pb[n]]
+        assert float(sa["step"]) == float(sb["step"])
+        assert np.allclose(sa["exp_avg"].cpu().numpy(), sb["exp_avg"].cpu().numpy(), rtol=ADAM_RTOL, atol=3e-9), n
+        assert np.allclose(sa["exp_avg_sq"].cpu().numpy(), sb["exp_avg_sq"].cpu().numpy(), rtol=ADAM_RTOL, atol=1e-12), n
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_training_side_against_reference_model_vectors(gpu, case):
+    """training_setup -> 3 fused Adam steps -> densify_and_prune -> reset_opacity, every stage against what the
+    reference's GaussianModel produced from the same inputs, gradients and normal draws."""
+    import torch
+    scale_lb, alpha_lb, max_grad, extent, pd, lr_scale = G[f"{case}_cfg"]
+    cloud = _cloud_from({n: G[f"{case}_in_{n}"] for n in to.FIELDS}, scale_lb, alpha_lb)
+    cloud.training_setup(_targs(percent_dense=pd), spatial_lr_scale=lr_scale)
+    for it in range(3):
+        for n, p in cloud._named().items():
+            p.grad = torch.tensor(G[f"{case}_grad{it}_{n}"], device="cuda")
+        cloud.optimizer.step()
+        cloud.optimizer.zero_grad(set_to_none=True)
+    for n, p in cloud._named().items():
+        assert np.allclose(p.detach().cpu().numpy(), G[f"{case}_adam_{n}"], rtol=ADAM_RTOL, atol=1e-7), n
+        st = cloud.optimizer.state[p]
+        assert np.allclose(st["exp_avg"].cpu().numpy(), G[f"{case}_adam_m_{n}"], rtol=ADAM_RTOL, atol=3e-9), n
+    # continue from the reference's own post-Adam state so that the densification comparison can be exact
+    for n, p in cloud._named().items():
+        p.data.copy_(torch.tensor(G[f"{case}_adam_{n}"]))
+        cloud.optimizer.state[p]["exp_avg"].copy_(torch.tensor(G[f"{case}_adam_m_{n}"]))
+        cloud.optimizer.state[p]["exp_avg_sq"].copy_(torch.tensor(G[f"{case}_adam_v_{n}"]))
+    cloud.xyz_gradient_accum = torch.tensor(G[f"{case}_accum"], device="cuda")
+    cloud.denom = torch.tensor(G[f"{case}_denom"], device="cuda")
+    counts = cloud.densify_and_prune(max_grad, extent, noise=torch.tensor(G[f"{case}_noise"], device="cuda"))
+    assert 2 * counts[3] == G[f"{case}_noise"].shape[0]
+    n_copy = counts[0] + counts[1]
+    for n, p in cloud._named().items():
+        ref = G[f"{case}_out_{n}"]
+        out = p.detach().cpu().numpy()
+        assert out.shape == ref.shape, n
+        assert np.array_equal(out[:n_copy], ref[:n_copy]), n          # survivors and clones are copies
+        if n in ("xyz", "scaling"):
+            assert np.allclose(out[n_copy:], ref[n_copy:], rtol=2e-6, atol=2e-6), n
+        else:
+            assert np.array_equal(out[n_copy:], ref[n_copy:]), n
+        st = cloud.optimizer.state[p]
+        assert float(st["step"]) == float(G[f"{case}_step_after"])
+        assert np.array_equal(st["exp_avg"].cpu().numpy(), G[f"{case}_out_m_{n}"]), n
+        assert np.array_equal(st["exp_avg_sq"].cpu().numpy(), G[f"{case}_out_v_{n}"]), n
+        assert cloud.optimizer.param_groups[to.FIELDS.index(n)]["params"][0] is p
+    Pn = cloud._xyz.shape[0]
+    assert cloud.xyz_gradient_accum.shape == (Pn, 1) and not cloud.xyz_gradient_accum.any()
+    assert cloud.max_radii2D.shape == (Pn,)
+    cloud.reset_opacity()
+    assert np.allclose(cloud._opacity.detach().cpu().numpy(), G[f"{case}_opacity_reset"], atol=1e-7)
+    assert not cloud.optimizer.state[cloud._opacity]["exp_avg"].any()
+    # the optimiser keeps working on the new tensors
+    for p in cloud.hot_parameters():
+        p.grad = torch.ones_like(p) * 1e-3
+    cloud.optimizer.step()
+
+
+def test_densify_matches_oracle_at_scale_without_optimizer_state(gpu):
+    import torch
+    rng = np.random.default_rng(11)
+    P = 200_000
+    arrs = dict(xyz=rng.normal(0, 1, (P, 3)), f_dc=rng.normal(0, 0.3, (P, 1, 3)), f_rest=rng.normal(0, 0.1, (P, 8, 3)),
+                scaling=np.log(rng.uniform(0.002, 0.08, (P, 3))), rotation=rng.normal(0, 1, (P, 4)),
+                opacity=rng.uniform(-0.02, 0.3, (P, 1)))
+    arrs = {k: v.astype(np.float32) for k, v in arrs.items()}
+    accum = rng.uniform(0, 1e-3, (P, 1)).astype(np.float32)
+    denom = rng.integers(0, 3, (P, 1)).astype(np.float32)
+    cloud = _cloud_from(arrs, scale_lb=0.001, alpha_lb=0.02)
+    cloud.percent_dense = 0.01
+    cloud.xyz_gradient_accum = torch.tensor(accum, device="cuda")
+    cloud.denom = torch.tensor(denom, device="cuda")
+    # count the split-selected Gaussians the way the oracle will, to size the normal draws
+    with np.errstate(all="ignore"):
+        g = np.nan_to_num((accum / denom).reshape(-1), nan=0.0)
+    m_sel = int(((g >= np.float32(3e-4)) & ((np.exp(arrs["scaling"]) + np.float32(0.001)).max(1) > np.float32(0.04))).sum())
+    noise = rng.normal(0, 1, (2 * m_sel, 3)).astype(np.float32)
+    counts = cloud.densify_and_prune(3e-4, 4.0, noise=torch.tensor(noise, device="cuda"))
+    assert counts[3] == m_sel and counts[2] < m_sel            # some selected Gaussians die in the opacity prune
+    ref, _, _ = to.densify_and_prune(arrs, None, None, accum, denom, 3e-4, 4.0, 0.01, noise, 0.001, 0.02)
+    n_copy = counts[0] + counts[1]
+    for n, p in cloud._named().items():
+        out = p.detach().cpu().numpy()
+        assert out.shape == ref[n].shape, n
+        assert np.array_equal(out[:n_copy], ref[n][:n_copy]), n
+        assert np.allclose(out[n_copy:], ref[n][n_copy:], rtol=2e-6, atol=2e-6), n
+    # an empty plan is the identity
+    cloud.xyz_gradient_accum.zero_()
+    cloud.denom.fill_(1.0)
+    before = [p.detach().clone() for p in cloud.hot_parameters()]
+    c2 = cloud.densify_and_prune(3e-4, 4.0)
+    assert c2[1] == 0 and c2[2] == 0 and c2[0] == before[0].shape[0]
+    for a, b in zip(before, cloud.hot_parameters()):
+        assert torch.equal(a, b.detach())
