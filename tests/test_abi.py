@@ -28,8 +28,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_no_torch_types_in_the_abi():
+    import re
     text = open(os.path.join(ROOT, "include", "dgs_hip.h")).read()
-    assert "torch" not in text.lower().replace("pytorch", "").replace("no torch types", "")
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)     # comments cite the torch calls an entry point replaces
+    assert "torch" not in code.lower() and "tensor" not in code.lower()
     assert "#include <hip" not in text      # plain C: stream handle is a void*
 
 
