@@ -109,6 +109,9 @@ EXPORTS = {
     "dgs_densify_apply": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 3 +
                           [ctypes.POINTER(DgsCloudArrays), ctypes.POINTER(DgsCloudArrays), ctypes.c_void_p,
                            ctypes.c_float, ctypes.c_void_p]),
+    "dgs_knn_tmp_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
+    "dgs_knn_mean_dist2": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p]),
     "dgs_pose_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dgs_pose_forward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 4),
     "dgs_pose_backward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32]

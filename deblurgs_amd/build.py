@@ -20,6 +20,7 @@ SOURCES = {
     "composite.hip": ["-fno-slp-vectorize"],
     "geometry_bwd.hip": [],
     "pose.hip": [],
+    "knn.hip": [],
     # Adam / densification restate torch elementwise ops one rounding per statement
     "optim.hip": ["-ffp-contract=off"],
     "api.hip": [],

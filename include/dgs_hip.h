@@ -246,6 +246,14 @@ int dgs_densify_apply(int32_t P, int32_t n_rest, const uint32_t* counts, const u
                       const DgsCloudArrays* src, const DgsCloudArrays* dst, const float* noise, float scale_lb,
                       dgs_stream_t stream);
 
+/* ---- initialisation: mean squared distance to the 3 nearest neighbours -------------------------
+ * Replaces simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26, simple_knn.cu:138-221), which
+ * create_from_pcd uses for the initial scales (scene/gaussian_model.py:148-156): mean_dist2[i] = mean of the three
+ * smallest |p_j - p_i|^2 over j != i (exact search; duplicates count with distance 0; fewer than three neighbours
+ * leave FLT_MAX terms, i.e. +inf, like the reference).  points is [P,3] fp32, tmp >= dgs_knn_tmp_bytes(P). */
+size_t dgs_knn_tmp_bytes(int32_t P);
+int dgs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* tmp, dgs_stream_t stream);
+
 /* Pose path of the blur-integration loop on device: Bezier curves in se(3) evaluated at the K
  * subframe times nu, se3_exp_map, and the three camera tensors render() reads -- scene/bezier.py:54-83,
  * utils/pytorch3d_functions.py:373-457, scene/motion.py:248-294, scene/cameras.py:63-74 -- as one kernel, and its

@@ -1,0 +1,24 @@
+"""TEST INFRASTRUCTURE ONLY -- the definition simple-knn's distCUDA2 computes (submodules/simple-knn/
+simple_knn.cu:123-174: exact 3-nearest-neighbour search, self excluded by index, squared distances accumulated in
+fp32 as dx*dx + dy*dy + dz*dz, result (b0 + b1 + b2) / 3).  Brute force in blocks; no reference build exists for
+this path (CUDA + cub/thrust), so it is pinned by construction on small hand-checkable cases in the tests."""
+import numpy as np
+
+
+def mean_dist2(points, block=2048):
+    p = np.asarray(points, np.float32)
+    P = p.shape[0]
+    out = np.empty(P, np.float32)
+    big = np.float32(np.finfo(np.float32).max)
+    for s in range(0, P, block):
+        q = p[s:s + block]
+        d = q[:, None, :] - p[None, :, :]
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]).astype(np.float32)
+        d2[np.arange(q.shape[0]), np.arange(s, s + q.shape[0])] = big          # self, by index
+        if P < 4:
+            d2 = np.concatenate([d2, np.full((q.shape[0], 3), big, np.float32)], 1)
+        best = np.partition(d2, 2, axis=1)[:, :3]
+        best.sort(axis=1)
+        with np.errstate(over="ignore"):
+            out[s:s + block] = (best[:, 0] + best[:, 1] + best[:, 2]) / np.float32(3.0)
+    return out

@@ -156,3 +156,46 @@ def test_densify_matches_oracle_at_scale_without_optimizer_state(gpu):
     assert c2[1] == 0 and c2[2] == 0 and c2[0] == before[0].shape[0]
     for a, b in zip(before, cloud.hot_parameters()):
         assert torch.equal(a, b.detach())
+
+
+@pytest.mark.parametrize("P,kind", [(1, "normal"), (2, "normal"), (3, "normal"), (4, "normal"), (300, "normal"), (5000, "clustered"),
+                                    (70_001, "normal"), (20_000, "plane"), (4096, "duplicates")])
+def test_knn_mean_dist2_matches_definition(gpu, P, kind):
+    """simple-knn's distCUDA2: exact 3-NN mean squared distance."""
+    import torch
+    from oracle import knn_oracle
+    from deblurgs_amd.simple_knn import distCUDA2
+    rng = np.random.default_rng(P)
+    pts = rng.normal(0, 1, (P, 3)).astype(np.float32)
+    if kind == "clustered":
+        pts = (rng.normal(0, 0.01, (P, 3)) + rng.integers(-3, 4, (P, 1)) * 5.0).astype(np.float32)
+    if kind == "plane":
+        pts[:, 2] = 0.0           # a flat axis (and the Morton box still spans the origin)
+        pts[:, 0] += 10.0
+    if kind == "duplicates":
+        pts[::2] = pts[1::2]
+    out = distCUDA2(torch.tensor(pts, device="cuda")).cpu().numpy()
+    ref = knn_oracle.mean_dist2(pts)
+    assert out.shape == (P,)
+    if P == 1:
+        assert np.all(np.isinf(out)) and np.all(np.isinf(ref))     # three FLT_MAX terms overflow
+    else:
+        assert np.allclose(out, ref, rtol=1e-5, atol=1e-12)        # P == 3: one FLT_MAX term -> FLT_MAX / 3
+    if kind == "duplicates":
+        assert (out[:10] >= 0).all()
+
+
+def test_create_from_points_initialisation(gpu):
+    import torch
+    from deblurgs_amd.simple_knn import create_from_points
+    from oracle import knn_oracle
+    rng = np.random.default_rng(5)
+    pts = rng.normal(0, 1, (2000, 3)).astype(np.float32)
+    col = rng.random((2000, 3)).astype(np.float32)
+    cloud = create_from_points(pts, col, sh_degree=2)
+    d2 = np.maximum(knn_oracle.mean_dist2(pts), 1e-7)
+    assert np.allclose(cloud.get_scaling.detach().cpu().numpy(), np.sqrt(d2)[:, None].repeat(3, 1), rtol=1e-5)
+    assert cloud.active_sh_degree == 0 and cloud._features_rest.shape == (2000, 8, 3)
+    assert np.allclose(cloud._features_dc.detach().cpu().numpy()[:, 0], (col - 0.5) / 0.28209479177387814, atol=1e-6)
+    assert np.allclose(cloud.get_opacity.detach().cpu().numpy(), 0.1)
+    assert torch.equal(cloud._rotation.detach()[:, 0], torch.ones(2000, device="cuda"))
