@@ -227,10 +227,18 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     accA[q] = accB[q] = (v2f){0.0f, 0.0f};
     maxc = max(maxc, last[q]);
   }
-  // wave-wide max of n_contrib: entries at or beyond it are skipped by every pixel (backward.cu:566-568)
+  // wave-wide max of n_contrib: entries at or beyond it are skipped by every pixel (backward.cu:566-568); the same
+  // per quadrant lets a (Gaussian, quadrant) pass be dropped once all 64 pixels of that quadrant are past their last
+  // contributor
+  uint32_t maxq[4];
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, d, 64));
-  maxc = __builtin_amdgcn_readfirstlane(maxc);
+  for (int q = 0; q < 4; q++) {
+    uint32_t mq = last[q];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mq = max(mq, (uint32_t)__shfl_xor((int)mq, d, 64));
+    maxq[q] = __builtin_amdgcn_readfirstlane(mq);
+  }
+  maxc = max(max(maxq[0], maxq[1]), max(maxq[2], maxq[3]));
 
   const DgsRow* krows = rows + (size_t)t.k * v.P;
   const uint32_t n = t.r1 - t.r0;
@@ -261,7 +269,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const float ex = A.x - (qx0 + (float)((q & 1) * 8)), ey = A.y - (qy0 + (float)((q >> 1) * 8));
-        const bool hit = has && (base + lane < maxc) && cull_hit(cg, ex - 7.0f, ex, ey - 7.0f, ey);
+        const bool hit = has && (base + lane < maxq[q]) && cull_hit(cg, ex - 7.0f, ex, ey - 7.0f, ey);
         m[q] = __ballot(hit);
       }
       s_a[w][lane] = A;
