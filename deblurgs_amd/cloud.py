@@ -125,10 +125,16 @@ class GaussianCloud(nn.Module):
                                                     lr_final=a.position_lr_final * self.spatial_lr_scale,
                                                     max_steps=a.iterations)
 
-    def update_learning_rate(self, iteration):
+    def update_learning_rate(self, iteration, opt=None, alignment_lr=None):
+        """scene/gaussian_model.py:197-210: xyz follows the exponential schedule, the curve groups halve every
+        curve_lr_half_iter iterations once the curve optimisation has started, curve_alignment is set from outside."""
         for group in self.optimizer.param_groups:
             if group["name"] == "xyz":
                 group["lr"] = self.xyz_scheduler_args(iteration)
+            elif opt is not None and group["name"] in ["curve_rot", "curve_trans"] and iteration >= opt.curve_start_iter:
+                group["lr"] = group["lr"] * (0.5) ** (1 / opt.curve_lr_half_iter)
+            elif alignment_lr is not None and group["name"] == "curve_alignment":
+                group["lr"] = alignment_lr
 
     def _moments(self):
         m, v, steps = [], [], []

@@ -67,6 +67,28 @@ class CameraMotionModule:
     def link_gaussian(self, gaussians):
         self.gaussians = gaussians
 
+    def add_training_setup(self, gaussians, lr_dict):
+        """scene/motion.py:63-76: the curve parameters join the Gaussians' optimiser as the groups curve_rot,
+        curve_trans and curve_alignment (FusedAdam updates them in the same launches as the per-Gaussian groups)."""
+        opt = gaussians.optimizer
+        for group in opt.param_groups:
+            if "curve_" in group['name'] and group['params'][0] in opt.state:
+                del opt.state[group['params'][0]]
+        opt.param_groups = [e for e in opt.param_groups if 'curve_' not in e['name']]
+        opt.add_param_group({'params': list(self._rot.parameters()), 'lr': lr_dict['curve_rot'], 'name': 'curve_rot'})
+        opt.add_param_group({'params': list(self._trans.parameters()), 'lr': lr_dict['curve_trans'],
+                             'name': 'curve_trans'})
+        opt.add_param_group({'params': [self._nu], 'lr': lr_dict['curve_alignment'], 'name': 'curve_alignment'})
+
+    def is_optimizing(self):
+        return bool(self._nu.requires_grad)
+
+    def alternate_optimization(self):
+        """scene/motion.py:312-320."""
+        new_state = not self.is_optimizing()
+        for optimizable in [self._rot, self._trans, self._nu]:
+            optimizable.requires_grad_(new_state)
+
     def parameters(self):
         return list(self._rot.parameters()) + list(self._trans.parameters()) + [self._nu]
 

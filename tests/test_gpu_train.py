@@ -199,3 +199,66 @@ def test_create_from_points_initialisation(gpu):
     assert np.allclose(cloud._features_dc.detach().cpu().numpy()[:, 0], (col - 0.5) / 0.28209479177387814, atol=1e-6)
     assert np.allclose(cloud.get_opacity.detach().cpu().numpy(), 0.1)
     assert torch.equal(cloud._rotation.detach()[:, 0], torch.ones(2000, device="cuda"))
+
+
+def test_training_loop_with_densification_and_fused_adam(gpu):
+    """train.py:104-208 on the fused path (deblurgs_amd.training.TrainingLoop): schedules, single-subframe warm-up
+    before curve_start_iter, fused loss, densification statistics, densify_and_prune / reset_opacity on their
+    schedule, ONE fused Adam launch for Gaussians + trajectory.  The perturbed scene must fit its own blurry
+    render again while the cloud is being densified and pruned."""
+    import torch
+    from helpers import synthetic
+    from deblurgs_amd.cloud import GaussianCloud
+    from deblurgs_amd.motion import CameraMotionModule, RefCamera
+    from deblurgs_amd.training import TrainingLoop, default_optimization_params
+    from deblurgs_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    sc = synthetic.make_scene(4000, 160, 112, K=5, seed=21, sigma_px=3.0)
+    ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device="cuda")
+
+    def make(perturb):
+        cloud = GaussianCloud.from_scene(sc, "cuda")
+        m = CameraMotionModule(ref, torch.zeros(1, 3, sc["H"], sc["W"], device="cuda"), curve_order=3, num_subframes=5,
+                               device="cuda")
+        with torch.no_grad():
+            m._trans._control_points.copy_(torch.from_numpy(sc["ctrl_trans"])[None].cuda())
+            m._rot._control_points.copy_(torch.from_numpy(sc["ctrl_rot"])[None].cuda())
+            if perturb:
+                cloud._features_dc.add_(torch.randn_like(cloud._features_dc) * 0.3)
+                cloud._opacity.mul_(0.7)
+                cloud._xyz.add_(torch.randn_like(cloud._xyz) * 0.01)
+        m.link_gaussian(cloud)
+        return cloud, m
+
+    with torch.no_grad():
+        _, m_gt = make(False)
+        gt = m_gt.query(0, "all", background=torch.tensor([0.2, 0.3, 0.4], device="cuda"))["blurred"].clone()
+    cloud, m = make(True)
+    m.gt_images = gt[None]
+    opt = default_optimization_params(iterations=61, feature_lr=2e-2, opacity_lr=2e-2, position_lr_init=2e-4,
+                                      position_lr_final=2e-5, curve_start_iter=4, curve_controlpoints_lr=1e-4,
+                                      curve_rotation_lr=1e-4, densify_from_iter=10, densification_interval=10,
+                                      densify_until_iter=45, opacity_reset_interval=1000, densify_grad_threshold_init=2e-5,
+                                      densify_grad_threshold_final=1e-5, lambda_t_smooth_init=1e-4,
+                                      lambda_t_smooth_final=1e-4, clip_grad=0.5)
+    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0)
+    assert isinstance(cloud.optimizer, FusedAdam) and len(cloud.optimizer.param_groups) == 9
+    assert not m.is_optimizing()
+    hist, sizes = [], []
+    for it in range(1, 61):
+        # the random background of query() is part of the reference loop; fix it so that the loss history is comparable
+        torch.manual_seed(it)
+        out = loop.step(it, 0)
+        assert torch.isfinite(out["loss"]), it
+        hist.append(float(out["l1"]))
+        sizes.append(out["num_points"])
+        if it == 4:
+            assert m.is_optimizing()
+    assert len(set(sizes)) > 1, "densify_and_prune never changed the cloud"
+    P = cloud._xyz.shape[0]
+    for p in cloud.hot_parameters():
+        st = cloud.optimizer.state[p]
+        assert p.shape[0] == P and st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+    assert cloud.xyz_gradient_accum.shape == (P, 1) and cloud.max_radii2D.shape == (P,)
+    assert cloud.optimizer.state[m._nu]["step"] > 0 and cloud.optimizer.state[m._trans._control_points]["step"] > 0
+    assert min(hist[-5:]) < 0.6 * max(hist[4:9]), (hist[4:9], hist[-5:])
