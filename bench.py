@@ -5,9 +5,11 @@
 
 One "step" = one query()-equivalent of the reference's training iteration (train.py:126-165) for one blurry view:
 pose path (Bezier -> se3_exp_map -> K cameras), ONE fused K-subframe rasterisation, the fused loss-gradient
-image (L1 of the pixel-averaged blur + temporal smoothness) + opacity hinge, and the full backward to the
-per-Gaussian and trajectory gradients.  Optimiser step, densification and data loading are excluded
-(SURVEY.md 8d).  Default workload = BASELINE.json's metric configuration: 1M Gaussians, 1920x1080, K=15,
+image (L1 of the pixel-averaged blur + temporal smoothness) + opacity hinge, the full backward to the
+per-Gaussian and trajectory gradients, and the iteration's tail (train.py:188-208): densification statistics and
+ONE fused Adam launch over all parameter groups (--no-optimizer leaves the tail out; it costs ~0.3 ms of 17).
+Densification itself (every 200 iterations in the reference) and data loading are excluded.
+Default workload = BASELINE.json's metric configuration: 1M Gaussians, 1920x1080, K=15,
 curve order 3, SH degree 2.
 
 N GPUs ("views" sharding, weak scaling): every rank renders all K subframes of its own view; per-Gaussian
@@ -80,6 +82,8 @@ def main():
     ap.add_argument("--sh-degree", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lambda-t", type=float, default=1e-3)
+    ap.add_argument("--no-optimizer", action="store_true",
+                    help="time query + loss + backward (+ all-reduce) only, without densification stats and Adam")
     args = ap.parse_args()
 
     from deblurgs_amd import _lib, losses, sharding, synthetic
@@ -108,6 +112,19 @@ def main():
     params = cloud.hot_parameters()
     curve_params = motion.parameters()
     lambda_hinge = 0.1
+    # the iteration's tail (train.py:188-208): densification statistics + ONE fused Adam launch over the six
+    # per-Gaussian groups and the trajectory groups, reference learning rates (arguments/__init__.py:84-123)
+    from deblurgs_amd.densify_stats import add_densification_stats_subframes
+    from deblurgs_amd.training import default_optimization_params
+    cloud.training_setup(default_optimization_params(), spatial_lr_scale=1.0)
+    motion.add_training_setup(cloud, {"curve_rot": 1e-3, "curve_trans": 1e-2, "curve_alignment": 0.0})
+    # The ground truth is noise, so real learning rates would pull the cloud away from the configured workload within
+    # the timed region (opacities collapse and the step gets ~5 % cheaper).  The Adam kernel does the same work for
+    # any learning rate; scale the rates down so that every timed step renders the workload BASELINE.json names.
+    LR_SCALE = 1e-6
+    for group in cloud.optimizer.param_groups:
+        group["lr"] *= LR_SCALE
+    cloud.xyz_scheduler_args = lambda it: 0.00016 * LR_SCALE
 
     stats = {}
 
@@ -119,8 +136,12 @@ def main():
         if world > 1:
             sharding.flat_allreduce_grads(params, average=True)
         stats["radii"] = out["radii_all"]
-        for p in params + curve_params:
-            p.grad = None
+        if not args.no_optimizer:
+            with torch.no_grad():
+                add_densification_stats_subframes(out["viewspace_points_all"], out["radii_all"], cloud.max_radii2D,
+                                                  cloud.xyz_gradient_accum, cloud.denom)
+            cloud.optimizer.step()
+        cloud.optimizer.zero_grad(set_to_none=True)
 
     def sync():
         if world > 1:
@@ -190,6 +211,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: P={P} Gaussians, {W}x{H}, K={K} subframes fused, curve_order={C}, "
                                    f"SH degree {args.sh_degree} (M={s}); one blurry view per GPU per step",
+                       "step": ("query + fused loss + backward" + (" + grad all-reduce" if world > 1 else "") +
+                                ("" if args.no_optimizer else " + densification stats + fused Adam (all groups; learning "
+                                 "rates x1e-6 so the synthetic workload stays stationary)")),
+                       "tile_cull": bool(__import__("deblurgs_amd.diff_gaussian_rasterization",
+                                                    fromlist=["x"]).TILE_CULL),
                        "sharding": "views" if world > 1 else "none", "Pv_total": Pv_tot, "R_total": int(R_tot),
                        "pixel_gaussian_evals_upper_bound_per_step": int(256 * R_tot)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
