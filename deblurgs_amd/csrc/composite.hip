@@ -205,7 +205,8 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
 
   // per-pixel channel state kept as (r,g) and (b,depth) pairs so the channel arithmetic issues as packed fp32
   float T[4], tb[4];  // tb = -T_final * (bg . dL_dpixel + z_far * dL_ddepthpix), backward.cu:613-618
-  v2f accA[4], accB[4], gA[4], gB[4];
+  v2f gA[4], gB[4];
+  float accg[4];  // sum_ch dL_dpixel[ch] * (colour accumulated behind the current pair)[ch]
   uint32_t last[4];
   uint32_t maxc = 0;
 #pragma unroll
@@ -224,7 +225,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     gA[q] = (v2f){g0, g1};
     gB[q] = (v2f){g2, gd};
     tb[q] = -Tfin * (bg0 * g0 + bg1 * g1 + bg2 * g2 + v.z_far * gd);
-    accA[q] = accB[q] = (v2f){0.0f, 0.0f};
+    accg[q] = 0.0f;
     maxc = max(maxc, last[q]);
   }
   // wave-wide max of n_contrib: entries at or beyond it are skipped by every pixel (backward.cu:566-568); the same
@@ -322,12 +323,15 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           const float inv1ma = __builtin_amdgcn_rcpf(oma);
           T[q] = T[q] * inv1ma;
           const float dchannel_dcolor = alpha * T[q];
-          const v2f dd = (colA - accA[q]) * gA[q] + (colB - accB[q]) * gB[q];
-          float dL_dalpha = dd.x + dd.y;
+          // dL_dalpha = sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch] (backward.cu:590-600) only ever uses the
+          // colour behind the pair through its dot product with dL_dpixel, and that dot product obeys the same
+          // recurrence as the colour itself (it is linear): keep the one scalar per pixel instead of four channels
+          const v2f cgv = colA * gA[q] + colB * gB[q];
+          const float cg = cgv.x + cgv.y;
+          float dL_dalpha = cg - accg[q];
           sA += gA[q] * dchannel_dcolor;
           sB += gB[q] * dchannel_dcolor;
-          accA[q] = colA * alpha + accA[q] * oma;
-          accB[q] = colB * alpha + accB[q] * oma;
+          accg[q] = cg * alpha + accg[q] * oma;
           dL_dalpha *= T[q];
           dL_dalpha += tb[q] * inv1ma;
           const float wgt = ok ? au * dL_dalpha : 0.0f;
