@@ -57,6 +57,14 @@ __device__ __forceinline__ bool load_tile_ctx(const DgsView& v, const uint2* __r
 // origin, otherwise it sits on one of the four edges, where q is a 1-D quadratic with a closed-form clamped
 // minimiser.  A slack on r2 and a relative slack on q keep it conservative under fp32 rounding, so the exact
 // per-pixel tests of the reference still decide every pair that survives.
+constexpr float K_LOG2E = -1.4426950408889634f;        // cross term:  -b dx dy        -> log2 domain
+constexpr float K_HALF_LOG2E = -0.7213475204444817f;   // square terms: -0.5 a dx^2 ...
+// log2(e) * (-0.5 (a dx^2 + c dy^2) - b dx dy) from the pre-scaled conic (A, B, C) = (-0.5 l a, -l b, -0.5 l c)
+__device__ __forceinline__ float dgs_power2(float A, float B, float C, float dx, float dy) {
+  const float u = fmaf(B, dy, A * dx);
+  return fmaf(C * dy, dy, dx * u);
+}
+
 using CullGauss = DgsCull;
 #define make_cull dgs_make_cull
 #define cull_hit dgs_cull_hit
@@ -116,8 +124,10 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       const uint64_t bh = __ballot(hit);
       m[q] = alive[q] ? bh : 0ull;
     }
-    s_a[w][lane] = A;
-    s_b[w][lane] = B;
+    // the conic goes to LDS pre-multiplied by -0.5 log2(e) (-log2(e) for the cross term): the per-pair exponent is
+    // then a 5-instruction quadratic form that feeds v_exp_f32 directly (forward and backward use the same bits)
+    s_a[w][lane] = make_float4(A.x, A.y, A.z * K_HALF_LOG2E, A.w * K_LOG2E);
+    s_b[w][lane] = make_float4(B.x * K_HALF_LOG2E, B.y, B.z, B.w);
     s_c[w][lane] = make_float2(Cc.x, Cc.y);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -138,8 +148,8 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           const float dy = (q >> 1) ? dy1 : dy0;
           // forward.cu:348-380, branch-free: a pair that fails one of the reference's tests gets alpha = 0,
           // which leaves T, C, D and `last` untouched (T >= 1e-4 always, so alpha = 0 can never terminate).
-          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-          const float alpha_raw = fminf(0.99f, b.y * __expf(power));
+          const float power = dgs_power2(a.z, a.w, b.x, dx, dy);  // log2(e) * the reference's `power`
+          const float alpha_raw = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
           const bool ok = (!done[q]) && (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
           const float alpha = ok ? alpha_raw : 0.0f;
           const float test_T = T[q] * (1.0f - alpha);
@@ -273,8 +283,8 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         const bool hit = has && (base + lane < maxq[q]) && cull_hit(cg, ex - 7.0f, ex, ey - 7.0f, ey);
         m[q] = __ballot(hit);
       }
-      s_a[w][lane] = A;
-      s_b[w][lane] = B;
+      s_a[w][lane] = make_float4(A.x, A.y, A.z * K_HALF_LOG2E, A.w * K_LOG2E);
+      s_b[w][lane] = make_float4(B.x * K_HALF_LOG2E, B.y, B.z, B.w);
       s_c[w][lane] = make_float2(Cc.x, Cc.y);
     }
     const float4 z4 = make_float4(0, 0, 0, 0);
@@ -313,12 +323,12 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           // eagerly (acc <- alpha*c + (1-alpha)*acc right after the pair is used) instead of one pair late with a
           // remembered last_alpha / last_color as in the reference: same operations in the same order, 5 fewer
           // live registers per pixel.
-          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-          const float au = b.y * __expf(power);  // opacity * G: the unclamped alpha the backward differentiates
-          const float alpha_raw = fminf(0.99f, au);
-          const bool ok = (pos < last[q]) && (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
+          const float power = dgs_power2(a.z, a.w, b.x, dx, dy);  // log2(e) * the reference's `power`
+          const float au_any = b.y * __builtin_amdgcn_exp2f(power);
+          const bool ok = (pos < last[q]) && (power <= 0.0f) && (au_any >= 1.0f / 255.0f);
           touched = touched || ok;
-          const float alpha = ok ? alpha_raw : 0.0f;
+          const float au = ok ? au_any : 0.0f;  // opacity * G: the unclamped alpha the backward differentiates
+          const float alpha = fminf(0.99f, au);
           const float oma = 1.0f - alpha;
           const float inv1ma = __builtin_amdgcn_rcpf(oma);
           T[q] = T[q] * inv1ma;
@@ -334,7 +344,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           accg[q] = cg * alpha + accg[q] * oma;
           dL_dalpha *= T[q];
           dL_dalpha += tb[q] * inv1ma;
-          const float wgt = ok ? au * dL_dalpha : 0.0f;
+          const float wgt = au * dL_dalpha;  // au == 0 for a skipped pair
           const float wx = wgt * dx, wy = wgt * dy;
           S_w += wgt;
           S_wx += wx;
