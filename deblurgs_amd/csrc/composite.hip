@@ -190,7 +190,9 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
 }
 
 // ----------------------------------------------------------------------------------------------- backward
-template <bool TIGHT>  // TIGHT: the duplicate index travels in the low key word (tile_cull emission)
+// TIGHT: the duplicate index travels in the low key word (tile_cull emission).  HASDEPTH: dL_ddepth is given (the
+// default training loss does not use the depth output: the depth channel then drops out of the per-pair math)
+template <bool TIGHT, bool HASDEPTH>
 __global__ void __launch_bounds__(64 * CW)
 composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
                      const uint32_t* __restrict__ point_list, const uint64_t* __restrict__ keys,
@@ -336,11 +338,19 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           // dL_dalpha = sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch] (backward.cu:590-600) only ever uses the
           // colour behind the pair through its dot product with dL_dpixel, and that dot product obeys the same
           // recurrence as the colour itself (it is linear): keep the one scalar per pixel instead of four channels
-          const v2f cgv = colA * gA[q] + colB * gB[q];
-          const float cg = cgv.x + cgv.y;
+          float cg;
+          if (HASDEPTH) {
+            const v2f cgv = colA * gA[q] + colB * gB[q];
+            cg = cgv.x + cgv.y;
+          } else {
+            cg = fmaf(colB.x, gB[q].x, fmaf(colA.y, gA[q].y, colA.x * gA[q].x));
+          }
           float dL_dalpha = cg - accg[q];
           sA += gA[q] * dchannel_dcolor;
-          sB += gB[q] * dchannel_dcolor;
+          if (HASDEPTH)
+            sB += gB[q] * dchannel_dcolor;
+          else
+            sB.x = fmaf(gB[q].x, dchannel_dcolor, sB.x);
           accg[q] = cg * alpha + accg[q] * oma;
           dL_dalpha *= T[q];
           dL_dalpha += tb[q] * inv1ma;
@@ -409,11 +419,14 @@ hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const f
                                     const float* dL_ddepth, float* contrib, hipStream_t s) {
   const uint32_t per = per_xcd_blocks(v);
   if (per == 0) return hipSuccess;
-  if (v.tile_cull)
-    hipLaunchKernelGGL(composite_bwd_kernel<true>, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
-                       c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth, contrib);
-  else
-    hipLaunchKernelGGL(composite_bwd_kernel<false>, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges,
-                       c.point_list, c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth, contrib);
+#define DGS_CBWD(TI, HD)                                                                                            \
+  hipLaunchKernelGGL((composite_bwd_kernel<TI, HD>), dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list, \
+                     c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth, contrib)
+  if (v.tile_cull) {
+    if (dL_ddepth != nullptr) DGS_CBWD(true, true); else DGS_CBWD(true, false);
+  } else {
+    if (dL_ddepth != nullptr) DGS_CBWD(false, true); else DGS_CBWD(false, false);
+  }
+#undef DGS_CBWD
   return hipGetLastError();
 }
