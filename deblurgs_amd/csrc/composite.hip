@@ -216,9 +216,14 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   
 
   // per-pixel channel state kept as (r,g) and (b,depth) pairs so the channel arithmetic issues as packed fp32
-  float T[4], tb[4];  // tb = -T_final * (bg . dL_dpixel + z_far * dL_ddepthpix), backward.cu:613-618
+  float T[4];
   v2f gA[4], gB[4];
-  float accg[4];  // sum_ch dL_dpixel[ch] * (colour accumulated behind the current pair)[ch]
+  // sum_ch dL_dpixel[ch] * (colour behind the current pair)[ch].  It starts at the background's dot product
+  // (bg . dL_dpixel + z_far * dL_ddepthpix): the background is what lies behind the last contributor, and with that
+  // start T_i * (c.g - accg_i) already contains the reference's separate background term
+  // -T_final / (1 - alpha_i) * bg_dot_dpixel (backward.cu:613-618), because T_i (1 - alpha_i) prod_{k>i}(1 - alpha_k)
+  // = T_final.
+  float accg[4];
   uint32_t last[4];
   uint32_t maxc = 0;
 #pragma unroll
@@ -236,8 +241,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     const float gd = (inside && dL_ddepth != nullptr) ? dL_ddepth[(size_t)t.k * N + pix] : 0.0f;
     gA[q] = (v2f){g0, g1};
     gB[q] = (v2f){g2, gd};
-    tb[q] = -Tfin * (bg0 * g0 + bg1 * g1 + bg2 * g2 + v.z_far * gd);
-    accg[q] = 0.0f;
+    accg[q] = bg0 * g0 + bg1 * g1 + bg2 * g2 + v.z_far * gd;
     maxc = max(maxc, last[q]);
   }
   // wave-wide max of n_contrib: entries at or beyond it are skipped by every pixel (backward.cu:566-568); the same
@@ -353,7 +357,6 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
             sB.x = fmaf(gB[q].x, dchannel_dcolor, sB.x);
           accg[q] = cg * alpha + accg[q] * oma;
           dL_dalpha *= T[q];
-          dL_dalpha += tb[q] * inv1ma;
           const float wgt = au * dL_dalpha;  // au == 0 for a skipped pair
           const float wx = wgt * dx, wy = wgt * dy;
           S_w += wgt;
