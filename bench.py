@@ -129,7 +129,7 @@ def main():
     stats = {}
 
     def step():
-        out = motion.query(0, "all")
+        out = motion.query(0, "all", compute_blurred=False)
         loss, _blur, _ls = losses.blur_l1_smooth(out["subframes"], out["gt"], args.lambda_t)
         loss = loss + lambda_hinge * losses.hinge_l2(cloud._opacity)
         loss.backward()

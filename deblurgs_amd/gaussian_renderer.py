@@ -79,7 +79,9 @@ def render_subframes(world_views, full_projs, camera_centers, ref_camera, pc, bg
     K = world_views.shape[0]
     # a leaf whose .grad receives the per-subframe screen-space gradients (the reference's `zeros + 0` +
     # retain_grad() idiom costs an extra elementwise pass over [K,P,3] for the same effect)
-    screenspace_points = torch.zeros((K,) + tuple(xyz.shape), dtype=xyz.dtype, requires_grad=True, device=xyz.device)
+    # (its values are never read -- the rasteriser ignores means2D, forward.cu has no use for it -- so it is not
+    # zero-filled: at the metric config that is 180 MB per step)
+    screenspace_points = torch.empty((K,) + tuple(xyz.shape), dtype=xyz.dtype, device=xyz.device).requires_grad_(True)
     raster_settings = GaussianRasterizationSettings(
         image_height=int(ref_camera.image_height),
         image_width=int(ref_camera.image_width),

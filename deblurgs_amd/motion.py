@@ -144,7 +144,8 @@ class CameraMotionModule:
     def get_gt_image(self, idx):
         return self.gt_images[idx]
 
-    def query(self, cam_idx: int, subframe_indice="all", post_process=None, background="random"):
+    def query(self, cam_idx: int, subframe_indice="all", post_process=None, background="random",
+              compute_blurred=True):
         """Render a blurry view (scene/motion.py:78-160).  Returns the reference's dict: 'blurred', 'gt',
         'subframes' [f,3,H,W], 'depths' [f,1,H,W], 'render_pkgs' (list of f per-subframe dicts whose
         'viewspace_points' entries are views of ONE [f,P,3] grad carrier, exposed as 'viewspace_points_all')."""
@@ -168,8 +169,9 @@ class CameraMotionModule:
         world_views, full_projs, centers = self.get_trajectory_matrices(cam_idx, nu)
         pkg = gaussian_renderer.render_subframes(world_views, full_projs, centers, self.ref_cam, gaussians, bg)
         render_subframes = pkg["render"]
-        blurred = render_subframes.mean(dim=0)
-        if post_process is not None:
+        # compute_blurred=False: the caller takes the blur from the fused loss kernel (losses.blur_l1_smooth)
+        blurred = render_subframes.mean(dim=0) if compute_blurred else None
+        if post_process is not None and blurred is not None:
             blurred = post_process(blurred)
         f = render_subframes.shape[0]
         render_pkgs = [{"render": render_subframes[i], "depth": pkg["depth"][i],

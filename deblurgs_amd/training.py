@@ -51,7 +51,7 @@ class TrainingLoop:
         if iteration % 1000 == 0:
             g.oneupSHdegree()
         subframe_indice = "all" if iteration >= opt.curve_start_iter else 1
-        r = self.motion.query(cam_idx=cam_idx, subframe_indice=subframe_indice)
+        r = self.motion.query(cam_idx=cam_idx, subframe_indice=subframe_indice, compute_blurred=False)
         total, blur, lv = losses.blur_l1_smooth(r["subframes"], r["gt"], lambda_t_smooth)
         Ll1, L_t = lv[0], lv[1]
         loss = total
