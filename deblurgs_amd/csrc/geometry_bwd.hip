@@ -134,6 +134,44 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     for (int i = 0; i < MAXC * 3; i++) sh[i] = (i < ncoef * 3) ? shp[i] : 0.0f;
   }
 
+  // Software pipeline over the subframes: the loads of one (subframe, Gaussian) are three dependent hops
+  // (tiles_touched -> geometry row -> contribution row at the row's duplicate offset) and this kernel runs at two
+  // waves per SIMD, so they are issued ahead: row of k+2 and contribution row of k+1 are in flight while k computes.
+  struct RowPf {
+    uint32_t nt, doff;
+    float4 ga, gb;  // x, y, cx, cy | cz, op, r, g
+  };
+  auto load_row = [&](int k) {
+    RowPf r;
+    const size_t o = (size_t)k * v.P + gi;
+    const float4* rowp = reinterpret_cast<const float4*>(rows + o);
+    r.nt = valid ? tiles_touched[o] : 0u;
+    r.ga = rowp[0];   // unconditional (no dependent hop); rows of invisible pairs are never used
+    r.gb = rowp[1];
+    r.doff = __float_as_uint(rowp[2].z);
+    return r;
+  };
+  struct SumPf {
+    float4 r0, r1, r2;
+  };
+  auto load_sums = [&](const RowPf& r) {
+    // the (subframe, Gaussian) total left by contrib_reduce_kernel in the first row of the segment; tile_cull
+    // leaves doff = ~0 for a visible pair whose every tile was culled: all its sums are zero
+    SumPf c;
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    c.r0 = c.r1 = c.r2 = z4;
+    if (r.nt > 0 && r.doff != 0xFFFFFFFFu) {
+      const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)r.doff * DGS_CONTRIB_F);
+      c.r0 = cp[0];
+      c.r1 = cp[1];
+      c.r2 = cp[2];
+    }
+    return c;
+  };
+  RowPf row1 = load_row(0);
+  RowPf row2 = load_row(v.K > 1 ? 1 : 0);
+  SumPf sum1 = load_sums(row1);
+
   for (int k = 0; k < v.K; k++) {
     const float* V = viewm + 16 * k;
     const float* F = projm + 16 * k;
@@ -142,18 +180,15 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
 #pragma unroll
     for (int i = 0; i < NMAT; i++) mat[i] = 0.0f;
     float g2x = 0.0f, g2y = 0.0f;
-    const uint32_t ntiles = valid ? tiles_touched[o] : 0u;
+    const RowPf cur = row1;
+    const SumPf cs = sum1;
+    row1 = row2;
+    if (k + 2 < v.K) row2 = load_row(k + 2);
+    if (k + 1 < v.K) sum1 = load_sums(row1);
+    const uint32_t ntiles = cur.nt;
     if (ntiles > 0) {
-      // ---- the (subframe, Gaussian) total left by contrib_reduce_kernel in the first row of the segment
-      const float4* rowp = reinterpret_cast<const float4*>(rows + o);
-      const float4 ga = rowp[0];   // x, y, cx, cy
-      const float4 gb = rowp[1];   // cz, op, r, g
-      const uint32_t dup_off = __float_as_uint(rowp[2].z);
-      // tile_cull leaves dup_off = ~0 for a visible pair whose every tile was culled: all its sums are zero
-      const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)(dup_off == 0xFFFFFFFFu ? 0u : dup_off) * DGS_CONTRIB_F);
-      const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      const bool none = dup_off == 0xFFFFFFFFu;
-      const float4 r0 = none ? z4 : cp[0], r1 = none ? z4 : cp[1], r2 = none ? z4 : cp[2];
+      const float4 ga = cur.ga, gb = cur.gb;
+      const float4 r0 = cs.r0, r1 = cs.r1, r2 = cs.r2;
       const float s[10] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
       // raw sums -> the reference's per-Gaussian sinks (backward.cu:620-637; see composite.hip):
       //   dL_dmean2D = -(0.5 W, 0.5 H) * (cx*Swx + cy*Swy, cz*Swy + cy*Swx),  dL_dconic = -0.5 * (Sxx, Sxy, Syy),
