@@ -299,6 +299,57 @@ def test_tile_cull_gradients_bitwise_equal(gpu, depth):
         assert np.array_equal(a[key], b[key]), key
 
 
+@pytest.mark.parametrize("case", ["faint", "indefinite_cov", "huge", "mixed_opacity"])
+def test_tile_cull_edge_cases_equal_reference_lists_results(gpu, case):
+    """Corner cases of the tile test: every pair below 1/255 (all duplicates culled while the pairs stay visible:
+    R == 0 with radii > 0), covariances that are not positive definite (conic with det <= 0: never culled), a
+    Gaussian covering every tile, opacities above 1 and at the 1/255 boundary.  Forward and backward must equal the
+    tile_cull = 0 results bit for bit, and those are checked against the oracle."""
+    kw = {}
+    sc = small_scene(P=1200, W=96, H=80, K=2, seed=12, sigma_px=4.0)
+    rng = np.random.default_rng(13)
+    if case == "faint":
+        sc["opacities"][:] = 0.003            # < 1/255 by more than the test's slack: alpha can never reach the threshold
+    elif case == "indefinite_cov":
+        st = oracle_forward(sc, 0, render=False)
+        cov = st["cov3D"].copy()
+        cov[st["depths"] == 0] = np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], np.float32)
+        cov[::3, 1] += cov[::3, 0] * 1.5      # xy covariance larger than the variances: not PSD
+        cov[1::7, 0] *= -1.0
+        kw = dict(cov3D_precomp=cov)
+    elif case == "huge":
+        sc["scales"][0] = 40.0
+        sc["means3D"][0] = [0, 0, 5]
+        sc["opacities"][0] = 0.2
+    elif case == "mixed_opacity":
+        sc["opacities"][:] = rng.choice(np.array([1.0 / 255.0, 0.00392, 0.00393, 0.5, 1.0, 3.0], np.float32),
+                                        size=sc["opacities"].shape)
+    gC, gD = _grads(sc, 2, seed=14)
+    with tile_cull(False):
+        a = hip_forward_backward(sc, 2, gC, gD, **kw)
+    with tile_cull(True):
+        b = hip_forward_backward(sc, 2, gC, gD, **kw)
+    keys = ["color", "depth", "dL_dmeans3D", "dL_dopacities", "dL_dmeans2D", "dL_dviewmatrix", "dL_dprojmatrix", "dL_dsh"]
+    keys += ["dL_dcov3D_precomp"] if kw else ["dL_dscales", "dL_drotations"]
+    for key in keys:
+        assert np.array_equal(a[key], b[key], equal_nan=True), key
+    ref = hip_forward_state(sc, 2, cull=False, **kw)
+    cul = hip_forward_state(sc, 2, cull=True, **kw)
+    assert np.array_equal(ref["radii"], cul["radii"]) and cul["R"] <= ref["R"]
+    if case == "faint":
+        assert cul["R"] == 0 and ref["R"] > 0 and (cul["radii"] > 0).any()
+        assert not np.any(b["dL_dmeans3D"]) and not np.any(b["dL_dsh"])
+    if case == "huge":
+        assert ref["tiles_touched"][0, 0] == 30 and cul["tt_tight"].max() == 30     # every tile of the 6 x 5 grid
+    if case != "indefinite_cov":     # (the oracle's cov3D path is covered by test_variants)
+        ora = oracle_forward_backward(sc, 2, gC, gD)
+        for k in range(2):
+            un = unstable_pixels(ora["states"][k])
+            assert np.abs(b["color"][k] - ora["color"][k]).max(axis=0)[~un].max() <= IMG_TOL
+        for key in ["dL_dmeans3D", "dL_dopacities", "dL_dsh", "dL_dscales"]:
+            assert relerr(b[key].reshape(ora[key].shape), ora[key]) <= GRAD_TOL, key
+
+
 def test_ragged_image_and_empty_tiles(gpu):
     """W, H not multiples of 16 (partial tiles, partial quadrants) and many empty tiles."""
     sc = small_scene(P=300, W=75, H=41, K=2, seed=7)
