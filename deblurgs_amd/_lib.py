@@ -70,7 +70,7 @@ class DgsCloudArrays(ctypes.Structure):
     _fields_ = [("param", ctypes.c_void_p * 6), ("exp_avg", ctypes.c_void_p * 6), ("exp_avg_sq", ctypes.c_void_p * 6)]
 
 
-ADAM_MAX_GROUPS = 8
+ADAM_MAX_GROUPS = 16
 
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {

@@ -203,7 +203,7 @@ int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t
  * `step` is the 1-based count of THIS update (state["step"] after its increment).  A group whose grad is NULL is
  * skipped, like a parameter whose .grad is None.  clip_value > 0 clamps the gradient first
  * (torch.nn.utils.clip_grad_value_, train.py:204-205); the gradient buffer itself is left untouched. */
-#define DGS_ADAM_MAX_GROUPS 8
+#define DGS_ADAM_MAX_GROUPS 16
 typedef struct DgsAdamGroup {
   float* param;
   const float* grad;

@@ -35,7 +35,8 @@ def test_fused_adam_matches_torch_adam(gpu, clip):
     from deblurgs_amd.optim import FusedAdam
     rng = np.random.default_rng(3)
     shapes = dict(xyz=(1003, 3), f_dc=(1003, 1, 3), f_rest=(1003, 8, 3), opacity=(1003, 1), scaling=(1003, 3),
-                  rotation=(1003, 4), odd=(4097,), one=(1,), curve=(10, 3))     # > DGS_ADAM_MAX_GROUPS tensors
+                  rotation=(1003, 4), odd=(4097,), one=(1,), curve=(10, 3))
+    shapes.update({f"extra{i}": (5 + 3 * i,) for i in range(9)})                  # 18 > DGS_ADAM_MAX_GROUPS tensors
     lrs = {n: 10.0 ** rng.uniform(-4, -1) for n in shapes}
     init = {n: rng.normal(0, 1, s).astype(np.float32) for n, s in shapes.items()}
     mk = lambda: {n: torch.nn.Parameter(torch.tensor(a, device="cuda")) for n, a in init.items()}
