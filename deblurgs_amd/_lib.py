@@ -71,6 +71,7 @@ class DgsCloudArrays(ctypes.Structure):
 
 
 ADAM_MAX_GROUPS = 16
+ABI_VERSION = 2            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
 
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {
@@ -138,7 +139,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.dgs_abi_version() != 2:
+        if L.dgs_abi_version() != ABI_VERSION:
             raise RuntimeError("libdgs_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -24,7 +24,9 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"libdgs_hip.so does not export {s}"
     assert set(syms) == set(_lib.EXPORTS), "ctypes binding and header disagree"
-    assert L.dgs_abi_version() == 2
+    import re
+    want = int(re.search(r"#define DGS_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "dgs_hip.h")).read()).group(1))
+    assert L.dgs_abi_version() == want == _lib.ABI_VERSION
 
 
 def test_no_torch_types_in_the_abi():
