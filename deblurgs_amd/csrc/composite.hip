@@ -86,22 +86,23 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   const float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
   const float qx0 = (float)(t.tx * DGS_TILE), qy0 = (float)(t.ty * DGS_TILE);
 
+  // T carries the pixel's "done" flag in its sign: positive while the pixel is live (then T >= 1e-4), and flipped to
+  // -T by the pair that would take it below 1e-4 (forward.cu:362-367), after which T (1 - alpha) < 1e-4 holds for every
+  // later pair by itself and |T| is the final transmittance.  No separate per-lane flag to test and update per pair.
   float T[4], C0[4], C1[4], C2[4], Dd[4];
   uint32_t last[4];
-  bool done[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    T[q] = 1.0f;
     C0[q] = C1[q] = C2[q] = Dd[q] = 0.0f;
     last[q] = 0;
     const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
-    done[q] = !(px < v.W && py < v.H);
+    T[q] = (px < v.W && py < v.H) ? 1.0f : -1.0f;
   }
   const DgsRow* krows = rows + (size_t)t.k * v.P;
   const uint32_t n = t.r1 - t.r0;
   uint64_t alive[4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) alive[q] = __ballot(!done[q]);
+  for (int q = 0; q < 4; q++) alive[q] = __ballot(T[q] > 0.0f);
 
   for (uint32_t base = 0; base < n; base += 64) {
     if ((alive[0] | alive[1] | alive[2] | alive[3]) == 0) break;  // whole tile terminated (forward.cu:325)
@@ -150,24 +151,22 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           // which leaves T, C, D and `last` untouched (T >= 1e-4 always, so alpha = 0 can never terminate).
           const float power = dgs_power2(a.z, a.w, b.x, dx, dy);  // log2(e) * the reference's `power`
           const float alpha_raw = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
-          const bool ok = (!done[q]) && (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
+          const bool ok = (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
           const float alpha = ok ? alpha_raw : 0.0f;
           const float test_T = T[q] * (1.0f - alpha);
-          const bool stop = test_T < 0.0001f;
-          const bool blend = ok && !stop;
-          const float wgt = blend ? alpha * T[q] : 0.0f;
+          const bool stop = test_T < 0.0001f;      // also every pair of a pixel that is already done (T < 0)
+          const float wgt = stop ? 0.0f : alpha * T[q];
           C0[q] += b.z * wgt;
           C1[q] += b.w * wgt;
           C2[q] += c.x * wgt;
           Dd[q] += c.y * wgt;
-          T[q] = blend ? test_T : T[q];
-          last[q] = blend ? (base + (uint32_t)j + 1u) : last[q];
-          done[q] = done[q] || stop;
+          T[q] = stop ? -fabsf(T[q]) : test_T;     // alpha = 0 leaves a live T unchanged
+          last[q] = (ok && !stop) ? (base + (uint32_t)j + 1u) : last[q];
         }
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) alive[q] = __ballot(!done[q]);
+    for (int q = 0; q < 4; q++) alive[q] = __ballot(T[q] > 0.0f);
     __builtin_amdgcn_wave_barrier();  // LDS rows are rewritten by the next batch
   }
 
@@ -178,13 +177,14 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
     if (px < v.W && py < v.H) {
       const size_t pix = (size_t)py * v.W + px;
-      final_T[(size_t)t.k * N + pix] = T[q];
+      const float Tf = fabsf(T[q]);
+      final_T[(size_t)t.k * N + pix] = Tf;
       n_contrib[(size_t)t.k * N + pix] = last[q];
       float* oc = out_color + (size_t)t.k * 3 * N;
-      oc[pix] = C0[q] + T[q] * bg0;
-      oc[N + pix] = C1[q] + T[q] * bg1;
-      oc[2 * N + pix] = C2[q] + T[q] * bg2;
-      out_depth[(size_t)t.k * N + pix] = Dd[q] + T[q] * v.z_far;
+      oc[pix] = C0[q] + Tf * bg0;
+      oc[N + pix] = C1[q] + Tf * bg1;
+      oc[2 * N + pix] = C2[q] + Tf * bg2;
+      out_depth[(size_t)t.k * N + pix] = Dd[q] + Tf * v.z_far;
     }
   }
 }
