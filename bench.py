@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--config", default="metric", help="metric | cfg2 | cfg3 | cfg5 | cfg1")
     ap.add_argument("--K", type=int, default=None)
     ap.add_argument("--sh-degree", type=int, default=2)
+    ap.add_argument("--P", type=int, default=None, help="override the number of Gaussians (stress variants)")
+    ap.add_argument("--sigma-px", type=float, default=None, help="override the splat size of the generator (default 1.5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lambda-t", type=float, default=1e-3)
     ap.add_argument("--no-optimizer", action="store_true",
@@ -96,6 +98,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     over = {} if args.K is None else {"K": args.K}
+    if args.P is not None:
+        over["P"] = args.P
+    if args.sigma_px is not None:
+        over["sigma_px"] = args.sigma_px
     scene = synthetic.make_config(args.config, seed=0, sh_degree=args.sh_degree, **over)
     P, W, H, K = scene["P"], scene["W"], scene["H"], scene["K"]
     C = synthetic.CONFIGS[args.config]["C"]

@@ -130,5 +130,6 @@ def make_scene(P, W, H, K=1, curve_order=3, sh_degree=2, seed=0, sigma_px=1.5, s
 def make_config(name, seed=0, **over):
     cfg = dict(CONFIGS[name])
     cfg.update(over)
+    extra = {k: over[k] for k in ("sigma_px", "sigma_log") if k in over}
     return make_scene(cfg["P"], cfg["W"], cfg["H"], K=cfg["K"], curve_order=cfg["C"], seed=seed,
-                      sh_degree=over.get("sh_degree", 2))
+                      sh_degree=over.get("sh_degree", 2), **extra)
