@@ -24,8 +24,9 @@ class DgsProblem(ctypes.Structure):
         ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
         ("z_near", ctypes.c_float), ("z_far", ctypes.c_float),
         ("use_sigmoid", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
-        ("tile_cull", ctypes.c_int32),
-        ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p), ("colors_precomp", ctypes.c_void_p),
+        ("tile_cull", ctypes.c_int32), ("raw_params", ctypes.c_int32), ("scale_lb", ctypes.c_float),
+        ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p), ("shs_rest", ctypes.c_void_p),
+        ("colors_precomp", ctypes.c_void_p),
         ("opacities", ctypes.c_void_p), ("scales", ctypes.c_void_p), ("rotations", ctypes.c_void_p),
         ("cov3D_precomp", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p), ("projmatrix", ctypes.c_void_p),
         ("campos", ctypes.c_void_p), ("bg", ctypes.c_void_p),
@@ -45,6 +46,7 @@ class DgsBackwardIO(ctypes.Structure):
         ("num_rendered", ctypes.c_uint32), ("radii", ctypes.c_void_p), ("dL_dout_color", ctypes.c_void_p),
         ("dL_dout_depth", ctypes.c_void_p), ("scratch", ctypes.c_void_p), ("scratch_bytes", ctypes.c_size_t),
         ("dL_dmeans3D", ctypes.c_void_p), ("dL_dmeans2D", ctypes.c_void_p), ("dL_dsh", ctypes.c_void_p),
+        ("dL_dsh_rest", ctypes.c_void_p),
         ("dL_dcolors", ctypes.c_void_p), ("dL_dopacity", ctypes.c_void_p), ("dL_dscales", ctypes.c_void_p),
         ("dL_drotations", ctypes.c_void_p), ("dL_dcov3D", ctypes.c_void_p), ("dL_dviewmatrix", ctypes.c_void_p),
         ("dL_dprojmatrix", ctypes.c_void_p),
@@ -71,7 +73,7 @@ class DgsCloudArrays(ctypes.Structure):
 
 
 ADAM_MAX_GROUPS = 16
-ABI_VERSION = 2            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
+ABI_VERSION = 3            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
 
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {

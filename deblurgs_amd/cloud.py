@@ -42,6 +42,9 @@ class GaussianCloud(nn.Module):
         self._opacity = nn.Parameter(opacity)              # identity-with-clamp activation
         self.scaling_activation = LowerBoundExponent(scale_lb)
         self.scale_lower_bound = scale_lb
+        # render_subframes() hands the raw parameters to the kernels, which apply exactly the activations below
+        # (set False to go through the getters, as the reference's render() does)
+        self.fused_activations = True
         self.alpha_lower_bound = alpha_lower_bound
         self.optimizer = None
         self.percent_dense = 0.0

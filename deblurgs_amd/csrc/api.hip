@@ -82,6 +82,13 @@ int check_problem(const DgsProblem* p) {
     return fail(DGS_E_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
   (void)sr;
   if (p->shs != nullptr && p->M < (p->D + 1) * (p->D + 1)) return fail(DGS_E_ARG, "M < (D+1)^2");
+  if (p->raw_params) {
+    if (p->shs == nullptr || p->scales == nullptr || p->rotations == nullptr)
+      return fail(DGS_E_ARG, "raw_params needs shs (dc), scales and rotations");
+    if (p->M > 1 && p->shs_rest == nullptr) return fail(DGS_E_ARG, "raw_params with M > 1 needs shs_rest");
+  } else if (p->shs_rest != nullptr) {
+    return fail(DGS_E_ARG, "shs_rest is only meaningful with raw_params");
+  }
   if (p->viewmatrix == nullptr || p->projmatrix == nullptr || p->campos == nullptr || p->bg == nullptr)
     return fail(DGS_E_ARG, "viewmatrix / projmatrix / campos / bg are null");
   if ((uint64_t)p->K * (uint64_t)p->P >= (1ull << 32)) return fail(DGS_E_ARG, "K*P must be < 2^32");
@@ -101,6 +108,8 @@ DgsView make_view(const DgsProblem* p) {
   v.z_far = p->z_far;
   v.use_sigmoid = p->use_sigmoid; v.prefiltered = p->prefiltered;
   v.tile_cull = p->tile_cull != 0;
+  v.raw_params = p->raw_params != 0;
+  v.scale_lb = p->scale_lb;
   return v;
 }
 
@@ -465,6 +474,7 @@ int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stre
       io->dL_dcov3D == nullptr)
     return fail(DGS_E_ARG, "DgsBackwardIO: a required pointer is null");
   if (p->shs != nullptr && io->dL_dsh == nullptr) return fail(DGS_E_ARG, "dL_dsh is null");
+  if (p->raw_params && p->M > 1 && io->dL_dsh_rest == nullptr) return fail(DGS_E_ARG, "dL_dsh_rest is null");
   if (p->scales != nullptr && (io->dL_dscales == nullptr || io->dL_drotations == nullptr))
     return fail(DGS_E_ARG, "dL_dscales / dL_drotations are null");
   const uint64_t R = io->num_rendered;

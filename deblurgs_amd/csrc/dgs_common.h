@@ -122,7 +122,17 @@ struct DgsView {  // per-launch scalars shared by the kernels
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier, z_far;
   int use_sigmoid, prefiltered;
   int tile_cull;
+  int raw_params;   // kernels apply the cloud's activations (DgsProblem.raw_params)
+  float scale_lb;
 };
+
+// ---- the reference's parameter activations (scene/gaussian_activation.py:29-52, torch.nn.functional.normalize) for
+// DgsProblem.raw_params = 1; forward and backward call the same functions so that both see identical values
+__device__ __forceinline__ float dgs_act_opacity(float x) { return fminf(1.0f, fmaxf(0.0f, x)); }
+__device__ __forceinline__ float dgs_act_scale(float x, float lb) { return expf(x) + lb; }
+__device__ __forceinline__ float dgs_quat_norm(float r, float x, float y, float z) {
+  return fmaxf(sqrtf(r * r + x * x + y * y + z * z), 1e-12f);
+}
 
 // ---- exact "can this Gaussian reach alpha >= 1/255 anywhere in this pixel box" test -----------------------------
 // alpha = op * exp(-q/2), q(d) = a dx^2 + 2 b dx dy + c dy^2 with d = mean - pixel (forward.cu:346-358), so a pair

@@ -95,6 +95,7 @@ contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ tiles_touched, co
 template <int MAXC>  // MAXC = SH coefficients held in registers: 1, 4, 9 or 16
 __global__ void __launch_bounds__(GB_THREADS)
 geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* __restrict__ shs,
+                    const float* __restrict__ shs_rest, const float* __restrict__ opacities_raw,
                     const float* __restrict__ scales, const float* __restrict__ rotations,
                     const float* __restrict__ cov3D_precomp, const float* __restrict__ viewm,
                     const float* __restrict__ projm, const float* __restrict__ campos,
@@ -102,7 +103,8 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
                     const float* __restrict__ cov3Ds,
                     const float* __restrict__ pre_sigmoid, const uint32_t* __restrict__ tiles_touched,
                     const float* __restrict__ contrib, float* __restrict__ dL_dmeans3D,
-                    float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dsh, float* __restrict__ dL_dcolors,
+                    float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dsh, float* __restrict__ dL_dsh_rest,
+                    float* __restrict__ dL_dcolors,
                     float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales, float* __restrict__ dL_drots,
                     float* __restrict__ dL_dcov3D_out, float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float s_part[];  // [waves][K][NMAT]
@@ -129,9 +131,16 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
   // (D+1)^2 are touched, MAXC >= (D+1)^2 by construction of the launch)
   float sh[MAXC * 3];
   if (shs != nullptr) {
-    const float* shp = shs + (size_t)gi * v.M * 3;
+    if (shs_rest == nullptr) {
+      const float* shp = shs + (size_t)gi * v.M * 3;
 #pragma unroll
-    for (int i = 0; i < MAXC * 3; i++) sh[i] = (i < ncoef * 3) ? shp[i] : 0.0f;
+      for (int i = 0; i < MAXC * 3; i++) sh[i] = (i < ncoef * 3) ? shp[i] : 0.0f;
+    } else {
+      const float* dcp = shs + (size_t)gi * 3;
+      const float* rsp = shs_rest + (size_t)gi * (v.M - 1) * 3;
+#pragma unroll
+      for (int i = 0; i < MAXC * 3; i++) sh[i] = (i < ncoef * 3) ? ((i < 3) ? dcp[i] : rsp[i - 3]) : 0.0f;
+    }
   }
 
   // Software pipeline over the subframes: the loads of one (subframe, Gaussian) are three dependent hops
@@ -411,13 +420,32 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     dL_dmeans3D[3 * idx + 0] = a_mean[0];
     dL_dmeans3D[3 * idx + 1] = a_mean[1];
     dL_dmeans3D[3 * idx + 2] = a_mean[2];
-    dL_dopacity[idx] = a_op;
+    // raw parameters: torch.clamp passes the gradient where 0 <= x <= 1
+    dL_dopacity[idx] = (v.raw_params && !(opacities_raw[idx] >= 0.0f && opacities_raw[idx] <= 1.0f)) ? 0.0f : a_op;
     dL_dcolors[3 * idx + 0] = a_col[0];
     dL_dcolors[3 * idx + 1] = a_col[1];
     dL_dcolors[3 * idx + 2] = a_col[2];
 #pragma unroll
     for (int i = 0; i < 6; i++) dL_dcov3D_out[6 * (size_t)idx + i] = a_cov[i];
-    if (dL_dsh != nullptr) {
+    if (dL_dsh != nullptr && dL_dsh_rest != nullptr) {  // raw parameters: dc and rest gradients in two tensors
+      float* ddc = dL_dsh + (size_t)idx * 3;
+      float* drs = dL_dsh_rest + (size_t)idx * (v.M - 1) * 3;
+      ddc[0] = a_sh[0];
+      ddc[1] = a_sh[1];
+      ddc[2] = a_sh[2];
+#pragma unroll
+      for (int jj = 1; jj < MAXC; jj++)
+        if (jj < v.M) {
+          drs[3 * (jj - 1)] = a_sh[3 * jj];
+          drs[3 * (jj - 1) + 1] = a_sh[3 * jj + 1];
+          drs[3 * (jj - 1) + 2] = a_sh[3 * jj + 2];
+        }
+      for (int j = MAXC; j < v.M; j++) {
+        drs[3 * (j - 1)] = 0.0f;
+        drs[3 * (j - 1) + 1] = 0.0f;
+        drs[3 * (j - 1) + 2] = 0.0f;
+      }
+    } else if (dL_dsh != nullptr) {
       float* dsh = dL_dsh + (size_t)idx * v.M * 3;
 #pragma unroll
       for (int jj = 0; jj < MAXC; jj++)
@@ -433,13 +461,21 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
       }
     }
     if (scales != nullptr) {  // computeCov3D backward (backward.cu:299-362) on the K-summed dL_dcov3D
-      const float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2],
-                  z = rotations[4 * idx + 3];
+      float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2], z = rotations[4 * idx + 3];
+      float s0 = scales[3 * idx], s1 = scales[3 * idx + 1], s2 = scales[3 * idx + 2];
+      float qd = 1.0f, e0 = 1.0f, e1 = 1.0f, e2 = 1.0f;
+      if (v.raw_params) {
+        e0 = expf(s0); e1 = expf(s1); e2 = expf(s2);   // d(exp(x) + lb)/dx
+        s0 = dgs_act_scale(s0, v.scale_lb);
+        s1 = dgs_act_scale(s1, v.scale_lb);
+        s2 = dgs_act_scale(s2, v.scale_lb);
+        qd = dgs_quat_norm(r, x, y, z);
+        r = r / qd; x = x / qd; y = y / qd; z = z / qd;
+      }
       M3 R = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
                {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
-      const float sx = v.scale_modifier * scales[3 * idx], sy = v.scale_modifier * scales[3 * idx + 1],
-                  sz = v.scale_modifier * scales[3 * idx + 2];
+      const float sx = v.scale_modifier * s0, sy = v.scale_modifier * s1, sz = v.scale_modifier * s2;
       M3 S = {{{sx, 0, 0}, {0, sy, 0}, {0, 0, sz}}};
       M3 Mm = mul(S, R);
       M3 dSig = {{{a_cov[0], 0.5f * a_cov[1], 0.5f * a_cov[2]},
@@ -453,9 +489,9 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
       M3 dL_dM = mul(M2, dSig);
       M3 Rt = tr(R);
       M3 dMt = tr(dL_dM);
-      dL_dscales[3 * idx + 0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
-      dL_dscales[3 * idx + 1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
-      dL_dscales[3 * idx + 2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
+      dL_dscales[3 * idx + 0] = (Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2]) * e0;
+      dL_dscales[3 * idx + 1] = (Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2]) * e1;
+      dL_dscales[3 * idx + 2] = (Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2]) * e2;
 #pragma unroll
       for (int rr = 0; rr < 3; rr++) {
         dMt.m[0][rr] *= sx;
@@ -471,6 +507,17 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
              2 * z * (dMt.m[1][2] + dMt.m[2][1]) - 4 * y * (dMt.m[2][2] + dMt.m[0][0]);
       dq.w = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) +
              2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
+      if (v.raw_params) {
+        // x / max(|x|, eps) backward: (g - n (n . g)) / |x|  (n = normalised quaternion; constant denominator if
+        // the clamp is active)
+        const float4 raw = reinterpret_cast<const float4*>(rotations)[idx];
+        const bool clamped = sqrtf(raw.x * raw.x + raw.y * raw.y + raw.z * raw.z + raw.w * raw.w) < 1e-12f;
+        const float dot = clamped ? 0.0f : (r * dq.x + x * dq.y + y * dq.z + z * dq.w);
+        dq.x = (dq.x - r * dot) / qd;
+        dq.y = (dq.y - x * dot) / qd;
+        dq.z = (dq.z - y * dot) / qd;
+        dq.w = (dq.w - z * dot) / qd;
+      }
       reinterpret_cast<float4*>(dL_drots)[idx] = dq;
     }
   }
@@ -551,9 +598,11 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
                        const_cast<float*>(contrib));
 #define DGS_GB_LAUNCH(MAXC)                                                                                          \
   hipLaunchKernelGGL(geometry_bwd_kernel<MAXC>, dim3(blocks), dim3(GB_THREADS), lds, s, v, p.means3D, p.shs,         \
+                     p.shs_rest, p.opacities,                                                                        \
                      p.scales, p.rotations, p.cov3D_precomp, p.viewmatrix, p.projmatrix, p.campos, c.point_offsets, c.rows,       \
                      c.cov3D,  \
                      c.pre_sigmoid, c.tiles_touched, contrib, io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh,             \
+                     io.dL_dsh_rest,                                                                                 \
                      io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations, io.dL_dcov3D, partials)
   if (ncoef <= 1)
     DGS_GB_LAUNCH(1);

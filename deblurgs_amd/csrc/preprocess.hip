@@ -48,7 +48,8 @@ template <int DEG>  // active SH degree: the (DEG+1)^2 coefficients are read ONC
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float* __restrict__ scales,
                       const float* __restrict__ rotations, const float* __restrict__ opacities,
-                      const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+                      const float* __restrict__ shs, const float* __restrict__ shs_rest,
+                      const float* __restrict__ cov3D_precomp,
                       const float* __restrict__ colors_precomp, const float* __restrict__ viewm,
                       const float* __restrict__ projm, const float* __restrict__ campos, DgsRow* __restrict__ rows,
                       float* __restrict__ cov3Ds, float* __restrict__ pre_sigmoid,
@@ -65,7 +66,7 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
   const int wave_first = blockIdx.x * 256 + wv_ * 64;          // first Gaussian of this wave
   const int wave_count = min(64, v.P - wave_first);           // > 0 for every launched wave that has live lanes
   const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
-  const float opacity = opacities[idx];
+  const float opacity = v.raw_params ? dgs_act_opacity(opacities[idx]) : opacities[idx];
 
   float c3[6];
   if (cov3D_precomp != nullptr) {
@@ -74,11 +75,18 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
   } else {  // computeCov3D, forward.cu:129-163 (quaternion as given)
     const float mod = v.scale_modifier;
     M3 S = {{{1.0f, 0.f, 0.f}, {0.f, 1.0f, 0.f}, {0.f, 0.f, 1.0f}}};
-    S.m[0][0] = mod * scales[3 * idx];
-    S.m[1][1] = mod * scales[3 * idx + 1];
-    S.m[2][2] = mod * scales[3 * idx + 2];
-    const float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2],
-                z = rotations[4 * idx + 3];
+    float s0 = scales[3 * idx], s1 = scales[3 * idx + 1], s2 = scales[3 * idx + 2];
+    float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2], z = rotations[4 * idx + 3];
+    if (v.raw_params) {
+      s0 = dgs_act_scale(s0, v.scale_lb);
+      s1 = dgs_act_scale(s1, v.scale_lb);
+      s2 = dgs_act_scale(s2, v.scale_lb);
+      const float d = dgs_quat_norm(r, x, y, z);
+      r = r / d; x = x / d; y = y / d; z = z / d;
+    }
+    S.m[0][0] = mod * s0;
+    S.m[1][1] = mod * s1;
+    S.m[2][2] = mod * s2;
     M3 R = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
              {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
              {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
@@ -99,9 +107,16 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
   constexpr int NC = (DEG + 1) * (DEG + 1);
   float sh[NC * 3];
   if (colors_precomp == nullptr) {
-    const float* shp = shs + (size_t)idx * v.M * 3;
+    if (shs_rest == nullptr) {
+      const float* shp = shs + (size_t)idx * v.M * 3;
 #pragma unroll
-    for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+      for (int i = 0; i < NC * 3; i++) sh[i] = shp[i];
+    } else {  // raw parameters: dc and rest live in two tensors (GaussianModel._features_dc / _features_rest)
+      const float* dcp = shs + (size_t)idx * 3;
+      const float* rsp = shs_rest + (size_t)idx * (v.M - 1) * 3;
+#pragma unroll
+      for (int i = 0; i < NC * 3; i++) sh[i] = (i < 3) ? dcp[i] : rsp[i - 3];
+    }
   }
 
   for (int k = 0; k < v.K; k++) {
@@ -277,7 +292,7 @@ hipError_t dgs_launch_preprocess(const DgsProblem& p, const DgsView& v, const Dg
   const int blocks = (v.P + 255) / 256;
 #define DGS_PRE(DEG)                                                                                                  \
   hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, dim3(blocks), dim3(256), 0, s, v, p.means3D, p.scales, p.rotations, \
-                     p.opacities, p.shs, p.cov3D_precomp, p.colors_precomp, p.viewmatrix, p.projmatrix, p.campos,     \
+                     p.opacities, p.shs, p.shs_rest, p.cov3D_precomp, p.colors_precomp, p.viewmatrix, p.projmatrix, p.campos,     \
                      c.rows, c.cov3D, c.pre_sigmoid, c.tiles_touched, radii, c.gsort_keys, c.gsort_vals)
   const int deg = (p.colors_precomp != nullptr) ? 0 : v.D;
   if (deg <= 0)

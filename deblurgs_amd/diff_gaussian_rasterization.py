@@ -89,9 +89,12 @@ class _State:
 
 
 def _make_problem(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm, campos,
-                  rs, geom, image, binning, tile_cull):
+                  rs, geom, image, binning, tile_cull, raw=None):
     p = _lib.DgsProblem()
     p.tile_cull = int(bool(tile_cull))
+    p.raw_params = 0 if raw is None else 1
+    p.scale_lb = 0.0 if raw is None else float(raw["scale_lb"])
+    p.shs_rest = None if raw is None else _ptr(raw["sh_rest"])
     p.P = means3D.shape[0]
     p.D = int(rs.sh_degree)
     p.M = 0 if sh is None else sh.shape[1]
@@ -135,7 +138,9 @@ class _RS:
 
 
 def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm, campos,
-                  raster_settings):
+                  raster_settings, raw=None):
+    """raw = {"scale_lb": float, "sh_rest": [P,M-1,3] or None}: the inputs are the cloud's raw parameters
+    (DgsProblem.raw_params) and sh is the dc part [P,1,3]."""
     L = _lib.lib()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:60-62
@@ -158,7 +163,9 @@ def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, 
     stream = _stream(device)
     tile_cull = bool(TILE_CULL)
     prob = _make_problem(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm,
-                         campos, rs, geom, image, None, tile_cull)
+                         campos, rs, geom, image, None, tile_cull, raw)
+    if raw is not None:
+        prob.M = 1 + (0 if raw["sh_rest"] is None else raw["sh_rest"].shape[1])
     _lib.check(L.dgs_forward_geometry(ctypes.byref(prob), ctypes.byref(out), stream), "dgs_forward_geometry")
     torch.cuda.current_stream(device).synchronize()   # the one host read of num_rendered (rasterizer_impl.cu:287)
     if int(host_R[1].item()) != 0:
@@ -371,6 +378,102 @@ class _RasterizeGaussiansK(torch.autograd.Function):
             grad_projmatrix,
             None,
         )
+
+
+# ------------------------------------------------ K subframes straight from the cloud's raw parameters
+def _align4(n):
+    return (n + 3) // 4 * 4
+
+
+class _RasterizeCloudK(torch.autograd.Function):
+    """The K-subframe operator with the reference's parameter activations folded into the kernels
+    (DgsProblem.raw_params): inputs are GaussianModel's raw tensors (_xyz, _features_dc [P,1,3], _features_rest
+    [P,M-1,3], _opacity, _scaling, _rotation) instead of the activated values render() computes with
+    get_opacity / get_scaling / get_rotation / get_features (gaussian_renderer/__init__.py:60-77,
+    scene/gaussian_model.py:114-137), so the ~25 elementwise / cat / norm launches of those getters and of their
+    autograd backward disappear.  The six gradients are views of ONE flat buffer, in the order of the reference's
+    optimiser groups, so a data-parallel run can all-reduce them without packing (sharding.flat_allreduce_grads)."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, viewmatrices, projmatrices,
+                raster_settings, scale_lb):
+        m3, dc, opc, scc, rotc = (_f32c(t) for t in (xyz, f_dc, opacity, scaling, rotation))
+        rest = _f32c(f_rest) if f_rest is not None and f_rest.shape[1] > 0 else None
+        viewm, projm = _f32c(viewmatrices), _f32c(projmatrices)
+        K = viewm.shape[0]
+        campos = _f32c(raster_settings.campos.to(m3.device)).reshape(-1, 3)
+        if viewm.shape != (K, 4, 4) or projm.shape != (K, 4, 4) or campos.shape[0] != K:
+            raise RuntimeError("viewmatrices / projmatrices must be [K,4,4] and raster_settings.campos [K,3]")
+        raw = {"scale_lb": float(scale_lb), "sh_rest": rest}
+        num_rendered, color, depth, radii, geom, binning, img = _forward_impl(
+            K, m3, dc.reshape(-1, 1, 3), None, opc.reshape(-1), scc, rotc, None, viewm, projm, campos, raster_settings,
+            raw=raw)
+        ctx.raster_settings, ctx.num_rendered, ctx.K, ctx.scale_lb = raster_settings, num_rendered, K, float(scale_lb)
+        ctx.shapes = (f_dc.shape, None if f_rest is None else f_rest.shape, opacity.shape)
+        dummy = m3.new_empty(0)
+        ctx.save_for_backward(m3, dc, dummy if rest is None else rest, opc, scc, rotc, radii, geom, binning, img, viewm,
+                              projm, campos)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        return color, depth, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_out_depth, _):
+        rs, K = ctx.raster_settings, ctx.K
+        m3, dc, rest, opc, scc, rotc, radii, geom, binning, img, viewm, projm, campos = ctx.saved_tensors
+        rest = None if rest.numel() == 0 else rest
+        if grad_out_color is None and grad_out_depth is None:
+            return (None,) * 11
+        H, W = int(rs.image_height), int(rs.image_width)
+        device = m3.device
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((K, 3, H, W), dtype=torch.float32, device=device)
+        gc, gd = _f32c(grad_out_color), _f32c(grad_out_depth)
+        L = _lib.lib()
+        R = ctx.num_rendered
+        P = m3.shape[0]
+        Mr = 0 if rest is None else rest.shape[1]
+        f = dict(dtype=torch.float32, device=device)
+        # one flat gradient buffer, segments 16-byte aligned, in optimiser-group order
+        sizes = [3 * P, 3 * P, 3 * Mr * P, P, 3 * P, 4 * P]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + _align4(n))
+        flat = torch.empty(offs[-1], **f)
+        seg = lambda i, shape: flat[offs[i]:offs[i] + sizes[i]].view(shape)
+        g_xyz, g_dc, g_op, g_sc, g_rot = seg(0, (P, 3)), seg(1, (P, 1, 3)), seg(3, (P, 1)), seg(4, (P, 3)), seg(5, (P, 4))
+        g_rest = seg(2, (P, Mr, 3)) if Mr > 0 else None
+        g_means2D = torch.empty((K, P, 3), **f)
+        g_colors = torch.empty((P, 3), **f)
+        g_cov3D = torch.empty((P, 6), **f)
+        g_view, g_proj = torch.empty((K, 4, 4), **f), torch.empty((K, 4, 4), **f)
+        scratch = torch.empty(L.dgs_backward_scratch_bytes(R, P, K), dtype=torch.uint8, device=device)
+        io = _lib.DgsBackwardIO()
+        io.num_rendered = R
+        io.radii, io.dL_dout_color, io.dL_dout_depth = _ptr(radii), _ptr(gc), _ptr(gd)
+        io.scratch, io.scratch_bytes = _ptr(scratch), scratch.numel()
+        io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh, io.dL_dsh_rest = _ptr(g_xyz), _ptr(g_means2D), _ptr(g_dc), _ptr(g_rest)
+        io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations = _ptr(g_colors), _ptr(g_op), _ptr(g_sc), _ptr(g_rot)
+        io.dL_dcov3D, io.dL_dviewmatrix, io.dL_dprojmatrix = _ptr(g_cov3D), _ptr(g_view), _ptr(g_proj)
+        prob = _make_problem(K, m3, dc, None, opc.reshape(-1), scc, rotc, None, viewm, projm, campos, _RS(rs, device),
+                             geom, img, binning, getattr(R, "tile_cull", False),
+                             raw={"scale_lb": ctx.scale_lb, "sh_rest": rest})
+        prob.M = 1 + Mr
+        _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), _stream(device)), "dgs_backward")
+        if P == 0:
+            flat.zero_()
+            g_means2D.zero_()
+        dc_shape, rest_shape, op_shape = ctx.shapes
+        g_rest_out = g_rest.view(rest_shape) if g_rest is not None else (
+            None if rest_shape is None else flat.new_empty(rest_shape))
+        return (g_xyz, g_means2D, g_dc.view(dc_shape), g_rest_out,
+                g_op.view(op_shape), g_sc, g_rot, g_view, g_proj, None, None)
+
+
+def rasterize_cloud_subframes(xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, viewmatrices, projmatrices,
+                              raster_settings, scale_lb=0.0):
+    return _RasterizeCloudK.apply(xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, viewmatrices, projmatrices,
+                                  raster_settings, scale_lb)
 
 
 class GaussianRasterizer(nn.Module):

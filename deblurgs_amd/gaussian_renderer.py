@@ -11,7 +11,8 @@ import math
 
 import torch
 
-from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from .diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer,
+                                          rasterize_cloud_subframes)
 
 
 def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
@@ -97,6 +98,14 @@ def render_subframes(world_views, full_projs, camera_centers, ref_camera, pc, bg
         prefiltered=False,
         debug=False,
     )
+    if override_color is None and getattr(pc, "fused_activations", False):
+        # the cloud's activations (opacity clamp, exp(+lb) scale, quaternion normalise, dc|rest concat) run inside
+        # the kernels, forward and backward: no getter launches, gradients land on the raw parameters directly
+        images, depths, radii = rasterize_cloud_subframes(
+            pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation,
+            world_views, full_projs, raster_settings, pc.scale_lower_bound)
+        return {"render": images, "depth": depths, "viewspace_points": screenspace_points,
+                "visibility_filter": radii > 0, "radii": radii}
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     shs = None
     colors_precomp = None

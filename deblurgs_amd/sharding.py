@@ -46,16 +46,41 @@ def shard_range(K, rank, world):
     return (rank * K) // world, ((rank + 1) * K) // world
 
 
+def _shared_flat(grads):
+    """If the tensors are contiguous fp32 views of ONE storage that is (almost) covered by them -- the layout
+    _RasterizeCloudK.backward produces -- return the 1-D tensor spanning them, else None.  Alignment padding
+    between the segments is reduced along with the data (it is never read)."""
+    grads = [g for g in grads if g is not None and g.numel() > 0]
+    if len(grads) == 0 or any(g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+        return None
+    st = grads[0].untyped_storage()
+    if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in grads[1:]):
+        return None
+    lo = min(g.storage_offset() for g in grads)
+    hi = max(g.storage_offset() + g.numel() for g in grads)
+    if hi - lo > sum(g.numel() for g in grads) + 4 * len(grads):
+        return None
+    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (hi - lo,))
+
+
 def flat_allreduce_grads(params, average=False, group=None):
-    """Sum (or average) the .grad of `params` over ranks with ONE collective on a flat fp32 bucket."""
+    """Sum (or average) the .grad of `params` over ranks with ONE collective on a flat fp32 bucket.  Gradients that
+    already are views of one flat buffer are reduced in place (no packing copies); RCCL averages inside the
+    collective."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     params = [p for p in params if p is not None]
     grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
-    flat = torch.cat([g.reshape(-1).float() for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    if average:
-        flat /= dist.get_world_size(group)
+    shared = _shared_flat(grads) if all(p.grad is not None for p in params) else None
+    flat = shared if shared is not None else torch.cat([g.reshape(-1).float() for g in grads])
+    if average and dist.get_backend(group) == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= dist.get_world_size(group)
+    if shared is not None:
+        return
     off = 0
     for p, g in zip(params, grads):
         n = g.numel()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 2
+#define DGS_ABI_VERSION 3
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -60,9 +60,17 @@ typedef struct DgsProblem {
                         *    alpha >= 1/255 at any pixel of the tile (pairs the reference skips at every pixel,
                         *    forward.cu:356-358), so R is smaller and the outputs are unchanged.  Must be the same
                         *    in the forward and backward calls of one problem. */
+  int32_t raw_params;  /* 0: opacities / scales / rotations / shs are activated values, as the reference's render() passes
+                        *    them (gaussian_renderer/__init__.py:60-77).  1: they are the cloud's raw parameters and the
+                        *    kernels apply the reference's activations themselves (scene/gaussian_model.py:36-50,
+                        *    scene/gaussian_activation.py): opacity clamp(x, 0, 1), scale exp(x) + scale_lb, rotation
+                        *    x / max(|x|, 1e-12), SH = [shs (dc, [P,1,3]) | shs_rest ([P,M-1,3])]; the backward then
+                        *    returns gradients with respect to the raw parameters. */
+  float scale_lb;
   /* inputs, device pointers, fp32 contiguous */
   const float* means3D;        /* [P,3] */
   const float* shs;            /* [P,M,3] or NULL */
+  const float* shs_rest;       /* raw_params = 1 only: [P,M-1,3] (then shs is [P,1,3]); else NULL */
   const float* colors_precomp; /* [P,3]   or NULL   (exactly one of shs / colors_precomp) */
   const float* opacities;      /* [P] */
   const float* scales;         /* [P,3] or NULL */
@@ -97,7 +105,8 @@ typedef struct DgsBackwardIO {
    * consume them per subframe (train.py:188-193, scene/motion.py:248-294). */
   float* dL_dmeans3D;  /* [P,3] */
   float* dL_dmeans2D;  /* [K,P,3] NDC-scaled screen gradient, .z = 0 (backward.cu:628-629) */
-  float* dL_dsh;       /* [P,M,3]  (NULL when colors_precomp was used) */
+  float* dL_dsh;       /* [P,M,3]  (NULL when colors_precomp was used); [P,1,3] with raw_params */
+  float* dL_dsh_rest;  /* raw_params = 1 only: [P,M-1,3] */
   float* dL_dcolors;   /* [P,3]    (written always; the grad of colors_precomp when that was used) */
   float* dL_dopacity;  /* [P] */
   float* dL_dscales;   /* [P,3]  (NULL when cov3D_precomp was used) */

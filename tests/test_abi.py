@@ -39,10 +39,10 @@ def test_no_torch_types_in_the_abi():
 
 def test_struct_sizes_match_the_header_layout():
     from deblurgs_amd import _lib
-    # 6 ints + 5 floats + 4 ints = 60 bytes (+4 padding), then 11 pointers, then 3 x (pointer + size_t)
-    assert ctypes.sizeof(_lib.DgsProblem) == 64 + 11 * 8 + 3 * 16
+    # 6 ints + 5 floats + 5 ints + 1 float = 68 bytes (+4 padding), then 12 pointers, then 3 x (pointer + size_t)
+    assert ctypes.sizeof(_lib.DgsProblem) == 72 + 12 * 8 + 3 * 16
     assert ctypes.sizeof(_lib.DgsForwardOut) == 32
-    assert ctypes.sizeof(_lib.DgsBackwardIO) == 8 + 8 * 3 + 16 + 10 * 8
+    assert ctypes.sizeof(_lib.DgsBackwardIO) == 8 + 8 * 3 + 16 + 11 * 8
     assert ctypes.sizeof(_lib.DgsLayout) == 27 * 8 + 8
 
 

@@ -263,3 +263,59 @@ def test_training_loop_with_densification_and_fused_adam(gpu):
     assert cloud.xyz_gradient_accum.shape == (P, 1) and cloud.max_radii2D.shape == (P,)
     assert cloud.optimizer.state[m._nu]["step"] > 0 and cloud.optimizer.state[m._trans._control_points]["step"] > 0
     assert min(hist[-5:]) < 0.6 * max(hist[4:9]), (hist[4:9], hist[-5:])
+
+
+@pytest.mark.parametrize("deg,scale_lb", [(2, 0.0), (2, 0.003), (0, 0.0), (3, 0.0)])
+def test_fused_activations_equal_the_getter_path(gpu, deg, scale_lb):
+    """render_subframes() with the cloud's activations folded into the kernels (DgsProblem.raw_params) against the
+    reference's arrangement (get_opacity / get_scaling / get_rotation / get_features evaluated by torch, their
+    backward by autograd): same images, same gradients on the RAW parameters, including clamped opacities (zero
+    gradient outside [0, 1]), non-unit quaternions and the dc / rest split of the SH tensor."""
+    import torch
+    from helpers import synthetic
+    from deblurgs_amd.cloud import GaussianCloud
+    from deblurgs_amd.motion import RefCamera
+    from deblurgs_amd import gaussian_renderer
+    from deblurgs_amd.sharding import _shared_flat
+    K = 3
+    sc = synthetic.make_scene(2500, 144, 96, K=K, seed=31, sigma_px=2.5, sh_degree=deg)
+    ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device="cuda")
+    t = lambda a: torch.tensor(a, device="cuda")
+    rng = np.random.default_rng(1)
+    gC = t(rng.normal(size=(K, 3, sc["H"], sc["W"])).astype(np.float32))
+    gD = t(rng.normal(size=(K, 1, sc["H"], sc["W"])).astype(np.float32) * 0.01)
+    out = {}
+    for fused in (False, True):
+        cloud = GaussianCloud.from_scene(sc, "cuda")
+        cloud.scaling_activation.lower_bound = scale_lb
+        cloud.scale_lower_bound = scale_lb
+        with torch.no_grad():
+            cloud._rotation.mul_(t(rng.uniform(0.3, 3.0, (sc["P"], 1)).astype(np.float32)) if fused is False else 1.0)
+            cloud._opacity[::7] = 1.2          # clamped from above
+            cloud._opacity[3::11] = -0.1       # clamped from below (invisible)
+        if fused:   # same raw values as the unfused run
+            cloud._rotation.data.copy_(out["rot_raw"])
+        else:
+            out["rot_raw"] = cloud._rotation.detach().clone()
+        cloud.fused_activations = fused
+        wv, fp, cc = (t(sc[k][:K]).requires_grad_(k != "campos") for k in ("viewmatrix", "projmatrix", "campos"))
+        pkg = gaussian_renderer.render_subframes(wv, fp, cc, ref, cloud, t(sc["bg"]))
+        (pkg["render"] * gC).sum().add((pkg["depth"] * gD).sum()).backward()
+        grads = [p.grad for p in cloud.hot_parameters()]
+        if fused:
+            assert _shared_flat(grads) is not None, "raw-parameter gradients must be views of one flat buffer"
+        out[fused] = dict(img=pkg["render"].detach().cpu().numpy(), depth=pkg["depth"].detach().cpu().numpy(),
+                          radii=pkg["radii"].cpu().numpy(), g=[g.cpu().numpy() for g in grads],
+                          view=wv.grad.cpu().numpy(), proj=fp.grad.cpu().numpy(),
+                          m2d=pkg["viewspace_points"].grad.cpu().numpy())
+    a, b = out[False], out[True]
+    assert (a["radii"] != b["radii"]).mean() < 1e-3          # exp() may differ by an ulp between torch and the kernel
+    assert np.abs(a["img"] - b["img"]).max() < 2e-5 and np.abs(a["depth"] - b["depth"]).max() < 2e-3
+    names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    for n, ga, gb in zip(names, a["g"], b["g"]):
+        assert ga.shape == gb.shape, n
+        if ga.size:
+            assert np.abs(ga - gb).max() <= 2e-5 * (np.abs(ga).max() + 1e-30), (n, np.abs(ga - gb).max(), np.abs(ga).max())
+    assert not b["g"][3][::7].any() and not b["g"][3][3::11].any()      # clamp: no gradient outside [0, 1]
+    for key in ("view", "proj", "m2d"):
+        assert np.abs(a[key] - b[key]).max() <= 2e-5 * np.abs(a[key]).max(), key

@@ -110,6 +110,26 @@ def _worker_views(rank, world, port, out):
     sharding.flat_allreduce_grads(params, average=True)
     if rank == 0:
         torch.save([p.grad.clone() for p in params], out)
+    # the same gradients laid out as views of one padded flat buffer (what the fused-activation operator returns)
+    # must be reduced in place, without re-binding .grad
+    torch.manual_seed(200 + rank)
+    flat = torch.full((64 + 4 + 8,), float("nan"))
+    views = [flat[0:60].view(20, 3), flat[64:71]]
+    for v_, p in zip(views, params):
+        v_.copy_(torch.randn_like(p))
+    mine = [v_.clone() for v_ in views]
+    for v_, p in zip(views, params):
+        p.grad = v_
+    keep = [p.grad for p in params]
+    sharding.flat_allreduce_grads(params, average=True)
+    assert all(p.grad is k for p, k in zip(params, keep)), "shared-storage gradients must be reduced in place"
+    assert sharding._shared_flat(keep) is not None
+    gathered = [torch.zeros_like(m) for m in mine]
+    for g_, m in zip(gathered, mine):
+        g_.copy_(m)
+        dist.all_reduce(g_)
+        g_ /= world
+    assert all(torch.allclose(p.grad, g_, atol=1e-7) for p, g_ in zip(params, gathered))
     dist.barrier()
     dist.destroy_process_group()
 
