@@ -214,37 +214,65 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
   float l1 = 0.0f, sm = 0.0f;
   if (e < E) {
     auto ld = [](const float* p) { return *reinterpret_cast<const vec*>(p); };
-    vec acc = ld(sub + e);
-    for (int k = 1; k < K; k++) acc += ld(sub + (size_t)k * E + e);
-    const vec b = acc / (float)K;
-    if (MODE != 1) *reinterpret_cast<vec*>(blur + e) = b;
-    const vec d = b - ld(gt + e);
-    const float up = (MODE != 0 && scale != nullptr) ? scale[0] : 1.0f;
-    const float c_l1 = up / ((float)E * (float)K);
-    const float ws = (K > 1) ? up * lambda_t / ((float)E * (float)(K - 1)) : 0.0f;
-    vec g_l1;
-#pragma unroll
-    for (int i = 0; i < V; i++) {
-      l1 += fabsf(d[i]);
-      g_l1[i] = c_l1 * sgn(d[i]);
-    }
-    vec prev = ld(sub + e);
-    vec s_prev = (vec)(0.0f);  // sign(x_k - x_{k-1})
-    for (int k = 0; k < K; k++) {
-      vec s_next = (vec)(0.0f);
-      vec nxt = prev;
-      if (k + 1 < K) {
-        nxt = ld(sub + (size_t)(k + 1) * E + e);
+    if (MODE == 0) {
+      // forward: ONE pass over the K subframes (sum for the blur and the adjacent differences together), unrolled so
+      // that several 16-byte loads per lane are in flight
+      vec prev = ld(sub + e);
+      vec acc = prev;
+#pragma unroll 4
+      for (int k = 1; k < K; k++) {
+        const vec nxt = ld(sub + (size_t)k * E + e);
         const vec dd = nxt - prev;
+        acc += nxt;
 #pragma unroll
-        for (int i = 0; i < V; i++) {
-          sm += fabsf(dd[i]);
-          s_next[i] = sgn(dd[i]);
-        }
+        for (int i = 0; i < V; i++) sm += fabsf(dd[i]);
+        prev = nxt;
       }
-      if (MODE != 0) *reinterpret_cast<vec*>(dsub + (size_t)k * E + e) = g_l1 + ws * (s_prev - s_next);
-      s_prev = s_next;
-      prev = nxt;
+      const vec b = acc / (float)K;
+      *reinterpret_cast<vec*>(blur + e) = b;
+      const vec d = b - ld(gt + e);
+#pragma unroll
+      for (int i = 0; i < V; i++) l1 += fabsf(d[i]);
+    } else {
+      vec b;
+      if (MODE == 1 && blur != nullptr) {
+        b = ld(blur + e);   // backward: the forward's blur is handed back in, no second summation
+      } else {
+        vec acc = ld(sub + e);
+#pragma unroll 4
+        for (int k = 1; k < K; k++) acc += ld(sub + (size_t)k * E + e);
+        b = acc / (float)K;
+        if (MODE == 2) *reinterpret_cast<vec*>(blur + e) = b;
+      }
+      const vec d = b - ld(gt + e);
+      const float up = (scale != nullptr) ? scale[0] : 1.0f;
+      const float c_l1 = up / ((float)E * (float)K);
+      const float ws = (K > 1) ? up * lambda_t / ((float)E * (float)(K - 1)) : 0.0f;
+      vec g_l1;
+#pragma unroll
+      for (int i = 0; i < V; i++) {
+        l1 += fabsf(d[i]);
+        g_l1[i] = c_l1 * sgn(d[i]);
+      }
+      vec prev = ld(sub + e);
+      vec s_prev = (vec)(0.0f);  // sign(x_k - x_{k-1})
+#pragma unroll 4
+      for (int k = 0; k < K; k++) {
+        vec s_next = (vec)(0.0f);
+        vec nxt = prev;
+        if (k + 1 < K) {
+          nxt = ld(sub + (size_t)(k + 1) * E + e);
+          const vec dd = nxt - prev;
+#pragma unroll
+          for (int i = 0; i < V; i++) {
+            sm += fabsf(dd[i]);
+            s_next[i] = sgn(dd[i]);
+          }
+        }
+        *reinterpret_cast<vec*>(dsub + (size_t)k * E + e) = g_l1 + ws * (s_prev - s_next);
+        s_prev = s_next;
+        prev = nxt;
+      }
     }
   }
   if (MODE == 1) return;
@@ -529,8 +557,10 @@ int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t*
 int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW, float lambda_t,
                        const float* upstream, float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream) {
   const bool fwd = (blur != nullptr && losses != nullptr);
+  // losses given: blur is an output (forward, or forward + backward when dL_dsubframes is given too);
+  // losses NULL: backward only, blur (optional) is the forward's blur handed back in
   if (subframes == nullptr || gt == nullptr || K < 1 || C < 1 || HW < 1 || (!fwd && dL_dsubframes == nullptr) ||
-      ((blur == nullptr) != (losses == nullptr)))
+      (losses != nullptr && blur == nullptr))
     return fail(DGS_E_ARG, "blur_loss_grad: bad argument");
   hipError_t e = dgs_launch_blur_loss(subframes, gt, K, C, HW, lambda_t, upstream, blur, dL_dsubframes, losses,
                                       reinterpret_cast<hipStream_t>(stream));

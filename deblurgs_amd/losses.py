@@ -87,7 +87,7 @@ class _BlurL1Smooth(torch.autograd.Function):
         st = ctypes.c_void_p(torch.cuda.current_stream(sub.device).cuda_stream)
         _lib.check(_lib.lib().dgs_blur_loss_grad(sub.data_ptr(), g.data_ptr(), K, C, HW, float(lambda_t), None,
                                                  blur.data_ptr(), None, losses.data_ptr(), st), "dgs_blur_loss_grad")
-        ctx.save_for_backward(sub, g)
+        ctx.save_for_backward(sub, g, blur)
         ctx.lambda_t = float(lambda_t)
         total = losses[0] + float(lambda_t) * losses[1]
         ctx.mark_non_differentiable(blur, losses)
@@ -95,14 +95,14 @@ class _BlurL1Smooth(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_blur, _g_losses):
-        sub, g = ctx.saved_tensors
+        sub, g, blur = ctx.saved_tensors
         K, C = sub.shape[0], sub.shape[1]
         HW = sub[0, 0].numel()
         dsub = torch.empty_like(sub)
         up = g_total.detach().float().reshape(1).contiguous()     # device scalar: read by the kernel, no sync
         st = ctypes.c_void_p(torch.cuda.current_stream(sub.device).cuda_stream)
         _lib.check(_lib.lib().dgs_blur_loss_grad(sub.data_ptr(), g.data_ptr(), K, C, HW, ctx.lambda_t, up.data_ptr(),
-                                                 None, dsub.data_ptr(), None, st), "dgs_blur_loss_grad")
+                                                 blur.data_ptr(), dsub.data_ptr(), None, st), "dgs_blur_loss_grad")
         return dsub, None, None
 
 

@@ -191,8 +191,9 @@ int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t*
 
 /* Fused loss-gradient image (train.py:143-165, utils/loss_utils.py:17-18,80-93): from the K rendered subframes
  * and the target, produces blur = mean_k, the L1 and temporal-smoothness loss values (losses = {l1, smooth}) and/or
- * dL/dsubframes in one pass.  Forward call: blur + losses non-null, dL_dsubframes NULL.  Backward call: blur and
- * losses NULL, dL_dsubframes non-null, `upstream` = device pointer to the scalar dL/d(l1 + lambda_t*smooth) (NULL = 1).
+ * dL/dsubframes in one pass.  Forward call: blur + losses non-null, dL_dsubframes NULL.  Backward call: losses
+ * NULL, dL_dsubframes non-null, `upstream` = device pointer to the scalar dL/d(l1 + lambda_t*smooth) (NULL = 1); blur
+ * is then an optional INPUT (the forward call's blur, which saves re-summing the K subframes; NULL = recompute).
  * All three outputs non-null computes everything at once. */
 int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW, float lambda_t,
                        const float* upstream, float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream);
