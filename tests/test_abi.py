@@ -112,3 +112,38 @@ def test_product_has_no_cpu_fallback():
                                rotations=torch.ones(4, 4), viewmatrix=torch.eye(4), projmatrix=torch.eye(4))
     with pytest.raises(Exception, match="excatly one"):
         GaussianRasterizer(rs)(m, m, torch.ones(4, 1), scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+
+
+def test_argument_checks_of_the_training_side_entry_points_need_no_gpu():
+    """Bad arguments are rejected before any HIP call, with a message in dgs_last_error()."""
+    from deblurgs_amd import _lib
+    L = _lib.lib()
+    g = (_lib.DgsAdamGroup * 1)(_lib.DgsAdamGroup(None, 16, None, None, 8, 1e-3, 1))
+    assert L.dgs_adam_step(g, _lib.ADAM_MAX_GROUPS + 1, 0.9, 0.999, 1e-15, 0.0, None) != 0
+    assert b"groups" in L.dgs_last_error()
+    assert L.dgs_adam_step(g, 1, 0.9, 0.999, 1e-15, 0.0, None) != 0          # grad given but null state pointers
+    g[0].grad = None
+    assert L.dgs_adam_step(g, 1, 0.9, 0.999, 1e-15, 0.0, None) == 0          # no gradient: the group is skipped
+    assert L.dgs_adam_step(None, 0, 0.9, 0.999, 1e-15, 0.0, None) == 0
+    assert L.dgs_knn_mean_dist2(-1, None, None, None, None) != 0
+    assert L.dgs_knn_mean_dist2(0, None, None, None, None) == 0
+    assert L.dgs_knn_tmp_bytes(1000) > 1000 * 40
+    assert L.dgs_densify_tmp_bytes(1000) >= 256
+    assert L.dgs_densify_plan(5, None, None, None, None, 0.0, 0.0, 0.0, 0.0, None, None, None, None, None, None) != 0
+    assert L.dgs_densify_apply(-1, 0, None, None, None, None, None, None, 0.0, None) != 0
+    p = _lib.DgsProblem()
+    p.P, p.W, p.H, p.K, p.D, p.M = 10, 32, 32, 1, 0, 1
+    for name in ("means3D", "opacities", "shs", "viewmatrix", "projmatrix", "campos", "bg"):
+        setattr(p, name, 16)                      # non-null dummies: only the argument logic is exercised
+    p.cov3D_precomp = 16                          # a precomputed covariance is valid on its own ...
+    p.raw_params = 1                              # ... but raw parameters need scales + rotations
+    out = _lib.DgsForwardOut()
+    import ctypes
+    host = (ctypes.c_uint32 * 2)()
+    out.num_rendered_host = ctypes.cast(host, ctypes.c_void_p)
+    assert L.dgs_forward_geometry(ctypes.byref(p), ctypes.byref(out), None) != 0
+    assert b"raw_params" in L.dgs_last_error()
+    p.raw_params = 0
+    p.shs_rest = 16
+    assert L.dgs_forward_geometry(ctypes.byref(p), ctypes.byref(out), None) != 0
+    assert b"shs_rest" in L.dgs_last_error()
