@@ -210,6 +210,16 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   const float qx0 = (float)(t.tx * DGS_TILE), qy0 = (float)(t.ty * DGS_TILE);
   const size_t N = (size_t)v.W * v.H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  // contribution-row slot this lane stores after the per-duplicate reduce-scatter (-1: none); slots are
+  // [S_wx, S_wy, S_xx, S_xy, S_yy, S_w, r, g, b, depth]
+  int wslot = -1;
+  if ((lane & 3) == 0) {
+    const int rr = lane >> 4, bank = (lane & 15) >> 2;
+    if (bank == 0) wslot = (rr == 0) ? 0 : (rr == 1) ? 2 : (rr == 2) ? 1 : 3;
+    if (bank == 2) wslot = (rr == 0) ? 4 : (rr == 1) ? 6 : (rr == 2) ? 5 : 7;
+    if (bank == 1 && rr == 0) wslot = 8;
+    if (bank == 1 && rr == 2) wslot = 9;
+  }
   
 
   // per-pixel channel state kept as (r,g) and (b,depth) pairs so the channel arithmetic issues as packed fp32
@@ -363,25 +373,19 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         }
       }
       {  // (every dup that reaches here passed the quadrant test for >= 1 quadrant; 98 % of those passes contribute)
-        // 10 wave sums as a reduce-scatter: two fold levels (v_permlane32_swap / v_permlane16_swap) halve the
-        // number of live registers each, then 4 row-DPP steps finish 4 values per register: 27 VALU ops instead
-        // of 60 for ten independent butterflies.  Row r of the result registers holds:
-        //   ua: (S_wx, S_xx, S_wy, S_xy)   ub: (S_yy, sA.x, S_w, sA.y)   uc: rows 1,3 = (sB.x, sB.y)
-        float ua = dgs_row_sum(dgs_fold16(dgs_fold32(S_wx, S_wy), dgs_fold32(S_xx, S_xy)));
-        float ub = dgs_row_sum(dgs_fold16(dgs_fold32(S_yy, S_w), dgs_fold32(sA.x, sA.y)));
-        float uc = dgs_row_sum(dgs_fold32(sB.x, sB.y));
-        uc += dgs_dpp<0x142, 0xa>(uc);  // row_bcast15: row1 += row0, row3 += row2
-        asm volatile("" : "+v"(ua), "+v"(ub), "+v"(uc));  // finish the DPP adds here, not inside the lane-0 branch
-        if ((lane & 15) == 0) {
-          const int r = lane >> 4;
-          float* acc = reinterpret_cast<float*>(&s_acc[w][j][0]);
-          // row r of ua holds value index {0:S_wx, 1:S_xx, 2:S_wy, 3:S_xy}[r] -> contribution-row slots
-          const int slot_a = (r == 0) ? 0 : (r == 1) ? 2 : (r == 2) ? 1 : 3;  // [S_wx, S_wy, S_xx, S_xy, ...]
-          const int slot_b = (r == 0) ? 4 : (r == 1) ? 6 : (r == 2) ? 5 : 7;  // [..., S_yy, S_w, r, g, ...]
-          acc[slot_a] = ua;
-          acc[slot_b] = ub;
-          if (r & 1) acc[8 + (r >> 1)] = uc;                                  // [..., b, depth]
-        }
+        // 10 wave sums as a reduce-scatter: every fold level halves the number of live registers -- v_permlane32_swap
+        // (half waves), v_permlane16_swap (rows), then bank-masked DPP adds inside the rows (8 lanes, 4 lanes) and a
+        // quad sum: 23 VALU ops instead of 60 for ten independent butterflies.  After it, in row r of the wave,
+        //   lanes 0-3  hold (S_wx, S_xx, S_wy, S_xy)[r],  lanes 8-11 hold (S_yy, sA.x, S_w, sA.y)[r],
+        //   lanes 4-7  hold sB.x (rows 0, 1) or sB.y (rows 2, 3),
+        // and one lane of each of those quads stores its value into the duplicate's LDS row (wslot, set up once).
+        const float ua = dgs_fold16(dgs_fold32(S_wx, S_wy), dgs_fold32(S_xx, S_xy));
+        const float ub = dgs_fold16(dgs_fold32(S_yy, S_w), dgs_fold32(sA.x, sA.y));
+        const float r4 = dgs_fold32(sB.x, sB.y);
+        float uc = dgs_fold16(r4, r4);
+        uc += dgs_dpp<0x128, 0xf>(uc);  // row_ror:8
+        const float tot = dgs_quad_sum(dgs_fold4(dgs_fold8(ua, ub), uc));
+        if (wslot >= 0) reinterpret_cast<float*>(&s_acc[w][j][0])[wslot] = tot;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
