@@ -384,7 +384,8 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         const float r4 = dgs_fold32(sB.x, sB.y);
         float uc = dgs_fold16(r4, r4);
         uc += dgs_dpp<0x128, 0xf>(uc);  // row_ror:8
-        const float tot = dgs_quad_sum(dgs_fold4(dgs_fold8(ua, ub), uc));
+        float tot = dgs_quad_sum(dgs_fold4(dgs_fold8(ua, ub), uc));
+        asm volatile("" : "+v"(tot));  // finish the last DPP add here, not inside the store's exec branch
         if (wslot >= 0) reinterpret_cast<float*>(&s_acc[w][j][0])[wslot] = tot;
       }
     }
