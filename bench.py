@@ -242,6 +242,18 @@ def main():
                     result["roofline"]["traffic"] = tr[dom]
             except Exception:
                 pass
+        valu_file = os.path.join(ROOT, "profiles", "valu_r01.json")
+        if os.path.exists(valu_file) and args.config == "metric":
+            try:
+                vv = json.load(open(valu_file))
+                hit = [v_ for k_, v_ in vv.items() if k_.startswith(dom + "_kernel")]
+                if hit:
+                    result["roofline"]["valu"] = {
+                        "insts_per_launch": hit[0]["valu_insts"], "ipc_per_simd": hit[0]["ipc_per_simd"],
+                        "practical_peak_ipc_per_simd": 0.37,
+                        "note": "rocprofv3 PMC SQ_INSTS_VALU (profiles/valu_r01.json); peak = tools/valu_rate.hip at 8 waves/SIMD"}
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(scene, K // 2)
         print(json.dumps(result), flush=True)

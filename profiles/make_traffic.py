@@ -27,7 +27,8 @@ STREAMING = {"blur_loss", "sort(hist)", "sort(scatter)", "adam"}
 
 def per_kernel(d, counter):
     tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:      # the newest pass only (gpurun merges, it does not replace, earlier passes' files)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
