@@ -31,11 +31,18 @@ def init_distributed(device_type="cuda"):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        # DGS_DIST_BACKEND=gloo and DGS_DIST_ONE_DEVICE=1 let the N-rank code path run on a box with ONE GPU
+        # (all ranks on cuda:0, collectives staged through the host): a functional check, not a measurement
+        backend = os.environ.get("DGS_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+        if os.environ.get("DGS_DIST_ONE_DEVICE", "0") == "1":
+            local_rank = 0
         if device_type == "cuda":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            if backend == "nccl":
+                dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
