@@ -670,6 +670,7 @@ FUZZ = [
     (900, 130, 97, 2, 106, 1.0, 1, {"sh_degree": 1}),
     (3000, 96, 96, 7, 107, 2.0, 2, {"sh_degree": 0}),
     (700, 31, 33, 16, 108, 2.0, 2, {}),                      # many subframes
+    (500, 48, 32, 40, 109, 2.0, 2, {}),                      # more subframes than the reference ever uses (K <= 128)
 ]
 
 
