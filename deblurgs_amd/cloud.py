@@ -92,6 +92,26 @@ class GaussianCloud(nn.Module):
         """The per-Gaussian tensors whose gradients the sharded loop all-reduces."""
         return [self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation]
 
+    # ------------------------------------------------------------------ checkpoints (scene/gaussian_model.py:80-112)
+    def capture(self):
+        """The reference's checkpoint tuple, field for field (train.py:214-216 saves (capture(), iteration))."""
+        return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+                self._opacity, self.max_radii2D, self.xyz_gradient_accum, self.denom, self.optimizer.state_dict(),
+                self.spatial_lr_scale)
+
+    def restore(self, model_args, training_args, fused=True):
+        (self.active_sh_degree, xyz, f_dc, f_rest, scaling, rotation, opacity, self.max_radii2D, xyz_gradient_accum,
+         denom, opt_dict, spatial_lr_scale) = model_args
+        dev = self._xyz.device
+        as_param = lambda t: nn.Parameter(t.detach().to(dev).float().contiguous().requires_grad_(True))
+        (self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+         self._opacity) = (as_param(t) for t in (xyz, f_dc, f_rest, scaling, rotation, opacity))
+        self.training_setup(training_args, spatial_lr_scale=spatial_lr_scale, fused=fused)
+        self.max_radii2D = self.max_radii2D.to(dev)
+        self.xyz_gradient_accum = xyz_gradient_accum.to(dev)
+        self.denom = denom.to(dev)
+        self.optimizer.load_state_dict(opt_dict)
+
     # ------------------------------------------------------------------ training side (SURVEY 8f, f3)
     def _named(self):
         return dict(zip(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"), self.hot_parameters()))

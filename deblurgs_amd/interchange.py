@@ -127,6 +127,11 @@ def load_checkpoint(path: str, device="cuda", **cloud_kw):
     return cloud, iteration, extras
 
 
+def save_checkpoint(cloud: GaussianCloud, iteration: int, path: str):
+    """train.py:214-216: torch.save((gaussians.capture(), iteration), model_path + "/chkpnt<it>.pth")."""
+    torch.save((cloud.capture(), iteration), path)
+
+
 def save_camera_motion(module, path: str):
     """scene/motion.py:337-350."""
     assert path.endswith(".pth")

@@ -95,6 +95,24 @@ def flat_allreduce_grads(params, average=False, group=None):
         off += n
 
 
+def allreduce_densification_stats(cloud, prev, group=None):
+    """Data-parallel runs must densify identically on every rank, so the densification statistics each rank gathered
+    from ITS view since the last synchronisation are combined first (determinism caveat): the increments
+    of xyz_gradient_accum and denom are summed over ranks, max_radii2D is maximised.  `prev` = (accum, denom)
+    snapshots taken right after the previous call (or zeros); returns the new snapshots."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return cloud.xyz_gradient_accum.clone(), cloud.denom.clone()
+    d_acc = cloud.xyz_gradient_accum - prev[0]
+    d_den = cloud.denom - prev[1]
+    buf = torch.cat([d_acc.reshape(-1), d_den.reshape(-1)])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    n = d_acc.numel()
+    cloud.xyz_gradient_accum = prev[0] + buf[:n].view_as(d_acc)
+    cloud.denom = prev[1] + buf[n:].view_as(d_den)
+    dist.all_reduce(cloud.max_radii2D, op=dist.ReduceOp.MAX, group=group)
+    return cloud.xyz_gradient_accum.clone(), cloud.denom.clone()
+
+
 def _sgn(x):
     return torch.sign(x)
 

@@ -171,3 +171,31 @@ def test_view_sharding_averages_gradients(tmp_path):
         acc = g if acc is None else [a + b for a, b in zip(acc, g)]
     for a, b in zip(got, acc):
         assert torch.allclose(a, b / 2, atol=1e-6)
+
+
+def _worker_stats(rank, world, port, out):
+    sharding = _setup(rank, world, port)
+    import types
+    cloud = types.SimpleNamespace(xyz_gradient_accum=torch.full((6, 1), 10.0), denom=torch.full((6, 1), 3.0),
+                                  max_radii2D=torch.zeros(6))
+    prev = (cloud.xyz_gradient_accum.clone(), cloud.denom.clone())
+    # each rank accumulates the statistics of its own view
+    cloud.xyz_gradient_accum += torch.arange(6.0).reshape(6, 1) * (rank + 1)
+    cloud.denom[rank::2] += 1.0
+    cloud.max_radii2D[rank] = 7.0 + rank
+    new_prev = sharding.allreduce_densification_stats(cloud, prev)
+    assert torch.allclose(cloud.xyz_gradient_accum, 10.0 + torch.arange(6.0).reshape(6, 1) * 3)
+    assert torch.allclose(cloud.denom, torch.full((6, 1), 4.0))
+    assert cloud.max_radii2D[0] == 7.0 and cloud.max_radii2D[1] == 8.0
+    assert torch.equal(new_prev[0], cloud.xyz_gradient_accum)
+    if rank == 0:
+        torch.save(True, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_densification_stats_are_combined_across_ranks(tmp_path):
+    """SURVEY 8e determinism caveat: replicas only densify identically if the statistics are all-reduced first."""
+    out = str(tmp_path / "stats.pt")
+    mp.spawn(_worker_stats, args=(2, 29655, out), nprocs=2, join=True)
+    assert torch.load(out) is True

@@ -64,3 +64,31 @@ def test_checkpoint_and_camera_motion_round_trip(tmp_path):
     a = m.get_trajectory_matrices(2, fused=False)
     b = m2.get_trajectory_matrices(2, fused=False)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_capture_restore_round_trip(tmp_path):
+    """GaussianCloud.capture() is the reference's checkpoint tuple; restore() rebuilds the cloud, its optimiser
+    groups and the optimiser state from it (scene/gaussian_model.py:80-112)."""
+    import types
+    from deblurgs_amd import interchange
+    cloud = _cloud(40, 2)
+    targs = types.SimpleNamespace(iterations=1000, position_lr_init=1.6e-4, position_lr_final=1.6e-6, feature_lr=2.5e-3,
+                                  opacity_lr=0.05, scaling_lr=5e-3, rotation_lr=1e-3, percent_dense=0.01)
+    cloud.training_setup(targs, spatial_lr_scale=2.0, fused=False)      # torch Adam: this test runs on the CPU
+    for p in cloud.hot_parameters():
+        p.grad = torch.randn_like(p) * 1e-2
+    cloud.optimizer.step()
+    cloud.xyz_gradient_accum += 0.5
+    path = str(tmp_path / "chkpnt30.pth")
+    interchange.save_checkpoint(cloud, 30, path)
+    tup, it = torch.load(path, weights_only=False)
+    assert it == 30 and len(tup) == 12 and tup[0] == cloud.active_sh_degree and tup[11] == 2.0
+    other = _cloud(40, 2, seed=5)
+    other.restore(tup, targs, fused=False)
+    for a, b in zip(cloud.hot_parameters(), other.hot_parameters()):
+        assert torch.equal(a, b)
+        sa, sb = cloud.optimizer.state[a], other.optimizer.state[b]
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and float(sa["step"]) == float(sb["step"])
+    assert torch.equal(other.xyz_gradient_accum, cloud.xyz_gradient_accum) and other.spatial_lr_scale == 2.0
+    back, it2, extras = interchange.load_checkpoint(path, device="cpu")
+    assert it2 == 30 and torch.equal(back._xyz, cloud._xyz) and extras["spatial_lr_scale"] == 2.0
