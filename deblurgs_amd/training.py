@@ -26,8 +26,14 @@ def default_optimization_params(**overrides):
 
 
 class TrainingLoop:
-    def __init__(self, gaussians, cam_motion_module, opt, cameras_extent, white_background=False, spatial_lr_scale=None):
+    def __init__(self, gaussians, cam_motion_module, opt, cameras_extent, white_background=False, spatial_lr_scale=None,
+                 distributed=False):
+        """distributed=True ("views" sharding, deblurgs_amd.sharding): every rank steps on its own view; the
+        per-Gaussian gradients are averaged over ranks before the Adam step and the densification statistics are
+        combined before every densify_and_prune, so the replicas stay identical."""
         self.gaussians, self.motion, self.opt, self.extent = gaussians, cam_motion_module, opt, cameras_extent
+        self.distributed = distributed
+        self._stat_prev = None
         self.white_background = white_background
         gaussians.training_setup(opt, spatial_lr_scale=cameras_extent if spatial_lr_scale is None else spatial_lr_scale)
         cam_motion_module.link_gaussian(gaussians)
@@ -62,11 +68,19 @@ class TrainingLoop:
         if opt.lambda_depth_tv > 0.0:
             loss = loss + opt.lambda_depth_tv * losses.tv_loss(r["depths"])
         loss.backward()
+        if self.distributed:
+            from . import sharding
+            sharding.flat_allreduce_grads(g.hot_parameters(), average=True)
         with torch.no_grad():
             if iteration < opt.densify_until_iter:
+                if self.distributed and self._stat_prev is None:
+                    self._stat_prev = (g.xyz_gradient_accum.clone(), g.denom.clone())
                 add_densification_stats_subframes(r["viewspace_points_all"], r["radii_all"], g.max_radii2D,
                                                   g.xyz_gradient_accum, g.denom)
                 if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+                    if self.distributed:
+                        sharding.allreduce_densification_stats(g, self._stat_prev)
+                        self._stat_prev = None          # densify_and_prune resets the statistics to zeros
                     g.densify_and_prune(densification_threshold, self.extent)
                 if iteration % opt.opacity_reset_interval == 0 or (self.white_background and
                                                                    iteration == opt.densify_from_iter):
