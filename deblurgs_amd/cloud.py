@@ -194,7 +194,7 @@ class GaussianCloud(nn.Module):
         self._set_named(tensors)
 
     @torch.no_grad()
-    def densify_and_prune(self, max_grad, extent, noise=None):
+    def densify_and_prune(self, max_grad, extent, noise=None, generator=None):
         """scene/gaussian_model.py:436-448 in three kernels + four scans.  `noise` ([2 m, 3] standard normals for
         the m split-selected Gaussians x 2 copies) is drawn here when absent (the reference's torch.normal)."""
         from . import optim
@@ -203,7 +203,7 @@ class GaussianCloud(nn.Module):
                                                  self._opacity.detach(), max_grad, self.percent_dense * extent,
                                                  min_opacity, self.scale_lower_bound)
         if noise is None:
-            noise = torch.randn((2 * counts[3], 3), device=self._xyz.device)
+            noise = torch.randn((2 * counts[3], 3), device=self._xyz.device, generator=generator)
         m, v, states = self._moments()
         params = [p.detach().contiguous() for p in self.hot_parameters()]
         new_p, new_m, new_v = optim.densify_apply(counts, flags, offs, params, m, v, noise, self.scale_lower_bound)

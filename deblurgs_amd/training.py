@@ -81,7 +81,11 @@ class TrainingLoop:
                     if self.distributed:
                         sharding.allreduce_densification_stats(g, self._stat_prev)
                         self._stat_prev = None          # densify_and_prune resets the statistics to zeros
-                    g.densify_and_prune(densification_threshold, self.extent)
+                    gen = None
+                    if self.distributed:                # the split's normal draws must be the same on every rank
+                        gen = torch.Generator(device=g._xyz.device)
+                        gen.manual_seed(1_000_003 * int(iteration) + 17)
+                    g.densify_and_prune(densification_threshold, self.extent, generator=gen)
                 if iteration % opt.opacity_reset_interval == 0 or (self.white_background and
                                                                    iteration == opt.densify_from_iter):
                     g.reset_opacity()
