@@ -135,9 +135,11 @@ def main():
     stats = {}
 
     def step():
+        # hinge first: its backward then runs after the rasteriser's and adds into the flat gradient bucket in place
+        hinge = losses.hinge_l2(cloud._opacity)
         out = motion.query(0, "all", compute_blurred=False)
         loss, _blur, _ls = losses.blur_l1_smooth(out["subframes"], out["gt"], args.lambda_t)
-        loss = loss + lambda_hinge * losses.hinge_l2(cloud._opacity)
+        loss = loss + lambda_hinge * hinge
         loss.backward()
         if world > 1:
             sharding.flat_allreduce_grads(params, average=True)

@@ -20,6 +20,7 @@ struct AdamArgs {
   uint32_t block_end[DGS_ADAM_MAX_GROUPS];  // inclusive prefix of blocks per group
   float neg_step_size[DGS_ADAM_MAX_GROUPS];  // -(lr / (1 - beta1^step))
   float bc2_sqrt[DGS_ADAM_MAX_GROUPS];       // sqrt(1 - beta2^step)
+  uint8_t vec4[DGS_ADAM_MAX_GROUPS];         // all four pointers 16-byte aligned: float4 accesses
   int n;
   float beta2, w1, w2, eps, clip;  // w1 = 1 - beta1, w2 = 1 - beta2
 };
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(AdamArgs a) {
   const float* g = a.grad[gi] + base;
   float* m = a.m[gi] + base;
   float* v = a.v[gi] + base;
-  if (base + 4 <= n) {
+  if (base + 4 <= n && a.vec4[gi]) {
     float4 P4 = *reinterpret_cast<float4*>(p);
     const float4 G4 = *reinterpret_cast<const float4*>(g);
     float4 M4 = *reinterpret_cast<float4*>(m);
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(AdamArgs a) {
     *reinterpret_cast<float4*>(m) = M4;
     *reinterpret_cast<float4*>(v) = V4;
   } else {
-    for (int i = 0; base + i < n; i++) {
+    for (int i = 0; i < 4 && base + i < n; i++) {
       float pp = p[i], mm = m[i], vv = v[i];
       adam_one(pp, g[i], mm, vv, a, gi);
       p[i] = pp;
@@ -197,9 +198,11 @@ int dgs_adam_step(const DgsAdamGroup* groups, int32_t n_groups, double beta1, do
     if (g.grad == nullptr || g.numel == 0) continue;   // torch skips parameters without a gradient
     if (g.param == nullptr || g.exp_avg == nullptr || g.exp_avg_sq == nullptr || g.step < 1)
       return dgs_fail_arg("adam_step: null state pointer or step < 1");
-    if (((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq) & 15)
-      return dgs_fail_arg("adam_step: tensors must be 16-byte aligned");
+    if (((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq) & 3)
+      return dgs_fail_arg("adam_step: tensors must be 4-byte aligned");
     const int j = a.n++;
+    // views into packed buffers may start at any float: those groups take the scalar path
+    a.vec4[j] = (((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq) & 15) == 0;
     a.param[j] = g.param; a.grad[j] = g.grad; a.m[j] = g.exp_avg; a.v[j] = g.exp_avg_sq;
     a.numel[j] = g.numel;
     blocks += (g.numel + ADAM_PER_BLOCK - 1) / ADAM_PER_BLOCK;
@@ -215,6 +218,7 @@ int dgs_adam_step(const DgsAdamGroup* groups, int32_t n_groups, double beta1, do
   for (int j = a.n; j < DGS_ADAM_MAX_GROUPS; j++) {
     a.param[j] = nullptr; a.grad[j] = nullptr; a.m[j] = nullptr; a.v[j] = nullptr;
     a.numel[j] = 0; a.block_end[j] = (uint32_t)blocks; a.neg_step_size[j] = 0.0f; a.bc2_sqrt[j] = 1.0f;
+    a.vec4[j] = 0;
   }
   a.beta2 = (float)beta2;
   a.w1 = (float)(1.0 - beta1);

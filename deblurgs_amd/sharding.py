@@ -70,6 +70,36 @@ def _shared_flat(grads):
     return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, lo, (hi - lo,))
 
 
+def _adopt_into_bucket(params):
+    """The fused operator returns the six gradients as views of one bucket laid out in parameter order with 16-byte
+    aligned segments, but a parameter that also receives gradient from elsewhere (the opacity hinge) ends up with a
+    tensor of its own, because autograd sums the two contributions out of place.  If all other gradients still sit
+    in such a bucket, copy the stray ones into their (unused) slots and re-bind .grad to the slot views, so that the
+    whole bucket can be reduced in place.  Returns the bucket or None."""
+    grads = [p.grad for p in params]
+    if any(g is None or g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+        return None
+    st = grads[0].untyped_storage()
+    off = grads[0].storage_offset()
+    slots = []
+    for g in grads:
+        slots.append(off)
+        off += (g.numel() + 3) // 4 * 4
+    last_end = slots[-1] + grads[-1].numel()      # the operator does not pad after the final segment
+    if st.nbytes() < 4 * last_end:
+        return None
+    inside = [g.untyped_storage().data_ptr() == st.data_ptr() and g.storage_offset() == o for g, o in zip(grads, slots)]
+    if sum(g.numel() for g, i in zip(grads, inside) if i) < 0.5 * sum(g.numel() for g in grads):
+        return None
+    bucket = torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, slots[0], (last_end - slots[0],))
+    for p, g, o, i in zip(params, grads, slots, inside):
+        if not i and g.numel() > 0:
+            view = bucket[o - slots[0]:o - slots[0] + g.numel()].view_as(g)
+            view.copy_(g)
+            p.grad = view
+    return bucket
+
+
 def flat_allreduce_grads(params, average=False, group=None):
     """Sum (or average) the .grad of `params` over ranks with ONE collective on a flat fp32 bucket.  Gradients that
     already are views of one flat buffer are reduced in place (no packing copies); RCCL averages inside the
@@ -78,8 +108,21 @@ def flat_allreduce_grads(params, average=False, group=None):
         return
     params = [p for p in params if p is not None]
     grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
-    shared = _shared_flat(grads) if all(p.grad is not None for p in params) else None
-    flat = shared if shared is not None else torch.cat([g.reshape(-1).float() for g in grads])
+    shared = None
+    if all(p.grad is not None for p in params):
+        shared = _shared_flat(grads)
+        if shared is None:
+            shared = _adopt_into_bucket(params)
+    if shared is not None:
+        flat = shared
+    else:   # pack, every segment starting on a 16-byte boundary (the fused optimiser reads float4)
+        offs, total = [], 0
+        for g in grads:
+            offs.append(total)
+            total += (g.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=torch.float32, device=grads[0].device)
+        for g, o in zip(grads, offs):
+            flat[o:o + g.numel()].copy_(g.reshape(-1))
     if average and dist.get_backend(group) == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
     else:
@@ -88,11 +131,8 @@ def flat_allreduce_grads(params, average=False, group=None):
             flat /= dist.get_world_size(group)
     if shared is not None:
         return
-    off = 0
-    for p, g in zip(params, grads):
-        n = g.numel()
-        p.grad = flat[off:off + n].view_as(g).to(g.dtype)
-        off += n
+    for p, g, o in zip(params, grads, offs):
+        p.grad = flat[o:o + g.numel()].view_as(g).to(g.dtype)
 
 
 def allreduce_densification_stats(cloud, prev, group=None):

@@ -57,13 +57,15 @@ class TrainingLoop:
         if iteration % 1000 == 0:
             g.oneupSHdegree()
         subframe_indice = "all" if iteration >= opt.curve_start_iter else 1
+        # The opacity hinge is built BEFORE the render: autograd then runs its backward AFTER the rasteriser's, so the
+        # rasteriser's gradient (a view of the flat gradient buffer) becomes `_opacity.grad` and the hinge term is added
+        # into it in place -- the six gradients stay one contiguous bucket for the all-reduce.
+        L_hinge = losses.hinge_l2(g._opacity) if opt.lambda_hinge > 0.0 else None
         r = self.motion.query(cam_idx=cam_idx, subframe_indice=subframe_indice, compute_blurred=False)
         total, blur, lv = losses.blur_l1_smooth(r["subframes"], r["gt"], lambda_t_smooth)
         Ll1, L_t = lv[0], lv[1]
         loss = total
-        L_hinge = None
-        if opt.lambda_hinge > 0.0:
-            L_hinge = losses.hinge_l2(g._opacity)
+        if L_hinge is not None:
             loss = loss + opt.lambda_hinge * L_hinge
         if opt.lambda_depth_tv > 0.0:
             loss = loss + opt.lambda_depth_tv * losses.tv_loss(r["depths"])
