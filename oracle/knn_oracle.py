@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE ONLY -- the definition simple-knn's distCUDA2 computes (submodules/simple-knn/
 simple_knn.cu:123-174: exact 3-nearest-neighbour search, self excluded by index, squared distances accumulated in
-fp32 as dx*dx + dy*dy + dz*dz, result (b0 + b1 + b2) / 3).  Brute force in blocks; no reference build exists for
-this path (CUDA + cub/thrust), so it is pinned by construction on small hand-checkable cases in the tests."""
+fp32 as dx*dx + dy*dy + dz*dz, result (b0 + b1 + b2) / 3).  Brute force in blocks.  PARITY UNPINNED: the reference has
+no test or golden vector for this path and its source (CUDA + cub/thrust) cannot be built or run here; the restatement
+is checked on hand-computable cases and against scipy.spatial.cKDTree (tests/test_train_oracle.py)."""
 import numpy as np
 
 
