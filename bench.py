@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- subframe-renders/sec (fwd+bwd) of the blur-integration hot path on synthetic Gaussian clouds.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: started plainly, this process launches N ranks itself (one fresh child process per GPU, spawned BEFORE anything
+here touches the GPU, rendezvous on 127.0.0.1) and exits non-zero unless all N report; started under
+`python -m torch.distributed.run --nproc-per-node N ...` it is one of the ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+from the environment).  Either way: one process per GPU, torch.distributed backend "nccl" (= RCCL over xGMI).
 
 One "step" = one query()-equivalent of the reference's training iteration (train.py:126-165) for one blurry view:
 pose path (Bezier -> se3_exp_map -> K cameras), ONE fused K-subframe rasterisation, the fused loss-gradient
 image (L1 of the pixel-averaged blur + temporal smoothness) + opacity hinge, the full backward to the
 per-Gaussian and trajectory gradients, and the iteration's tail (train.py:188-208): densification statistics and
-ONE fused Adam launch over all parameter groups (--no-optimizer leaves the tail out; it costs ~0.3 ms of 17).
+ONE fused Adam launch over all parameter groups (--no-optimizer leaves the tail out; it costs ~0.3 ms).
 Densification itself (every 200 iterations in the reference) and data loading are excluded.
-Default workload = BASELINE.json's metric configuration: 1M Gaussians, 1920x1080, K=15,
-curve order 3, SH degree 2.
+Default workload = BASELINE.json's metric configuration: 1M Gaussians, 1920x1080, K=15, curve order 3, SH degree 2.
 
-N GPUs ("views" sharding, weak scaling): every rank renders all K subframes of its own view; per-Gaussian
-gradients are averaged with one flat RCCL all-reduce per step.  value = N * K * steps / seconds.
+Sharding over N GPUs:
+  --shard views      (default; weak scaling) every rank renders all K subframes of its own view; per-Gaussian and
+                     trajectory gradients are averaged with one flat RCCL all-reduce per step.
+                     value = N * K * steps / seconds.
+  --shard subframes  (strong scaling; the reference's single-view step) the K subframes of ONE view are split over the
+                     ranks; partial blur sum + boundary subframes are exchanged before the backward, gradients are
+                     summed after it.  value = K * steps / seconds.
 
 Prints ONE JSON line on rank 0 (metric contract + "roofline" for the dominant kernel + "cpu_baseline").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,13 +38,68 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="metric", help="metric | cfg2 | cfg3 | cfg5 | cfg1")
+    ap.add_argument("--shard", default="views", choices=["views", "subframes"])
+    ap.add_argument("--K", type=int, default=None)
+    ap.add_argument("--sh-degree", type=int, default=2)
+    ap.add_argument("--P", type=int, default=None, help="override the number of Gaussians (stress variants)")
+    ap.add_argument("--sigma-px", type=float, default=None, help="override the splat size of the generator (default 1.5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-lists", action="store_true",
+                    help="skip the second timed region with tile_cull=0 (the reference's duplicate lists)")
+    ap.add_argument("--lambda-t", type=float, default=1e-3)
+    ap.add_argument("--no-optimizer", action="store_true",
+                    help="time query + loss + backward (+ all-reduce) only, without densification stats and Adam")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ N-rank launcher
+def launch_ranks(args):
+    """Parent of an N-GPU run: spawns N fresh rank processes and relays rank 0's JSON line.  Makes NO GPU call itself
+    (torch.cuda.device_count() does not initialise the device on this image), never re-execs."""
+    import torch
+    n = args.gpus
+    one_device = os.environ.get("DGS_DIST_ONE_DEVICE", "0") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not one_device:
+        print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible; refusing to report a smaller run as "
+              f"n_gpus={n}", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if any(rc != 0 for rc in rcs) or line is None:
+        print(f"bench.py: rank exit codes {rcs}; no result line" if line is None else
+              f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        return 1
+    if json.loads(line)["n_gpus"] != n:
+        print(f"bench.py: the ranks saw {json.loads(line)['n_gpus']} peers, not {n}", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ byte model
 def stage_bytes(P, Pv_tot, R_tot, N, K, s):
     """Algorithmic bytes per K-fused launch of each stage (SURVEY.md 8d byte model, summed over the K subframes;
     K-fused: the P*(44+12s) input read and the per-Gaussian gradient write are paid once per launch)."""
@@ -53,8 +119,10 @@ def stage_bytes(P, Pv_tot, R_tot, N, K, s):
     }
 
 
-def cpu_baseline(scene, k):
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def cpu_baseline_port(scene, k):
     """The CPU oracle (OpenMP build, all host cores) timed on ONE of the K subframes of the same workload."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import oracle
     from helpers import oracle_forward
@@ -72,30 +140,65 @@ def cpu_baseline(scene, k):
                       f"oracle/dgs_oracle.cpp with OpenMP; {dt:.1f} s", "seconds": dt}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="metric", help="metric | cfg2 | cfg3 | cfg5 | cfg1")
-    ap.add_argument("--K", type=int, default=None)
-    ap.add_argument("--sh-degree", type=int, default=2)
-    ap.add_argument("--P", type=int, default=None, help="override the number of Gaussians (stress variants)")
-    ap.add_argument("--sigma-px", type=float, default=None, help="override the splat size of the generator (default 1.5)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lambda-t", type=float, default=1e-3)
-    ap.add_argument("--no-optimizer", action="store_true",
-                    help="time query + loss + backward (+ all-reduce) only, without densification stats and Adam")
-    args = ap.parse_args()
+def cpu_baseline_torch_naive(scene, k, side=96):
+    """The baseline north_star names: a naive dense PyTorch CPU rasteriser (oracle/torch_naive.py: every pixel against
+    every candidate Gaussian, autograd backward) on the box's own host cores.  Dense N x P is out of reach at these
+    sizes, so the sample is a side x side pixel window at the image centre of subframe k with the Gaussians whose
+    tile rectangles meet it; the measured figure is windows/sec, and the full-frame equivalent divides by the stated
+    pixel ratio (an extrapolation, labelled as such)."""
+    import numpy as np
+    import torch
+    from oracle import torch_naive
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    W, H = scene["W"], scene["H"]
+    x0, y0 = (W - side) // 2 // 16 * 16, (H - side) // 2 // 16 * 16
+    window = (x0, y0, x0 + side, y0 + side)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    leaves = {n: t(scene[n]).requires_grad_(True) for n in ("means3D", "opacities", "sh", "scales", "rotations")}
+    g = torch.from_numpy(np.random.default_rng(0).normal(size=(3, side, side)).astype(np.float32))
+    t0 = time.time()
+    color, depth, radii = torch_naive.rasterize(
+        leaves["means3D"], leaves["opacities"], t(scene["viewmatrix"][k]), t(scene["projmatrix"][k]),
+        t(scene["campos"][k]), t(scene["bg"]), W, H, scene["tanfovx"], scene["tanfovy"], sh=leaves["sh"],
+        scales=leaves["scales"], rotations=leaves["rotations"], sh_degree=scene["sh_degree"], pixel_chunk=2048,
+        window=window)
+    (color * g).sum().backward()
+    dt = time.time() - t0
+    ratio = (W * H) / float(side * side)
+    return {"value": 1.0 / dt, "unit": f"{side}x{side}-pixel windows/sec (fwd+bwd)", "cores": int(threads),
+            "kind": "port", "implementation": "oracle/torch_naive.py (dense PyTorch CPU rasteriser, autograd backward)",
+            "sample": f"pixel window {window} of subframe k={k} of this workload (1/{ratio:.0f} of the frame's pixels; "
+                      f"all {scene['P']} Gaussians preprocessed, those meeting the window composited); {dt:.1f} s",
+            "seconds": dt,
+            "full_frame_equivalent_renders_per_sec_extrapolated": 1.0 / (dt * ratio)}
 
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     from deblurgs_amd import _lib, losses, sharding, synthetic
+    from deblurgs_amd import diff_gaussian_rasterization as dgr
     from deblurgs_amd.cloud import GaussianCloud
+    from deblurgs_amd.densify_stats import add_densification_stats_subframes
     from deblurgs_amd.motion import CameraMotionModule, RefCamera
+    from deblurgs_amd.training import default_optimization_params
 
-    rank, world, local_rank = sharding.init_distributed("cuda")
-    assert world == max(args.gpus, 1) or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    rank, world_env, local_rank = sharding.init_distributed("cuda")
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined the process group")
+    if os.environ.get("DGS_DIST_ONE_DEVICE", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:      # count the peers through the collective library itself
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        assert int(ones.item()) == world, "all-reduce did not reach every rank"
+    subframes_mode = world > 1 and args.shard == "subframes"
 
     over = {} if args.K is None else {"K": args.K}
     if args.P is not None:
@@ -107,21 +210,19 @@ def main():
     C = synthetic.CONFIGS[args.config]["C"]
     cloud = GaussianCloud.from_scene(scene, dev)
     ref_cam = RefCamera(W, H, scene["FoVx"], scene["FoVy"], device=dev)
-    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    view_seed = 0 if subframes_mode else rank        # "subframes": every rank works on the SAME view
+    gen = torch.Generator(device="cpu").manual_seed(1234 + view_seed)
     gt = torch.rand((1, 3, H, W), generator=gen).to(dev)
     motion = CameraMotionModule(ref_cam, gt, curve_order=C, num_subframes=K, device=dev)
-    traj = synthetic.make_trajectory(K, C, scene["projection_matrix"], seed=rank)   # this rank's own view
+    traj = synthetic.make_trajectory(K, C, scene["projection_matrix"], seed=view_seed)
     with torch.no_grad():
         motion._trans._control_points.copy_(torch.from_numpy(traj["ctrl_trans"])[None].to(dev))
         motion._rot._control_points.copy_(torch.from_numpy(traj["ctrl_rot"])[None].to(dev))
     motion.link_gaussian(cloud)
     params = cloud.hot_parameters()
-    curve_params = motion.parameters()
     lambda_hinge = 0.1
     # the iteration's tail (train.py:188-208): densification statistics + ONE fused Adam launch over the six
     # per-Gaussian groups and the trajectory groups, reference learning rates (arguments/__init__.py:84-123)
-    from deblurgs_amd.densify_stats import add_densification_stats_subframes
-    from deblurgs_amd.training import default_optimization_params
     cloud.training_setup(default_optimization_params(), spatial_lr_scale=1.0)
     motion.add_training_setup(cloud, {"curve_rot": 1e-3, "curve_trans": 1e-2, "curve_alignment": 0.0})
     # The ground truth is noise, so real learning rates would pull the cloud away from the configured workload within
@@ -133,21 +234,38 @@ def main():
     cloud.xyz_scheduler_args = lambda it: 0.00016 * LR_SCALE
 
     stats = {}
+    ar_events = []
+
+    def reduce_grads(average):
+        if world == 1:
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sharding.flat_allreduce_grads(params, average=average, extra=motion.parameters())
+        e1.record()
+        ar_events.append((e0, e1))
 
     def step():
         # hinge first: its backward then runs after the rasteriser's and adds into the flat gradient bucket in place
         hinge = losses.hinge_l2(cloud._opacity)
-        out = motion.query(0, "all", compute_blurred=False)
-        loss, _blur, _ls = losses.blur_l1_smooth(out["subframes"], out["gt"], args.lambda_t)
-        loss = loss + lambda_hinge * hinge
-        loss.backward()
-        if world > 1:
-            sharding.flat_allreduce_grads(params, average=True)
+        if subframes_mode:
+            out = motion.query(0, "all", compute_blurred=False, shard=(rank, world))
+            sharding.subframe_sharded_loss_backward(out["subframes"], out["gt"], out["K_total"], out["k0"],
+                                                    args.lambda_t)
+            (lambda_hinge * hinge * (1.0 if rank == 0 else 0.0)).backward()
+            reduce_grads(average=False)
+        else:
+            out = motion.query(0, "all", compute_blurred=False)
+            loss, _blur, _ls = losses.blur_l1_smooth(out["subframes"], out["gt"], args.lambda_t)
+            loss = loss + lambda_hinge * hinge
+            loss.backward()
+            reduce_grads(average=True)
         stats["radii"] = out["radii_all"]
         if not args.no_optimizer:
             with torch.no_grad():
-                add_densification_stats_subframes(out["viewspace_points_all"], out["radii_all"], cloud.max_radii2D,
-                                                  cloud.xyz_gradient_accum, cloud.denom)
+                if out["radii_all"].shape[0] > 0:
+                    add_densification_stats_subframes(out["viewspace_points_all"], out["radii_all"], cloud.max_radii2D,
+                                                      cloud.xyz_gradient_accum, cloud.denom, K_total=out["K_total"])
             cloud.optimizer.step()
         cloud.optimizer.zero_grad(set_to_none=True)
 
@@ -156,30 +274,55 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(nsteps, profile):
+        sync()
+        if profile:
+            _lib.profile_reset()
+            _lib.profile_enable(True)
+        ar_events.clear()
+        sync()
+        t0 = time.time()
+        for _ in range(nsteps):
+            step()
+        sync()
+        dt = time.time() - t0
+        if profile:
+            _lib.profile_enable(False)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     for _ in range(args.warmup):
         step()
     sync()
-    # measured Pv / R of this workload (outputs of the forward)
-    radii = stats["radii"]
-    Pv_tot = int((radii > 0).sum().item())
-    _lib.profile_reset()
-    _lib.profile_enable(True)
-    sync()
-    t0 = time.time()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.time() - t0
-    _lib.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    Pv_tot = int((stats["radii"] > 0).sum().item())    # measured Pv of this rank's workload (output of the forward)
+    dt = timed(args.steps, profile=True)
     prof = _lib.profile_read()
+    allreduce_ms = None
+    if ar_events:
+        allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
+
+    # the same step on the reference's duplicate lists (tile_cull = 0: sort keys / point lists bit-identical to the
+    # reference's), reported beside the headline value
+    ref_lists = None
+    if world == 1 and not args.no_reference_lists and dgr.TILE_CULL:
+        dgr.TILE_CULL = False
+        try:
+            for _ in range(2):
+                step()
+            n0 = max(10, args.steps // 4)
+            dt0 = timed(n0, profile=False)
+            ref_lists = {"value": round(K * n0 / dt0, 2), "ms_per_step": round(dt0 / n0 * 1e3, 3), "steps": n0,
+                         "note": "same step with DgsProblem.tile_cull = 0: the duplicate lists, sort keys and tile ranges "
+                                 "are the reference's bit for bit; images and gradients are bitwise equal to the headline "
+                                 "run's (tests/test_gpu_configs.py)"}
+        finally:
+            dgr.TILE_CULL = True
 
     if rank == 0:
         # R from a state-level forward (the operator keeps it in its autograd ctx)
-        from deblurgs_amd import diff_gaussian_rasterization as dgr
         with torch.no_grad():
             wv, fp, cc = motion.get_trajectory_matrices(0)
             rs = dgr.GaussianRasterizationSettings(H, W, scene["tanfovx"], scene["tanfovy"],
@@ -191,7 +334,11 @@ def main():
                                       cc.contiguous(), rs)[0]
         N = W * H
         s = (args.sh_degree + 1) ** 2
-        bytes_by_stage = stage_bytes(P, Pv_tot, R_tot, N, K, s)
+        frac_k = 1.0
+        if subframes_mode:       # this rank's share of the K subframes
+            k0, k1 = sharding.shard_range(K, rank, world)
+            frac_k = (k1 - k0) / K
+        bytes_by_stage = stage_bytes(P, Pv_tot, R_tot * frac_k, N, K * frac_k, s)
         stages = {}
         for name, (ms, calls) in prof.items():
             if calls == 0:
@@ -203,7 +350,7 @@ def main():
         dom = max(stages, key=lambda n: stages[n]["avg_ms"])
         total_bytes = sum(bytes_by_stage.values())
         ms_per_step = dt / args.steps * 1e3
-        value = world * K * args.steps / dt
+        value = (K if subframes_mode else world * K) * args.steps / dt
         result = {
             "metric": "subframe-renders/sec (fwd+bwd), 1M Gaussians, K=15, 1080p, 1/2/4/8 GPU",
             "value": round(value, 2),
@@ -213,22 +360,26 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if subframes_mode else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: P={P} Gaussians, {W}x{H}, K={K} subframes fused, curve_order={C}, "
-                                   f"SH degree {args.sh_degree} (M={s}); one blurry view per GPU per step",
+                                   f"SH degree {args.sh_degree} (M={s}); " +
+                                   ("one blurry view per step, its K subframes split over the GPUs" if subframes_mode
+                                    else "one blurry view per GPU per step"),
                        "step": ("query + fused loss + backward" + (" + grad all-reduce" if world > 1 else "") +
                                 ("" if args.no_optimizer else " + densification stats + fused Adam (all groups; learning "
                                  "rates x1e-6 so the synthetic workload stays stationary)")),
-                       "tile_cull": bool(__import__("deblurgs_amd.diff_gaussian_rasterization",
-                                                    fromlist=["x"]).TILE_CULL),
-                       "sharding": "views" if world > 1 else "none", "Pv_total": Pv_tot, "R_total": int(R_tot),
+                       "tile_cull": bool(dgr.TILE_CULL),
+                       "sharding": (args.shard if world > 1 else "none"), "ranks_in_process_group": world,
+                       "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
+                       "Pv_total": Pv_tot, "R_total": int(R_tot),
                        "pixel_gaussian_evals_upper_bound_per_step": int(256 * R_tot)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 5), "traffic": None,
                          "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["avg_ms"],
+                         "avg_launch_ms_source": "HIP events on the launch stream inside this run (dgs_profile_*)",
                          "note": "compositing is VALU/LDS-bound, not HBM-bound (SURVEY 8d); frac is the honest HBM "
                                  "fraction of the byte model"},
             "pipeline_hbm": {"alg_bytes_per_step": int(total_bytes),
@@ -236,32 +387,44 @@ def main():
                              "frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stages": stages,
         }
-        traffic_file = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(traffic_file):
+        if ref_lists is not None:
+            result["value_reference_lists"] = ref_lists
+        # PMC counters cannot be collected inside this run (rocprofv3 wraps the process): traffic / VALU figures are the
+        # committed measurements of the same command, with their provenance, or null
+        for fname, key in (("traffic_r02.json", "traffic"), ("valu_r02.json", "valu")):
+            path = os.path.join(ROOT, "profiles", fname)
+            if not os.path.exists(path) or world != 1:
+                continue
             try:
-                tr = json.load(open(traffic_file))
-                if dom in tr and tr.get("_config") == args.config:
-                    result["roofline"]["traffic"] = tr[dom]
-            except Exception:
-                pass
-        valu_file = os.path.join(ROOT, "profiles", "valu_r01.json")
-        if os.path.exists(valu_file) and args.config == "metric":
-            try:
-                vv = json.load(open(valu_file))
-                hit = [v_ for k_, v_ in vv.items() if k_.startswith(dom + "_kernel")]
-                if hit:
-                    result["roofline"]["valu"] = {
-                        "insts_per_launch": hit[0]["valu_insts"], "ipc_per_simd": hit[0]["ipc_per_simd"],
-                        "practical_peak_ipc_per_simd": 0.37,
-                        "note": "rocprofv3 PMC SQ_INSTS_VALU (profiles/valu_r01.json); peak = tools/valu_rate.hip at 8 waves/SIMD"}
+                doc = json.load(open(path))
+                if doc.get("_config") != args.config:
+                    continue
+                if key == "traffic" and dom in doc:
+                    result["roofline"]["traffic"] = doc[dom]
+                    result["roofline"]["traffic_source"] = f"profiles/{fname}: {doc.get('_source', '')}"
+                if key == "valu":
+                    hit = [v_ for k_, v_ in doc.items() if k_.startswith(dom + "_kernel")]
+                    if hit:
+                        result["roofline"]["valu"] = dict(hit[0], source=f"profiles/{fname}: {doc.get('_source', '')}")
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(scene, K // 2)
+            result["cpu_baseline"] = cpu_baseline_port(scene, K // 2)
+            try:
+                result["cpu_baseline_torch_naive"] = cpu_baseline_torch_naive(scene, K // 2)
+            except Exception as ex:     # never lose the headline line to the secondary baseline
+                result["cpu_baseline_torch_naive"] = {"error": repr(ex)}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -73,7 +73,7 @@ class DgsCloudArrays(ctypes.Structure):
 
 
 ADAM_MAX_GROUPS = 16
-ABI_VERSION = 3            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
+ABI_VERSION = 4            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
 
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {
@@ -102,7 +102,10 @@ EXPORTS = {
     "dgs_blur_loss_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    "dgs_densify_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+    "dgs_cloud_activations": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p]),
+    "dgs_densify_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dgs_adam_step": (ctypes.c_int, [ctypes.POINTER(DgsAdamGroup), ctypes.c_int32, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),

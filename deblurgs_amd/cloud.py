@@ -84,6 +84,24 @@ class GaussianCloud(nn.Module):
     def get_opacity(self):
         return self.opacity_activation(self._opacity)
 
+    @torch.no_grad()
+    def device_activations(self):
+        """(get_scaling, get_rotation, get_opacity) as the raw-parameter kernels evaluate them (dgs_cloud_activations):
+        bit-identical to what render_subframes() rasterises with fused_activations; the torch getters above can differ
+        from it by an ulp of exp()."""
+        import ctypes
+        from . import _lib
+        dev = self._xyz.device
+        P = self._xyz.shape[0]
+        sc, rot, op = (t.detach().float().contiguous() for t in (self._scaling, self._rotation, self._opacity))
+        o_sc, o_rot, o_op = torch.empty_like(sc), torch.empty_like(rot), torch.empty_like(op)
+        _lib.check(_lib.lib().dgs_cloud_activations(P, sc.data_ptr(), rot.data_ptr(), op.data_ptr(),
+                                                    float(self.scale_lower_bound), o_sc.data_ptr(), o_rot.data_ptr(),
+                                                    o_op.data_ptr(),
+                                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                   "dgs_cloud_activations")
+        return o_sc, o_rot, o_op
+
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
@@ -99,7 +117,12 @@ class GaussianCloud(nn.Module):
                 self._opacity, self.max_radii2D, self.xyz_gradient_accum, self.denom, self.optimizer.state_dict(),
                 self.spatial_lr_scale)
 
-    def restore(self, model_args, training_args, fused=True):
+    def restore(self, model_args, training_args, fused=True, cam_motion_module=None, curve_lrs=None):
+        """scene/gaussian_model.py:97-112.  The checkpoint's optimiser state may hold the three trajectory groups that
+        CameraMotionModule.add_training_setup appended (curve_rot / curve_trans / curve_alignment, scene/motion.py:63-76)
+        after the six per-Gaussian ones; the reference's own restore() then fails in load_state_dict (6 fresh groups vs
+        9 saved).  Here: with `cam_motion_module` given its groups are attached first and everything is loaded; without
+        it only the per-Gaussian groups and their moments are loaded."""
         (self.active_sh_degree, xyz, f_dc, f_rest, scaling, rotation, opacity, self.max_radii2D, xyz_gradient_accum,
          denom, opt_dict, spatial_lr_scale) = model_args
         dev = self._xyz.device
@@ -110,6 +133,23 @@ class GaussianCloud(nn.Module):
         self.max_radii2D = self.max_radii2D.to(dev)
         self.xyz_gradient_accum = xyz_gradient_accum.to(dev)
         self.denom = denom.to(dev)
+        saved_groups = [dict(g) for g in opt_dict["param_groups"]]       # never edit the caller's checkpoint in place
+        opt_dict = {"state": opt_dict["state"], "param_groups": saved_groups}
+        curve = [g for g in saved_groups if str(g.get("name", "")).startswith("curve_")]
+        if curve and cam_motion_module is not None:
+            lrs = {g["name"]: g["lr"] for g in curve}
+            lrs.update(curve_lrs or {})
+            cam_motion_module.add_training_setup(self, {"curve_rot": lrs.get("curve_rot", 0.0),
+                                                        "curve_trans": lrs.get("curve_trans", 0.0),
+                                                        "curve_alignment": lrs.get("curve_alignment", 0.0)})
+        elif curve:
+            keep = [g for g in saved_groups if not str(g.get("name", "")).startswith("curve_")]
+            ids = {i for g in keep for i in g["params"]}
+            opt_dict = {"state": {k: v for k, v in opt_dict["state"].items() if k in ids}, "param_groups": keep}
+        # group keys a foreign Adam did not write (torch versions differ) take this optimiser's defaults
+        for g in opt_dict["param_groups"]:
+            for key, val in self.optimizer.defaults.items():
+                g.setdefault(key, val)
         self.optimizer.load_state_dict(opt_dict)
 
     # ------------------------------------------------------------------ training side
@@ -249,6 +289,28 @@ class GaussianCloud(nn.Module):
                         st["exp_avg_sq"] = torch.zeros_like(new)
                         self.optimizer.state[new] = st
         self._opacity = new
+
+
+def get_scheduler(lr_init, lr_final, warmup_ratio, step_warmup, step_final):
+    """utils/general_utils.py:72-101 as the fork left it: 0 up to and including step_warmup (the exponential warm-up is
+    commented out there, so warmup_ratio has no effect), exponential decay lr_init -> lr_final over
+    (step_warmup, step_final], lr_final afterwards; identically 0 for lr_init <= 1e-8 inside the decay phase.  Drives
+    the curve_alignment learning rate (train.py:90-94,109)."""
+    import math
+
+    def get_lr(step):
+        if step < 1:
+            raise ValueError("Step must be greater than 0")
+        if step <= step_warmup:
+            return 0.0
+        if step <= step_final:
+            if lr_init <= 1e-8:
+                return 0.0
+            decay_rate = math.log(lr_final / lr_init) / (step_final - step_warmup)
+            return lr_init * math.exp(decay_rate * (step - step_warmup))
+        return lr_final
+
+    return get_lr
 
 
 def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, max_steps=1000000):

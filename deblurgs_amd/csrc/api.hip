@@ -294,12 +294,12 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
 
 // train.py:188-193 + scene/gaussian_model.py:456-458 for the K subframes of one step, in subframe order
 __global__ void __launch_bounds__(256)
-densify_stats_kernel(const float* __restrict__ vgrad, const int32_t* __restrict__ radii, int K, int P,
+densify_stats_kernel(const float* __restrict__ vgrad, const int32_t* __restrict__ radii, int K, int K_total, int P,
                      float* __restrict__ max_radii2D, float* __restrict__ accum, float* __restrict__ denom) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= P) return;
   float mr = max_radii2D[g], ac = accum[g], dn = denom[g];
-  const float inc = (float)(1.0 / (double)K);
+  const float inc = (float)(1.0 / (double)K_total);
   for (int k = 0; k < K; k++) {
     const size_t o = (size_t)k * P + g;
     const int r = radii[o];
@@ -535,6 +535,17 @@ int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
   return e == hipSuccess ? DGS_OK : fail_hip(e, "mark_visible");
 }
 
+int dgs_cloud_activations(int32_t P, const float* scaling, const float* rotation, const float* opacity, float scale_lb,
+                          float* out_scaling, float* out_rotation, float* out_opacity, dgs_stream_t stream) {
+  if (P < 0 || (out_scaling != nullptr && scaling == nullptr) || (out_rotation != nullptr && rotation == nullptr) ||
+      (out_opacity != nullptr && opacity == nullptr))
+    return fail(DGS_E_ARG, "cloud_activations: an output is requested without its input");
+  if (P == 0) return DGS_OK;
+  hipError_t e = dgs_launch_cloud_activations(P, scaling, rotation, opacity, scale_lb, out_scaling, out_rotation,
+                                              out_opacity, reinterpret_cast<hipStream_t>(stream));
+  return e == hipSuccess ? DGS_OK : fail_hip(e, "cloud_activations");
+}
+
 size_t dgs_scan_tmp_bytes(uint64_t n) { return dgs_scan_tmp_words(n) * 4; }
 int dgs_exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, void* tmp, uint32_t* total_out,
                            dgs_stream_t stream) {
@@ -567,14 +578,15 @@ int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32
   return e == hipSuccess ? DGS_OK : fail_hip(e, "blur_loss_grad");
 }
 
-int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t P, float* max_radii2D,
-                      float* xyz_gradient_accum, float* denom, dgs_stream_t stream) {
-  if (K < 1 || P < 0 || (P > 0 && (viewspace_grad == nullptr || radii == nullptr || max_radii2D == nullptr ||
+int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t K_total, int32_t P,
+                      float* max_radii2D, float* xyz_gradient_accum, float* denom, dgs_stream_t stream) {
+  if (K_total <= 0) K_total = K;
+  if (K < 1 || K_total < K || P < 0 || (P > 0 && (viewspace_grad == nullptr || radii == nullptr || max_radii2D == nullptr ||
                                    xyz_gradient_accum == nullptr || denom == nullptr)))
     return fail(DGS_E_ARG, "densify_stats: bad argument");
   if (P == 0) return DGS_OK;
   hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     viewspace_grad, radii, K, P, max_radii2D, xyz_gradient_accum, denom);
+                     viewspace_grad, radii, K, K_total, P, max_radii2D, xyz_gradient_accum, denom);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DGS_OK : fail_hip(e, "densify_stats");
 }

@@ -202,6 +202,9 @@ __device__ __forceinline__ bool dgs_cull_hit(const DgsCull& g, float dx_lo, floa
 hipError_t dgs_launch_preprocess(const DgsProblem& p, const DgsView& v, const DgsCarve& c, int32_t* radii,
                                  hipStream_t s);
 hipError_t dgs_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+hipError_t dgs_launch_cloud_activations(int P, const float* scales, const float* rotations, const float* opacities,
+                                        float scale_lb, float* out_scales, float* out_rotations, float* out_opacities,
+                                        hipStream_t s);
 hipError_t dgs_launch_duplicate(const DgsView& v, const DgsCarve& c, hipStream_t s);
 hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s);
 hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, uint32_t* total,

@@ -307,6 +307,38 @@ hipError_t dgs_launch_preprocess(const DgsProblem& p, const DgsView& v, const Dg
   return hipGetLastError();
 }
 
+// The activated values exactly as preprocess_fwd_kernel forms them in raw-parameter mode (same device functions, same
+// translation unit and compile flags, hence the same bits): the device-side counterpart of the reference's getters
+// get_scaling / get_rotation / get_opacity (scene/gaussian_model.py:114-137).
+__global__ void __launch_bounds__(256)
+cloud_activations_kernel(int P, const float* __restrict__ scales, const float* __restrict__ rotations,
+                         const float* __restrict__ opacities, float scale_lb, float* __restrict__ out_scales,
+                         float* __restrict__ out_rotations, float* __restrict__ out_opacities) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  if (out_scales != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) out_scales[3 * idx + i] = dgs_act_scale(scales[3 * idx + i], scale_lb);
+  }
+  if (out_rotations != nullptr) {
+    const float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2], z = rotations[4 * idx + 3];
+    const float d = dgs_quat_norm(r, x, y, z);
+    out_rotations[4 * idx] = r / d;
+    out_rotations[4 * idx + 1] = x / d;
+    out_rotations[4 * idx + 2] = y / d;
+    out_rotations[4 * idx + 3] = z / d;
+  }
+  if (out_opacities != nullptr) out_opacities[idx] = dgs_act_opacity(opacities[idx]);
+}
+
+hipError_t dgs_launch_cloud_activations(int P, const float* scales, const float* rotations, const float* opacities,
+                                        float scale_lb, float* out_scales, float* out_rotations, float* out_opacities,
+                                        hipStream_t s) {
+  hipLaunchKernelGGL(cloud_activations_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, scales, rotations, opacities,
+                     scale_lb, out_scales, out_rotations, out_opacities);
+  return hipGetLastError();
+}
+
 hipError_t dgs_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s) {
   hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
   return hipGetLastError();

@@ -1,31 +1,26 @@
 """Blur-integration loop: per-image learnable SE(3) Bezier trajectory and the K-subframe query.
 
 Mirrors the hot part of the reference's scene/motion.py (CameraMotionModule.query :78-160, get_trajectory
-:162-178, _sample_nu_from_alignment :209-219, _sample_c2w_from_nu :221-256, _c2w_to_minicam :258-294) for the
-default curve_type="se3".  Differences, all on purpose:
+:162-178, _sample_nu_from_alignment :209-219, _sample_c2w_from_nu :221-256, _c2w_to_minicam :258-294) for both
+curve types ("se3", the default, and "quarternion_cartesian").  Differences, all on purpose:
   * the K subframes are rasterised by ONE fused launch chain (gaussian_renderer.render_subframes) instead of a
     Python loop of K render() calls, and the K cameras are built with batched tensor ops;
   * dataset loading, PLY/COLMAP I/O, optimiser wiring and cm.pth checkpoints are out of scope (SURVEY 2, rows
     12-21): the module is constructed from initial c2w poses and ground-truth images held in memory;
-  * curve_type="quarternion_cartesian" (needs the unpinned third-party `roma`) is not provided.
+  * curve_type="quarternion_cartesian" calls the third-party `roma` in the reference (unpinned, absent here); its two
+    conversions are restated in pose.py (rotmat_to_unitquat / unitquat_to_rotmat) and pinned against scipy.  That
+    curve type evaluates its poses with torch ops (the fused pose kernel covers the default se3 type).
 """
 import torch
 import torch.nn as nn
 
 from . import gaussian_renderer
-from .pose import BezierModel, MiniCam, get_projection_matrix, se3_exp_map, c2w_to_view_proj, fused_trajectory
+from .pose import (BezierModel, MiniCam, get_projection_matrix, se3_exp_map, se3_log_map, c2w_to_view_proj,
+                   fused_trajectory, rotmat_to_unitquat, unitquat_to_rotmat)
 
 
 def inverse_sigmoid(x):
     return torch.log(x / (1 - x))
-
-
-def se3_log_of_identity_like(rotations, translations):
-    """Log map used only at initialisation (scene/motion.py:196-203).  For the synthetic scenes the initial
-    poses are (near) identity, so a first-order log is exact enough: rot_log = vee(R - R^T)/2, trans_log = t."""
-    skew = 0.5 * (rotations - rotations.transpose(-2, -1))
-    rot_log = torch.stack([skew[:, 2, 1], skew[:, 0, 2], skew[:, 1, 0]], dim=1)
-    return torch.cat([translations, rot_log], dim=1)
 
 
 class RefCamera:
@@ -43,26 +38,53 @@ class RefCamera:
 
 class CameraMotionModule:
     def __init__(self, ref_cam: RefCamera, gt_images, curve_order=9, num_subframes=21, init_se3=None,
-                 curve_random_sample=False, device="cuda"):
-        """gt_images: [n,3,H,W] observed blurry images; init_se3: [n,6] initial (trans_log | rot_log) poses."""
+                 curve_random_sample=False, device="cuda", curve_type="se3", init_c2w=None):
+        """gt_images: [n,3,H,W] observed blurry images.  Initial poses, one per image, either as
+        init_c2w = (rotations [n,3,3], translations [n,3]) -- the c2w rotation and camera position the reference takes
+        from its CameraInfo list (scene/motion.py:39-50: cam_info.R and -T @ R^T) -- or as init_se3 [n,6]
+        (trans_log | rot_log) logarithms; identity poses when neither is given."""
+        if curve_type not in ("se3", "quarternion_cartesian"):
+            raise NotImplementedError(curve_type)            # scene/motion.py:206-207
         self.curve_order = curve_order
         self.n_subframes = num_subframes
-        self.curve_type = "se3"
+        self.curve_type = curve_type
         self.curve_random_sample = curve_random_sample
         self.gaussians = None
         self.ref_cam = ref_cam
         self.gt_images = gt_images
         n = gt_images.shape[0]
-        if init_se3 is None:
-            init_se3 = torch.zeros(n, 6)
-        self._rot = BezierModel(init_se3[:, 3:], curve_order, device=device)
-        self._trans = BezierModel(init_se3[:, :3], curve_order, device=device)
+        if init_c2w is None:
+            if init_se3 is None:
+                init_se3 = torch.zeros(n, 6)
+            c2w = se3_exp_map(init_se3.double())
+            init_c2w = (c2w[:, :3, :3].transpose(-2, -1), c2w[:, 3, :3])
+        elif init_se3 is not None:
+            raise ValueError("give init_se3 or init_c2w, not both")
+        self._set_initial_parameters(init_c2w[0], init_c2w[1], device, init_se3)
         f = num_subframes
         if f > 2:
             nu0 = torch.linspace(1 / (f - 1), 1.0 - (1 / (f - 1)), f - 2)[None, :].repeat(n, 1).to(device)
             self._nu = nn.Parameter(inverse_sigmoid(nu0).contiguous().requires_grad_(True))
         else:
             self._nu = nn.Parameter(torch.zeros(n, 0, device=device))
+
+    def _set_initial_parameters(self, rotations, translations, device, init_se3=None):
+        """scene/motion.py:180-207.  rotations: c2w rotation [n,3,3]; translations: camera position [n,3]."""
+        n = rotations.shape[0]
+        if self.curve_type == "quarternion_cartesian":
+            self._rot = BezierModel(rotmat_to_unitquat(rotations), self.curve_order, device=device)
+            self._trans = BezierModel(translations, self.curve_order, initial_noise=0.01, device=device)
+            return
+        if init_se3 is not None:
+            params = init_se3            # already logarithms: skip the exp -> log round trip
+        else:
+            c2w = torch.zeros(n, 4, 4, dtype=rotations.dtype, device=rotations.device)
+            c2w[:, :3, :3] = rotations.transpose(-2, -1)     # row-vector (torch3d) convention
+            c2w[:, 3, :3] = translations
+            c2w[:, 3, 3] = 1.0
+            params = se3_log_map(c2w)
+        self._rot = BezierModel(params[:, 3:], self.curve_order, device=device)
+        self._trans = BezierModel(params[:, :3], self.curve_order, device=device)
 
     def link_gaussian(self, gaussians):
         self.gaussians = gaussians
@@ -107,7 +129,7 @@ class CameraMotionModule:
             nu_mid = nu_mid + torch.rand_like(nu_mid) / self.n_subframes - (1 / (2 * self.n_subframes))
         return torch.cat([torch.zeros(1, device=device), nu_mid, torch.ones(1, device=device)]).clamp(0.0, 1.0).sort().values
 
-    # ---- scene/motion.py:221-256 (se3 branch)
+    # ---- scene/motion.py:221-256
     def _sample_c2w_from_nu(self, idx, nu=None):
         if nu is None:
             nu = self._sample_nu_from_alignment(idx)
@@ -115,6 +137,10 @@ class CameraMotionModule:
             nu = nu.to(self.device)
         else:
             raise NotImplementedError
+        if self.curve_type == "quarternion_cartesian":
+            rot_quaternion = self._rot(nu, idx)
+            rot_quaternion = rot_quaternion / rot_quaternion.norm(dim=1, keepdim=True)
+            return unitquat_to_rotmat(rot_quaternion), self._trans(nu, idx)
         se3 = torch.cat([self._trans(nu, idx), self._rot(nu, idx)], dim=1)
         c2w = se3_exp_map(se3)
         return c2w[:, :3, :3].transpose(-2, -1), c2w[:, 3, :3]
@@ -123,8 +149,10 @@ class CameraMotionModule:
         """Batched _c2w_to_minicam: (world_view [K,4,4], full_proj [K,4,4], camera_center [K,3]).
         On device tensors the whole chain nu -> Bezier -> se3_exp_map -> cameras runs as one HIP kernel
         (pose.fused_trajectory); `fused=False` forces the torch-op reference implementation."""
-        use_fused = self.device.type == "cuda" if fused is None else fused
+        use_fused = (self.device.type == "cuda" and self.curve_type == "se3") if fused is None else fused
         if use_fused:
+            if self.curve_type != "se3":
+                raise NotImplementedError("the fused pose kernel covers curve_type='se3'")
             nu = self._sample_nu_from_alignment(idx) if t is None else t.to(self.device)
             if isinstance(idx, int):
                 ct, cr = self._trans._control_points[idx], self._rot._control_points[idx]
@@ -145,10 +173,15 @@ class CameraMotionModule:
         return self.gt_images[idx]
 
     def query(self, cam_idx: int, subframe_indice="all", post_process=None, background="random",
-              compute_blurred=True):
+              compute_blurred=True, shard=None):
         """Render a blurry view (scene/motion.py:78-160).  Returns the reference's dict: 'blurred', 'gt',
         'subframes' [f,3,H,W], 'depths' [f,1,H,W], 'render_pkgs' (list of f per-subframe dicts whose
-        'viewspace_points' entries are views of ONE [f,P,3] grad carrier, exposed as 'viewspace_points_all')."""
+        'viewspace_points' entries are views of ONE [f,P,3] grad carrier, exposed as 'viewspace_points_all').
+
+        shard=(rank, world): "subframes" sharding (deblurgs_amd.sharding): the view's f subframe cameras are computed on
+        every rank (a few hundred flops), but only the slice [floor(rank f / world), floor((rank+1) f / world)) is
+        rasterised here; 'subframes' / 'depths' / 'render_pkgs' then hold that slice, 'k0' its first index, 'K_total' = f,
+        and 'blurred' is None (the blur needs the other ranks' subframes: sharding.subframe_sharded_loss_backward)."""
         assert self.gaussians is not None
         gaussians = self.gaussians
         if isinstance(background, str) and background == "random":
@@ -167,6 +200,19 @@ class CameraMotionModule:
                 subfr_idx = subframe_indice
             nu = nu[subfr_idx]
         world_views, full_projs, centers = self.get_trajectory_matrices(cam_idx, nu)
+        K_total, k0 = world_views.shape[0], 0
+        if shard is not None:
+            from .sharding import shard_range
+            k0, k1 = shard_range(K_total, int(shard[0]), int(shard[1]))
+            if k1 == k0:        # more ranks than subframes: nothing to rasterise here
+                H, W = int(self.ref_cam.image_height), int(self.ref_cam.image_width)
+                dev, P = world_views.device, gaussians.get_xyz.shape[0]
+                e = lambda *shape, **kw: torch.zeros(shape, device=dev, **kw)
+                return {"blurred": None, "gt": self.get_gt_image(cam_idx), "subframes": e(0, 3, H, W),
+                        "depths": e(0, 1, H, W), "render_pkgs": [], "viewspace_points_all": e(0, P, 3),
+                        "radii_all": e(0, P, dtype=torch.int32), "background": bg, "k0": k0, "K_total": K_total}
+            world_views, full_projs, centers = world_views[k0:k1], full_projs[k0:k1], centers[k0:k1]
+            compute_blurred = False
         pkg = gaussian_renderer.render_subframes(world_views, full_projs, centers, self.ref_cam, gaussians, bg)
         render_subframes = pkg["render"]
         # compute_blurred=False: the caller takes the blur from the fused loss kernel (losses.blur_l1_smooth)
@@ -180,4 +226,4 @@ class CameraMotionModule:
                         "visibility_filter": pkg["visibility_filter"][i], "radii": pkg["radii"][i]} for i in range(f)]
         return {"blurred": blurred, "gt": self.get_gt_image(cam_idx), "subframes": render_subframes,
                 "depths": pkg["depth"], "render_pkgs": render_pkgs, "viewspace_points_all": pkg["viewspace_points"],
-                "radii_all": pkg["radii"], "background": bg}
+                "radii_all": pkg["radii"], "background": bg, "k0": k0, "K_total": K_total}

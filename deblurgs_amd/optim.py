@@ -23,9 +23,23 @@ def _stream(device):
 
 
 class FusedAdam(torch.optim.Optimizer):
+    # torch.optim.Adam's per-group keys: state_dict()["param_groups"] carries them, so that a checkpoint written with
+    # FusedAdam loads into torch.optim.Adam (the reference's restore, scene/gaussian_model.py:97-112) and the other way
+    # round.  Only these default values are implemented; step() rejects anything else.
+    _ADAM_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                          differentiable=False, fused=None, decoupled_weight_decay=False)
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clip_value=0.0):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, **self._ADAM_DEFAULTS))
         self.clip_value = float(clip_value)   # > 0: fused torch.nn.utils.clip_grad_value_ (train.py:204-205)
+
+    def _check_group(self, group):
+        for key, default in self._ADAM_DEFAULTS.items():
+            v = group.get(key, default)
+            if key in ("foreach", "fused"):
+                continue                       # implementation selectors of torch.optim.Adam: no effect on the maths
+            if v != default and not (key == "weight_decay" and float(v) == 0.0):
+                raise RuntimeError(f"FusedAdam implements torch.optim.Adam with {key}={default!r} only (got {v!r})")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -33,6 +47,8 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        for group in self.param_groups:
+            self._check_group(group)
         batches = {}
         keep = []
         for group in self.param_groups:

@@ -71,6 +71,90 @@ def se3_exp_map(log_transform: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
     return transform.permute(0, 2, 1)
 
 
+def _acos_linear_extrapolation(x, bound):
+    """acos(x) inside (-bound, bound), its first-order Taylor line outside (pytorch3d_functions.py:26-81)."""
+    def line(x0):
+        return (x - x0) * (-1.0 / math.sqrt(1.0 - x0 * x0)) + math.acos(x0)
+    inner = torch.acos(x.clamp(-bound, bound))
+    return torch.where(x >= bound, line(bound), torch.where(x <= -bound, line(-bound), inner))
+
+
+def so3_log_map(R: torch.Tensor, eps: float = 0.0001, cos_bound: float = 1e-4) -> torch.Tensor:
+    """[N,3,3] rotation matrices -> [N,3] logarithms (pytorch3d_functions.py:248-300 with so3_rotation_angle
+    :121-176 and hat_inv :303-336): angle from the trace through the linearly extrapolated acos, factor
+    phi / (2 sin phi) with its second-order Taylor value where |sin phi| <= eps / 2."""
+    if R.ndim != 3 or R.shape[1:] != (3, 3):
+        raise ValueError("Input has to be a batch of 3x3 Tensors.")
+    rot_trace = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    if ((rot_trace < -1.0 - eps) + (rot_trace > 3.0 + eps)).any():
+        raise ValueError("A matrix has trace outside valid range [-1-eps,3+eps].")
+    phi_cos = (rot_trace - 1.0) * 0.5
+    phi = _acos_linear_extrapolation(phi_cos, 1.0 - cos_bound) if cos_bound > 0.0 else torch.acos(phi_cos)
+    phi_sin = torch.sin(phi)
+    ok = phi_sin.abs() > (0.5 * eps)
+    safe = torch.where(ok, phi_sin, torch.ones_like(phi_sin))
+    phi_factor = torch.where(ok, phi / (2.0 * safe), 0.5 + (phi ** 2) * (1.0 / 12))
+    h = phi_factor[:, None, None] * (R - R.permute(0, 2, 1))
+    if float(torch.abs(h + h.permute(0, 2, 1)).max()) > 1e-5:
+        raise ValueError("One of input matrices is not skew-symmetric.")
+    return torch.stack((h[:, 2, 1], h[:, 0, 2], h[:, 1, 0]), dim=1)
+
+
+def se3_log_map(transform: torch.Tensor, eps: float = 1e-4, cos_bound: float = 1e-4) -> torch.Tensor:
+    """[N,4,4] SE(3) matrices in the row-vector convention [[R,0],[T,1]] -> [N,6] (log_translation | log_rotation)
+    (pytorch3d_functions.py:462-540): so3_log_map of the transposed upper-left block, translation = V^-1 T.
+    Used once, at initialisation, on the dataset's camera poses (scene/motion.py:196-205)."""
+    if transform.ndim != 3 or transform.shape[1:] != (4, 4):
+        raise ValueError("Input tensor shape has to be (N, 4, 4).")
+    if not torch.allclose(transform[:, :3, 3], torch.zeros_like(transform[:, :3, 3])):
+        raise ValueError("All elements of `transform[:, :3, 3]` should be 0.")
+    log_rotation = so3_log_map(transform[:, :3, :3].permute(0, 2, 1), eps=eps, cos_bound=cos_bound)
+    nrms = (log_rotation ** 2).sum(-1)
+    rotation_angles = torch.clamp(nrms, eps).sqrt()
+    skew = hat(log_rotation)
+    V = _se3_V_matrix(log_rotation, skew, torch.bmm(skew, skew), rotation_angles, eps=eps)
+    log_translation = torch.linalg.solve(V, transform[:, 3, :3][:, :, None])[:, :, 0]
+    return torch.cat((log_translation, log_rotation), dim=1)
+
+
+# ---- unit quaternions <-> rotation matrices for curve_type="quarternion_cartesian" (scene/motion.py:191-194,242-246).
+# The reference calls the third-party `roma` (unpinned in environment.yml:24, absent from /root/reference and from this
+# image): roma.rotmat_to_unitquat / roma.unitquat_to_rotmat, XYZW convention.  roma documents rotmat_to_unitquat as
+# adapted from SciPy's Rotation.from_matrix(...).as_quat(); that published algorithm is restated here and
+# tests/test_oracle_golden.py pins it against scipy (available in this image) -- "parity unpinned" against roma itself.
+def rotmat_to_unitquat(R: torch.Tensor) -> torch.Tensor:
+    """[N,3,3] -> [N,4] unit quaternions (x, y, z, w): pick the largest of (m00, m11, m22, trace) as pivot so that
+    no component is formed from a cancelling difference, then normalise.  No sign canonicalisation (as roma / scipy)."""
+    if R.ndim != 3 or R.shape[1:] != (3, 3):
+        raise ValueError("Input has to be a batch of 3x3 Tensors.")
+    m = R
+    trace = m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2]
+    decision = torch.stack([m[:, 0, 0], m[:, 1, 1], m[:, 2, 2], trace], dim=1)
+    choice = decision.argmax(dim=1)
+    quat = torch.empty((R.shape[0], 4), dtype=R.dtype, device=R.device)
+    for i in range(3):
+        j, k = (i + 1) % 3, (i + 2) % 3
+        q = torch.empty_like(quat)
+        q[:, i] = 1 - trace + 2 * m[:, i, i]
+        q[:, j] = m[:, j, i] + m[:, i, j]
+        q[:, k] = m[:, k, i] + m[:, i, k]
+        q[:, 3] = m[:, k, j] - m[:, j, k]
+        quat = torch.where((choice == i)[:, None], q, quat)
+    q = torch.stack([m[:, 2, 1] - m[:, 1, 2], m[:, 0, 2] - m[:, 2, 0], m[:, 1, 0] - m[:, 0, 1], 1 + trace], dim=1)
+    quat = torch.where((choice == 3)[:, None], q, quat)
+    return quat / quat.norm(dim=1, keepdim=True)
+
+
+def unitquat_to_rotmat(quat: torch.Tensor) -> torch.Tensor:
+    """[N,4] unit quaternions (x, y, z, w) -> [N,3,3]."""
+    x, y, z, w = quat.unbind(-1)
+    x2, y2, z2, w2 = x * x, y * y, z * z, w * w
+    xy, zw, xz, yw, yz, xw = x * y, z * w, x * z, y * w, y * z, x * w
+    return torch.stack([x2 - y2 - z2 + w2, 2 * (xy - zw), 2 * (xz + yw),
+                        2 * (xy + zw), -x2 + y2 - z2 + w2, 2 * (yz - xw),
+                        2 * (xz - yw), 2 * (yz + xw), -x2 - y2 + z2 + w2], dim=-1).reshape(quat.shape[:-1] + (3, 3))
+
+
 def _binom(n: int, k: int) -> float:
     return float(math.comb(n, k))
 

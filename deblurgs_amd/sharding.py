@@ -100,12 +100,41 @@ def _adopt_into_bucket(params):
     return bucket
 
 
-def flat_allreduce_grads(params, average=False, group=None):
-    """Sum (or average) the .grad of `params` over ranks with ONE collective on a flat fp32 bucket.  Gradients that
-    already are views of one flat buffer are reduced in place (no packing copies); RCCL averages inside the
-    collective."""
+def _allreduce(flat, average, group):
+    if average and dist.get_backend(group) == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= dist.get_world_size(group)
+
+
+def allreduce_small_grads(params, average=False, group=None):
+    """The trajectory parameters (curve control points, alignment) are replicated like the cloud; their gradients are a
+    few KB, packed into one small buffer and reduced next to the per-Gaussian bucket.  A parameter without a gradient on
+    this rank (its view was rendered elsewhere, or nothing reached it) contributes zeros, so that every rank calls the
+    collective with the same layout."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    params = [p for p in params if p is not None and p.numel() > 0]
+    if not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+    _allreduce(flat, average, group)
+    o = 0
+    for p in params:
+        p.grad = flat[o:o + p.numel()].view_as(p).to(p.dtype)
+        o += p.numel()
+
+
+def flat_allreduce_grads(params, average=False, group=None, extra=None):
+    """Sum (or average) the .grad of `params` over ranks with ONE collective on a flat fp32 bucket.  Gradients that
+    already are views of one flat buffer are reduced in place (no packing copies); RCCL averages inside the
+    collective.  `extra`: small replicated parameters (the trajectory groups) reduced by allreduce_small_grads."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    if extra:
+        allreduce_small_grads(extra, average=average, group=group)
     params = [p for p in params if p is not None]
     grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
     shared = None
@@ -123,12 +152,7 @@ def flat_allreduce_grads(params, average=False, group=None):
         flat = torch.zeros(total, dtype=torch.float32, device=grads[0].device)
         for g, o in zip(grads, offs):
             flat[o:o + g.numel()].copy_(g.reshape(-1))
-    if average and dist.get_backend(group) == "nccl":
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        if average:
-            flat /= dist.get_world_size(group)
+    _allreduce(flat, average, group)
     if shared is not None:
         return
     for p, g, o in zip(params, grads, offs):

@@ -8,7 +8,7 @@ import types
 import torch
 
 from . import losses
-from .cloud import get_expon_lr_func
+from .cloud import get_expon_lr_func, get_scheduler
 from .densify_stats import add_densification_stats_subframes
 
 
@@ -20,21 +20,36 @@ def default_optimization_params(**overrides):
              opacity_reset_interval=3000, densify_from_iter=500, densify_until_iter=75_000,
              densify_grad_threshold_init=4e-4, densify_grad_threshold_final=2e-4, densify_annealing_until=25_000,
              clip_grad=-1.0, curve_controlpoints_lr=1e-2, curve_rotation_lr=1e-3, curve_alignment_lr=0.0,
-             curve_lr_half_iter=15_000, curve_start_iter=1000, curve_end_iter=100_000)
+             curve_lr_half_iter=15_000, curve_start_iter=1000, curve_end_iter=100_000, curve_alignment_start=30_000,
+             random_sample_until=100_000, noise_init=0.0, noise_final=0.0)
     d.update(overrides)
     return types.SimpleNamespace(**d)
 
 
 class TrainingLoop:
     def __init__(self, gaussians, cam_motion_module, opt, cameras_extent, white_background=False, spatial_lr_scale=None,
-                 distributed=False):
-        """distributed=True ("views" sharding, deblurgs_amd.sharding): every rank steps on its own view; the
-        per-Gaussian gradients are averaged over ranks before the Adam step and the densification statistics are
-        combined before every densify_and_prune, so the replicas stay identical."""
+                 distributed=False, tone_mapping=None):
+        """distributed = "views" (or True): every rank steps on its own view (the caller passes each rank its cam_idx);
+        the per-Gaussian AND trajectory gradients are averaged over ranks (one flat all-reduce + one few-KB one) before
+        the Adam step and the densification statistics are combined before every densify_and_prune, so the replicas
+        (cloud, curves, alignment) stay identical.  This is a G-view mini-batch instead of the reference's one view per
+        step (train.py:126).
+        distributed = "subframes": every rank gets the SAME cam_idx and rasterises its share of that view's K subframes;
+        the loss is formed across ranks (sharding.subframe_sharded_loss_backward: partial blur sum + boundary
+        subframes) and the gradients are SUMMED -- exactly the reference's single-view step, K split over the ranks.
+        tone_mapping: the scene's ToneMapping (losses.ToneMapping("gamma"), arguments/__init__.py:71); its inverse is
+        applied to the ground truth as train.py:141-145 does every iteration (here once per image, cached).  None =
+        the ground-truth images are already linear.
+        Not carried over from train.py: logging / visualiser / checkpoint-saving calls and `args.flag`."""
         self.gaussians, self.motion, self.opt, self.extent = gaussians, cam_motion_module, opt, cameras_extent
-        self.distributed = distributed
+        self.mode = {True: "views", False: None, None: None}.get(distributed, distributed)
+        if self.mode not in (None, "views", "subframes"):
+            raise ValueError("distributed must be False, 'views' or 'subframes'")
+        self.distributed = self.mode is not None
         self._stat_prev = None
         self.white_background = white_background
+        self.tone_inverse = None if tone_mapping is None else tone_mapping.inverse()
+        self._gt_linear = {}
         gaussians.training_setup(opt, spatial_lr_scale=cameras_extent if spatial_lr_scale is None else spatial_lr_scale)
         cam_motion_module.link_gaussian(gaussians)
         cam_motion_module.add_training_setup(gaussians, {"curve_rot": opt.curve_rotation_lr,
@@ -44,16 +59,33 @@ class TrainingLoop:
                                                         max_steps=opt.densify_annealing_until)
         self.lambda_t_smooth_func = get_expon_lr_func(opt.lambda_t_smooth_init, opt.lambda_t_smooth_final,
                                                       max_steps=opt.iterations)
-        if opt.curve_start_iter > 1:
-            cam_motion_module.alternate_optimization()          # train.py:100 -- curve gradients off until curve_start_iter
+        self.noise_func = get_expon_lr_func(getattr(opt, "noise_init", 0.0), getattr(opt, "noise_final", 0.0),
+                                            max_steps=opt.iterations)
+        self.alignment_func = get_scheduler(lr_init=opt.curve_alignment_lr, lr_final=1e-7, warmup_ratio=0.0,
+                                            step_warmup=getattr(opt, "curve_alignment_start", 30_000),
+                                            step_final=opt.iterations)                  # train.py:90-94
+        cam_motion_module.alternate_optimization()      # train.py:102, unconditional: curve gradients off at the start
+
+    def _ground_truth(self, cam_idx, gt, iteration):
+        """train.py:141-145: gt = tone_mapping.inverse()(gt) + randn * noise(iteration)."""
+        if self.tone_inverse is not None:
+            if cam_idx not in self._gt_linear:
+                self._gt_linear[cam_idx] = self.tone_inverse(gt)
+            gt = self._gt_linear[cam_idx]
+        noise = self.noise_func(iteration)
+        if noise > 0.0:
+            gt = gt + torch.randn_like(gt) * noise
+        return gt
 
     def step(self, iteration, cam_idx):
         g, opt = self.gaussians, self.opt
-        g.update_learning_rate(iteration, opt)
+        g.update_learning_rate(iteration, opt, alignment_lr=self.alignment_func(iteration))     # train.py:109
         densification_threshold = self.densify_threshold_func(iteration)
         lambda_t_smooth = self.lambda_t_smooth_func(iteration)
         if iteration == opt.curve_start_iter or iteration == opt.curve_end_iter:
             self.motion.alternate_optimization()
+        if iteration == getattr(opt, "random_sample_until", -1):
+            self.motion.curve_random_sample = False                                              # train.py:118-119
         if iteration % 1000 == 0:
             g.oneupSHdegree()
         subframe_indice = "all" if iteration >= opt.curve_start_iter else 1
@@ -61,8 +93,12 @@ class TrainingLoop:
         # rasteriser's gradient (a view of the flat gradient buffer) becomes `_opacity.grad` and the hinge term is added
         # into it in place -- the six gradients stay one contiguous bucket for the all-reduce.
         L_hinge = losses.hinge_l2(g._opacity) if opt.lambda_hinge > 0.0 else None
+        if self.mode == "subframes":
+            return self._step_subframe_sharded(iteration, cam_idx, subframe_indice, lambda_t_smooth, L_hinge,
+                                               densification_threshold)
         r = self.motion.query(cam_idx=cam_idx, subframe_indice=subframe_indice, compute_blurred=False)
-        total, blur, lv = losses.blur_l1_smooth(r["subframes"], r["gt"], lambda_t_smooth)
+        gt = self._ground_truth(cam_idx, r["gt"], iteration)
+        total, blur, lv = losses.blur_l1_smooth(r["subframes"], gt, lambda_t_smooth)
         Ll1, L_t = lv[0], lv[1]
         loss = total
         if L_hinge is not None:
@@ -72,13 +108,47 @@ class TrainingLoop:
         loss.backward()
         if self.distributed:
             from . import sharding
-            sharding.flat_allreduce_grads(g.hot_parameters(), average=True)
+            # the trajectory parameters are replicated too: their gradients (rows of the views other ranks rendered
+            # are zero here) join the reduction, so every replica takes the same curve / alignment step
+            sharding.flat_allreduce_grads(g.hot_parameters(), average=True,
+                                          extra=[p for p in self.motion.parameters() if p.requires_grad])
+        self._tail(iteration, r, densification_threshold)
+        return {"loss": loss.detach(), "l1": Ll1, "smooth": L_t, "hinge": L_hinge, "num_points": g._xyz.shape[0]}
+
+    def _step_subframe_sharded(self, iteration, cam_idx, subframe_indice, lambda_t_smooth, L_hinge,
+                               densification_threshold):
+        import torch.distributed as dist
+        from . import sharding
+        g, opt = self.gaussians, self.opt
+        if opt.lambda_depth_tv > 0.0:
+            raise NotImplementedError("lambda_depth_tv with 'subframes' sharding")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        r = self.motion.query(cam_idx=cam_idx, subframe_indice=subframe_indice, compute_blurred=False,
+                              shard=(rank, world))
+        gt = self._ground_truth(cam_idx, r["gt"], iteration)
+        l1, sm = sharding.subframe_sharded_loss_backward(r["subframes"], gt, r["K_total"], r["k0"], lambda_t_smooth)
+        if L_hinge is not None:
+            # every rank holds the whole cloud: the hinge gradient is added once, on rank 0, and reaches the others
+            # through the gradient sum (after the rasteriser's backward, so that it accumulates into the bucket)
+            (opt.lambda_hinge * L_hinge * (1.0 if rank == 0 else 0.0)).backward()
+        sharding.flat_allreduce_grads(g.hot_parameters(), average=False,
+                                      extra=[p for p in self.motion.parameters() if p.requires_grad])
+        self._tail(iteration, r, densification_threshold)
+        loss = l1 + lambda_t_smooth * sm + (opt.lambda_hinge * float(L_hinge) if L_hinge is not None else 0.0)
+        return {"loss": torch.tensor(loss), "l1": torch.tensor(l1), "smooth": torch.tensor(sm), "hinge": L_hinge,
+                "num_points": g._xyz.shape[0]}
+
+    def _tail(self, iteration, r, densification_threshold):
+        """train.py:186-208: densification statistics, densify / reset on their schedule, the optimiser step."""
+        from . import sharding
+        g, opt = self.gaussians, self.opt
         with torch.no_grad():
             if iteration < opt.densify_until_iter:
                 if self.distributed and self._stat_prev is None:
                     self._stat_prev = (g.xyz_gradient_accum.clone(), g.denom.clone())
-                add_densification_stats_subframes(r["viewspace_points_all"], r["radii_all"], g.max_radii2D,
-                                                  g.xyz_gradient_accum, g.denom)
+                if r["radii_all"].shape[0] > 0:
+                    add_densification_stats_subframes(r["viewspace_points_all"], r["radii_all"], g.max_radii2D,
+                                                      g.xyz_gradient_accum, g.denom, K_total=r["K_total"])
                 if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
                     if self.distributed:
                         sharding.allreduce_densification_stats(g, self._stat_prev)
@@ -94,4 +164,4 @@ class TrainingLoop:
             if iteration < opt.iterations:
                 g.optimizer.step()                      # clip_grad_value_ is fused into the step (FusedAdam.clip_value)
                 g.optimizer.zero_grad(set_to_none=True)
-        return {"loss": loss.detach(), "l1": Ll1, "smooth": L_t, "hinge": L_hinge, "num_points": g._xyz.shape[0]}
+

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 3
+#define DGS_ABI_VERSION 4
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -201,10 +201,12 @@ int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32
 /* Densification-statistic consumers of the rasteriser's per-subframe outputs (train.py:188-193 with
  * scene/gaussian_model.py:456-458), for all K subframes in one pass and in subframe order:
  *   visible = radii[k] > 0;  max_radii2D = max(max_radii2D, radii[k]);
- *   xyz_gradient_accum += || viewspace_grad[k][:, :2] ||;  denom += 1/K.
- * viewspace_grad is the [K,P,3] gradient of the means2D carrier, radii is [K,P]; the three accumulators are [P]. */
-int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t P, float* max_radii2D,
-                      float* xyz_gradient_accum, float* denom, dgs_stream_t stream);
+ *   xyz_gradient_accum += || viewspace_grad[k][:, :2] ||;  denom += 1/K_total.
+ * viewspace_grad is the [K,P,3] gradient of the means2D carrier, radii is [K,P]; the three accumulators are [P].
+ * K_total = len(render_pkgs) of the whole view (train.py:192): K itself (pass 0) unless the view's subframes are
+ * split over ranks and this call covers only a rank's share. */
+int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t K_total, int32_t P,
+                      float* max_radii2D, float* xyz_gradient_accum, float* denom, dgs_stream_t stream);
 
 /* ---- optimiser step and densification of the Gaussian cloud ----------------------------------
  * Multi-tensor Adam: all parameter groups in one launch.  Replaces torch.optim.Adam(l, lr=0.0, eps=1e-15).step()
@@ -275,6 +277,13 @@ int dgs_pose_forward(const float* ctrl_trans, const float* ctrl_rot, const float
 int dgs_pose_backward(const float* ctrl_trans, const float* ctrl_rot, const float* nu, const float* proj, int32_t C,
                       int32_t K, const float* dL_dview, const float* dL_dfull, void* scratch, float* dL_dctrl_trans,
                       float* dL_dctrl_rot, float* dL_dnu, dgs_stream_t stream);
+
+/* The cloud's activations as the raw_params kernels evaluate them -- clamp(opacity, 0, 1), exp(scaling) + scale_lb,
+ * rotation / max(|rotation|, 1e-12): the reference's get_opacity / get_scaling / get_rotation getters
+ * (scene/gaussian_model.py:114-137, scene/gaussian_activation.py:29-52) on device, bit-identical to what
+ * dgs_forward_geometry uses with DgsProblem.raw_params = 1.  Any output pointer may be NULL (with its input). */
+int dgs_cloud_activations(int32_t P, const float* scaling, const float* rotation, const float* opacity, float scale_lb,
+                          float* out_scaling, float* out_rotation, float* out_opacity, dgs_stream_t stream);
 
 /* Stage timing with HIP events recorded on the caller's stream (bench.py's roofline leg). */
 #define DGS_STAGE_PREPROCESS 0

@@ -20,8 +20,14 @@
 // (GLM column-major mat3 products: third_party/glm/glm/detail/type_mat3x3.inl:486-518), ndc2Pix and
 // the dL_dproj terms in double.  float->int conversions saturate like the GPU's v_cvt_i32_f32.
 // Built twice from this one file (oracle/Makefile): libdgs_oracle.so (single thread, the parity checker) and
-// libdgs_oracle_omp.so (-fopenmp: tile/Gaussian loops spread over the host cores, accumulations become
-// `omp atomic`; used ONLY by bench.py's cpu_baseline leg, where summation order does not matter).
+// libdgs_oracle_omp.so (-fopenmp: tile/Gaussian loops spread over the host cores; used by bench.py's cpu_baseline leg
+// and by the BASELINE-size parity tests, where the single-thread build would take minutes).  The OpenMP build is
+// DETERMINISTIC and independent of the thread count: every place where the reference (and the single-thread build)
+// accumulates with float atomicAdds -- whose order the reference itself leaves undefined, backward.cu:599-637,
+// :277-294, :434-459 -- the OpenMP build accumulates in DOUBLE: per (tile, Gaussian) duplicate in pixel order, then per
+// Gaussian in duplicate order; pose sums per fixed 4096-Gaussian chunk, then over chunks in order.  Each individual
+// contribution is the same fp32 value in both builds; only the summation differs (the OpenMP build returns the
+// correctly rounded centre of the reference's order-dependent fp32 results).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -245,7 +251,15 @@ vec3 computeColorFromSH(int idx, int deg, int max_coeffs, const float* means, ve
 
 }  // namespace
 
+// OpenMP build only: 1 = round every accumulation of the compositing backward to fp32 (same deterministic order as the
+// double accumulation).  The difference between the two modes is the fp32 rounding noise of THAT summation structure
+// (per duplicate, then per Gaussian over duplicates -- the structure the HIP path uses too); the parity tests use it as
+// the noise floor next to the 1e-4 bar.
+bool g_accum_f32 = false;
+
 extern "C" {
+
+void dgs_oracle_set_accum_f32(int on) { g_accum_f32 = on != 0; }
 
 int dgs_oracle_threads(void) {
 #ifdef _OPENMP
@@ -438,6 +452,21 @@ void dgs_oracle_render_backward(int W, int H, const uint32_t* ranges, const uint
   const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
   const float ddelx_dx = 0.5 * W;  // backward.cu:535-536
   const float ddely_dy = 0.5 * H;
+#ifdef _OPENMP
+  // one row of double accumulators per (tile, Gaussian) duplicate = per position of the sorted list
+  uint32_t Rtot = 0;
+  for (int t = 0; t < gx * gy; t++) Rtot = std::max(Rtot, ranges[2 * t + 1]);
+  std::vector<double> dacc((size_t)Rtot * 10, 0.0);
+  const bool f32 = g_accum_f32;  // emulate fp32 accumulation in the same order (noise-floor estimate)
+#define DGS_ACC(slot, dst, val)                                   \
+  do {                                                            \
+    double& a__ = dacc[(size_t)s * 10 + (slot)];                  \
+    a__ += (double)(val);                                         \
+    if (f32) a__ = (double)(float)a__;                            \
+  } while (0)
+#else
+#define DGS_ACC(slot, dst, val) dst += (val)
+#endif
 #pragma omp parallel for collapse(2) schedule(dynamic, 4)
   for (int ty = 0; ty < gy; ty++)
     for (int tx = 0; tx < gx; tx++) {
@@ -480,15 +509,13 @@ void dgs_oracle_render_backward(int W, int H, const uint32_t* ranges, const uint
               last_color[ch] = c;
               const float dL_dchannel = dL_dpixel[ch];
               dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
-              _Pragma("omp atomic")
-            dL_dcolors[3 * (size_t)g + ch] += dchannel_dcolor * dL_dchannel;
+              DGS_ACC(ch, dL_dcolors[3 * (size_t)g + ch], dchannel_dcolor * dL_dchannel);
             }
             const float c_d = depths[g];
             accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
             last_depth = c_d;
             dL_dalpha += (c_d - accum_depth_rec) * dL_dpixeldepth;
-            _Pragma("omp atomic")
-            dL_ddepths[g] += dchannel_dcolor * dL_dpixeldepth;
+            DGS_ACC(3, dL_ddepths[g], dchannel_dcolor * dL_dpixeldepth);
             dL_dalpha *= T;
             last_alpha = alpha;
             float bg_dot_dpixel = 0;
@@ -500,21 +527,47 @@ void dgs_oracle_render_backward(int W, int H, const uint32_t* ranges, const uint
             const float gdy = G * dy;
             const float dG_ddelx = -gdx * co[0] - gdy * co[1];
             const float dG_ddely = -gdy * co[2] - gdx * co[1];
-            _Pragma("omp atomic")
-            dL_dmean2D[3 * (size_t)g + 0] += dL_dG * dG_ddelx * ddelx_dx;
-            _Pragma("omp atomic")
-            dL_dmean2D[3 * (size_t)g + 1] += dL_dG * dG_ddely * ddely_dy;
-            _Pragma("omp atomic")
-            dL_dconic2D[4 * (size_t)g + 0] += -0.5f * gdx * dx * dL_dG;
-            _Pragma("omp atomic")
-            dL_dconic2D[4 * (size_t)g + 1] += -0.5f * gdx * dy * dL_dG;
-            _Pragma("omp atomic")
-            dL_dconic2D[4 * (size_t)g + 3] += -0.5f * gdy * dy * dL_dG;
-            _Pragma("omp atomic")
-            dL_dopacity[g] += G * dL_dalpha;
+            DGS_ACC(4, dL_dmean2D[3 * (size_t)g + 0], dL_dG * dG_ddelx * ddelx_dx);
+            DGS_ACC(5, dL_dmean2D[3 * (size_t)g + 1], dL_dG * dG_ddely * ddely_dy);
+            DGS_ACC(6, dL_dconic2D[4 * (size_t)g + 0], -0.5f * gdx * dx * dL_dG);
+            DGS_ACC(7, dL_dconic2D[4 * (size_t)g + 1], -0.5f * gdx * dy * dL_dG);
+            DGS_ACC(8, dL_dconic2D[4 * (size_t)g + 3], -0.5f * gdy * dy * dL_dG);
+            DGS_ACC(9, dL_dopacity[g], G * dL_dalpha);
           }
         }
     }
+#undef DGS_ACC
+#ifdef _OPENMP
+  {
+    // per Gaussian: sum its duplicates' rows in duplicate (= tile) order, in double, round once.  P is not an argument
+    // of this entry point; the sums are formed in a map keyed by the point list instead.
+    uint32_t maxg = 0;
+    for (uint32_t s = 0; s < Rtot; s++) maxg = std::max(maxg, point_list[s]);
+    std::vector<double> gsum(((size_t)maxg + 1) * 10, 0.0);
+    for (uint32_t s = 0; s < Rtot; s++) {
+      const size_t g = point_list[s];
+      for (int i = 0; i < 10; i++) {
+        gsum[g * 10 + i] += dacc[(size_t)s * 10 + i];
+        if (f32) gsum[g * 10 + i] = (double)(float)gsum[g * 10 + i];
+      }
+    }
+    std::vector<uint8_t> seen((size_t)maxg + 1, 0);
+    for (uint32_t s = 0; s < Rtot; s++) seen[point_list[s]] = 1;
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g <= (int64_t)maxg; g++) {
+      if (!seen[g]) continue;
+      const double* a = &gsum[(size_t)g * 10];
+      for (int ch = 0; ch < 3; ch++) dL_dcolors[3 * g + ch] = (float)a[ch];
+      dL_ddepths[g] = (float)a[3];
+      dL_dmean2D[3 * g + 0] = (float)a[4];
+      dL_dmean2D[3 * g + 1] = (float)a[5];
+      dL_dconic2D[4 * g + 0] = (float)a[6];
+      dL_dconic2D[4 * g + 1] = (float)a[7];
+      dL_dconic2D[4 * g + 3] = (float)a[8];
+      dL_dopacity[g] = (float)a[9];
+    }
+  }
+#endif
 }
 
 // BACKWARD::preprocess = computeCov2DCUDA (backward.cu:145-295) then preprocessCUDA (backward.cu:367-460)
@@ -531,8 +584,23 @@ void dgs_oracle_preprocess_backward(int P, int D, int M, int W, int H, const flo
   const float h_y = H / (2.0f * tan_fovy);
   const float h_x = W / (2.0f * tan_fovx);
   const vec3 campos = {campos_[0], campos_[1], campos_[2]};
+  // Pose sums: the single-thread build adds every contribution to the fp32 result in index order (the reference uses
+  // float atomicAdds in an undefined order); the OpenMP build adds them in double per fixed chunk of POSE_CHUNK
+  // Gaussians and then over the chunks in order (deterministic, thread-count independent, rounded once at the end).
+  constexpr int POSE_CHUNK = 4096;
+  const int nchunks = (P + POSE_CHUNK - 1) / POSE_CHUNK;
+#ifdef _OPENMP
+  std::vector<double> part_view((size_t)nchunks * 16 * 2, 0.0), part_proj((size_t)nchunks * 16, 0.0);
+#endif
   // ---- computeCov2DCUDA
-  for (int idx = 0; idx < P; idx++) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int chunk = 0; chunk < nchunks; chunk++) {
+#ifdef _OPENMP
+  double* dL_dview_matrix_acc = &part_view[(size_t)chunk * 16];
+#else
+  float* dL_dview_matrix_acc = dL_dview_matrix;
+#endif
+  for (int idx = chunk * POSE_CHUNK; idx < std::min(P, (chunk + 1) * POSE_CHUNK); idx++) {
     if (!(radii[idx] > 0)) continue;
     const float* cov3D = cov3Ds + 6 * (size_t)idx;
     vec3 mean = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
@@ -603,21 +671,31 @@ void dgs_oracle_preprocess_backward(int P, int D, int M, int W, int H, const flo
     dL_dmeans[3 * idx + 1] = dL_dmean.y;
     dL_dmeans[3 * idx + 2] = dL_dmean.z;
     // backward.cu:277-294 -- view-matrix gradient through t = view * mean only
-    dL_dview_matrix[0] += dL_dtx * mean.x;
-    dL_dview_matrix[1] += dL_dty * mean.x;
-    dL_dview_matrix[2] += dL_dtz * mean.x;
-    dL_dview_matrix[4] += dL_dtx * mean.y;
-    dL_dview_matrix[5] += dL_dty * mean.y;
-    dL_dview_matrix[6] += dL_dtz * mean.y;
-    dL_dview_matrix[8] += dL_dtx * mean.z;
-    dL_dview_matrix[9] += dL_dty * mean.z;
-    dL_dview_matrix[10] += dL_dtz * mean.z;
-    dL_dview_matrix[12] += dL_dtx;
-    dL_dview_matrix[13] += dL_dty;
-    dL_dview_matrix[14] += dL_dtz;
+    dL_dview_matrix_acc[0] += dL_dtx * mean.x;
+    dL_dview_matrix_acc[1] += dL_dty * mean.x;
+    dL_dview_matrix_acc[2] += dL_dtz * mean.x;
+    dL_dview_matrix_acc[4] += dL_dtx * mean.y;
+    dL_dview_matrix_acc[5] += dL_dty * mean.y;
+    dL_dview_matrix_acc[6] += dL_dtz * mean.y;
+    dL_dview_matrix_acc[8] += dL_dtx * mean.z;
+    dL_dview_matrix_acc[9] += dL_dty * mean.z;
+    dL_dview_matrix_acc[10] += dL_dtz * mean.z;
+    dL_dview_matrix_acc[12] += dL_dtx;
+    dL_dview_matrix_acc[13] += dL_dty;
+    dL_dview_matrix_acc[14] += dL_dtz;
+  }
   }
   // ---- preprocessCUDA (bwd)
-  for (int idx = 0; idx < P; idx++) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int chunk = 0; chunk < nchunks; chunk++) {
+#ifdef _OPENMP
+  double* dL_dview_matrix_acc = &part_view[(size_t)(nchunks + chunk) * 16];
+  double* dL_dproj_acc = &part_proj[(size_t)chunk * 16];
+#else
+  float* dL_dview_matrix_acc = dL_dview_matrix;
+  float* dL_dproj_acc = dL_dproj;
+#endif
+  for (int idx = chunk * POSE_CHUNK; idx < std::min(P, (chunk + 1) * POSE_CHUNK); idx++) {
     if (!(radii[idx] > 0)) continue;
     vec3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
     vec4 m_hom = transformPoint4x4(m, proj);
@@ -757,23 +835,71 @@ void dgs_oracle_preprocess_backward(int P, int D, int M, int W, int H, const flo
     // backward.cu:423-457 -- the reference's (non-analytic) projection-matrix gradient, double arithmetic
     // rounded to float per contribution, plus the depth term of the view-matrix gradient.
     const float lastcol_element = (m_hom.x * W * g2x + m_hom.y * H * g2y) * m_w * m_w;
-    dL_dproj[0] += (float)(0.5 * g2x * m.x * W * m_w);
-    dL_dproj[1] += (float)(0.5 * g2y * m.x * H * m_w);
-    dL_dproj[3] += (float)(-0.5 * lastcol_element);
-    dL_dproj[4] += (float)(0.5 * g2x * m.y * W * m_w);
-    dL_dproj[5] += (float)(0.5 * g2y * m.y * H * m_w);
-    dL_dproj[7] += (float)(-0.5 * lastcol_element);
-    dL_dproj[8] += (float)(0.5 * g2x * m.z * W * m_w);
-    dL_dproj[9] += (float)(0.5 * g2y * m.z * H * m_w);
-    dL_dproj[11] += (float)(-0.5 * lastcol_element);
-    dL_dproj[12] += (float)(0.5 * g2x * W * m_w);
-    dL_dproj[13] += (float)(0.5 * g2y * H * m_w);
-    dL_dproj[15] += (float)(-0.5 * lastcol_element);
-    dL_dview_matrix[2] += dL_ddepth[idx] * m.x;
-    dL_dview_matrix[6] += dL_ddepth[idx] * m.y;
-    dL_dview_matrix[10] += dL_ddepth[idx] * m.z;
-    dL_dview_matrix[14] += dL_ddepth[idx];
+    dL_dproj_acc[0] += (float)(0.5 * g2x * m.x * W * m_w);
+    dL_dproj_acc[1] += (float)(0.5 * g2y * m.x * H * m_w);
+    dL_dproj_acc[3] += (float)(-0.5 * lastcol_element);
+    dL_dproj_acc[4] += (float)(0.5 * g2x * m.y * W * m_w);
+    dL_dproj_acc[5] += (float)(0.5 * g2y * m.y * H * m_w);
+    dL_dproj_acc[7] += (float)(-0.5 * lastcol_element);
+    dL_dproj_acc[8] += (float)(0.5 * g2x * m.z * W * m_w);
+    dL_dproj_acc[9] += (float)(0.5 * g2y * m.z * H * m_w);
+    dL_dproj_acc[11] += (float)(-0.5 * lastcol_element);
+    dL_dproj_acc[12] += (float)(0.5 * g2x * W * m_w);
+    dL_dproj_acc[13] += (float)(0.5 * g2y * H * m_w);
+    dL_dproj_acc[15] += (float)(-0.5 * lastcol_element);
+    dL_dview_matrix_acc[2] += dL_ddepth[idx] * m.x;
+    dL_dview_matrix_acc[6] += dL_ddepth[idx] * m.y;
+    dL_dview_matrix_acc[10] += dL_ddepth[idx] * m.z;
+    dL_dview_matrix_acc[14] += dL_ddepth[idx];
   }
+  }
+#ifdef _OPENMP
+  for (int i = 0; i < 16; i++) {
+    double v = 0.0, pj = 0.0;
+    for (int c = 0; c < 2 * nchunks; c++) v += part_view[(size_t)c * 16 + i];
+    for (int c = 0; c < nchunks; c++) pj += part_proj[(size_t)c * 16 + i];
+    // (the fp32-emulation mode does not cover the pose sums: their noise floor is reported by the term norms below)
+    dL_dview_matrix[i] += (float)v;
+    dL_dproj[i] += (float)pj;
+  }
+#endif
+}
+
+// Pixels whose ORACLE traversal has a (pixel, Gaussian) pair within a small margin of one of the reference's three
+// thresholds (power > 0, alpha < 1/255, T (1 - alpha) < 1e-4: forward.cu:356-368).  exp() differs by an ulp or two
+// between glibc, CUDA libdevice and the gfx950 v_exp_f32, so such a pair may legitimately fall on either side; the
+// parity tests hold every other pixel to the 1e-4 bar and count these.  Same rule as tests/helpers.unstable_pixels
+// (numpy, small scenes); this one is usable at BASELINE sizes.  flag is [H*W], zero-initialised by the caller.
+void dgs_oracle_unstable(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                         const float* conic_opacity, float alpha_tol, float power_tol, float T_tol, uint8_t* flag) {
+  const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
+  for (int ty = 0; ty < gy; ty++)
+    for (int tx = 0; tx < gx; tx++) {
+      const uint32_t r0 = ranges[2 * (ty * gx + tx)], r1 = ranges[2 * (ty * gx + tx) + 1];
+      for (int ly = 0; ly < BLOCK_Y; ly++)
+        for (int lx = 0; lx < BLOCK_X; lx++) {
+          const int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+          if (!(px < W && py < H)) continue;
+          const float pfx = (float)px, pfy = (float)py;
+          float T = 1.0f;
+          bool near = false;
+          for (uint32_t s = r0; s < r1 && !near; s++) {
+            const uint32_t g = point_list[s];
+            const float dx = means2D[2 * g] - pfx, dy = means2D[2 * g + 1] - pfy;
+            const float* co = conic_opacity + 4 * (size_t)g;
+            const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+            const float alpha = std::min(0.99f, co[3] * std::exp(power));
+            if (std::fabs(alpha - 1.0f / 255.0f) < alpha_tol || std::fabs(power) < power_tol) near = true;
+            if (power > 0.0f || alpha < 1.0f / 255.0f) continue;
+            const float test_T = T * (1 - alpha);
+            if (std::fabs(test_T - 0.0001f) < T_tol) near = true;
+            if (test_T < 0.0001f) break;
+            T = test_T;
+          }
+          if (near) flag[(size_t)W * py + px] = 1;
+        }
+    }
 }
 
 // checkFrustum / markVisible (rasterizer_impl.cu:54-66,141-153)

@@ -54,6 +54,13 @@ def use_openmp(on=True):
     return lib().dgs_oracle_threads()
 
 
+def set_accum_f32(on):
+    """OpenMP build only: accumulate the compositing backward in emulated fp32 (same deterministic order as the default
+    double accumulation).  |double - f32| is the rounding-noise floor the parity tests put next to their 1e-4 bar."""
+    assert _use_omp, "the fp32-emulation mode belongs to the OpenMP (deterministic, double-accumulating) build"
+    lib().dgs_oracle_set_accum_f32(int(bool(on)))
+
+
 def lib():
     global _lib, _lib_omp
     if not os.path.exists(_LIB_PATH) or not os.path.exists(_LIB_OMP_PATH):
@@ -175,6 +182,17 @@ def backward(st, dL_dcolor, dL_ddepth=None):
     g["dL_dviewmatrix"] = g["dL_dviewmatrix"].reshape(4, 4)
     g["dL_dprojmatrix"] = g["dL_dprojmatrix"].reshape(4, 4)
     return g
+
+
+def unstable(st, alpha_tol=5e-7, power_tol=1e-4, T_tol=1e-8):
+    """[H,W] bool: pixels where some pair of the oracle's own traversal sits within a margin of one of the reference's
+    three thresholds (dgs_oracle_unstable; same rule as tests/helpers.unstable_pixels, usable at BASELINE sizes)."""
+    W, H = st["W"], st["H"]
+    flag = np.zeros(W * H, np.uint8)
+    lib().dgs_oracle_unstable(W, H, _p(st["ranges"], _u32p), _p(st["point_list"], _u32p), _p(st["means2D"], _f32p),
+                              _p(st["conic_opacity"], _f32p), ctypes.c_float(alpha_tol), ctypes.c_float(power_tol),
+                              ctypes.c_float(T_tol), _p(flag, _u8p))
+    return flag.reshape(H, W).astype(bool)
 
 
 def mark_visible(means3D, viewmatrix):

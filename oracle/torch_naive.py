@@ -117,8 +117,10 @@ def preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx
 
 
 def rasterize(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy, z_far=100.0,
-              pixel_chunk=8192, **kw):
-    """Returns (color [3,H,W], depth [1,H,W], radii [P]).  All tensor inputs may require grad."""
+              pixel_chunk=8192, window=None, **kw):
+    """Returns (color [3,H,W], depth [1,H,W], radii [P]).  All tensor inputs may require grad.
+    window=(x0, y0, x1, y1): render only that pixel rectangle of the W x H image (outputs [3,y1-y0,x1-x0] /
+    [1,y1-y0,x1-x0]) from the Gaussians whose tile rectangle meets it -- the bounded sample bench.py times."""
     g = preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, **kw)
     dt = means3D.dtype
     vis = g["visible"]
@@ -128,11 +130,21 @@ def rasterize(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanf
     idx = idx[order]
     pix, conic, op, col, dep = g["pix"][idx], g["conic"][idx], g["opacity"][idx], g["color"][idx], g["depth"][idx]
     minx, miny, maxx, maxy = (r[idx] for r in g["rect"])
-    N = W * H
+    if window is not None:
+        x0, y0, x1, y1 = window
+        meets = (minx * 16 < x1) & (maxx * 16 > x0) & (miny * 16 < y1) & (maxy * 16 > y0)
+        pix, conic, op, col, dep = pix[meets], conic[meets], op[meets], col[meets], dep[meets]
+        minx, miny, maxx, maxy = minx[meets], miny[meets], maxx[meets], maxy[meets]
+        wpix = torch.stack(torch.meshgrid(torch.arange(y0, y1), torch.arange(x0, x1), indexing="ij"), -1).reshape(-1, 2)
+        all_pid = wpix[:, 0] * W + wpix[:, 1]
+    else:
+        x0, y0, x1, y1 = 0, 0, W, H
+        all_pid = torch.arange(W * H)
+    N = all_pid.shape[0]
     out_c = []
     out_d = []
     for s in range(0, N, pixel_chunk):
-        pid = torch.arange(s, min(s + pixel_chunk, N))
+        pid = all_pid[s:min(s + pixel_chunk, N)]
         pxi, pyi = pid % W, pid // W
         px, py = pxi.to(dt), pyi.to(dt)
         tx_, ty_ = (pxi // 16).to(dt), (pyi // 16).to(dt)
@@ -159,7 +171,7 @@ def rasterize(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanf
         Dp = w @ dep + T_final * z_far
         out_c.append(C)
         out_d.append(Dp)
-    color = torch.cat(out_c, 0).T.reshape(3, H, W)
-    depth = torch.cat(out_d, 0).reshape(1, H, W)
+    color = torch.cat(out_c, 0).T.reshape(3, y1 - y0, x1 - x0)
+    depth = torch.cat(out_d, 0).reshape(1, y1 - y0, x1 - x0)
     radii = torch.where(vis, g["radius"], torch.zeros_like(g["radius"])).to(torch.int32)
     return color, depth, radii

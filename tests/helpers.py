@@ -237,3 +237,211 @@ def relerr(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def grad_errors(a, b, rows=None, floor=0.05):
+    """Sharper than relerr (which lets a component 1e4 x smaller than the tensor's largest one be 100 % wrong):
+
+      col  max over the COLUMNS (the 3 / 27 / 1 / 3 / 4 components of a per-Gaussian gradient, each with its own
+           scale) of  max_g |a - b| / max_g |b|   -- every component is held to the bar against its own magnitude;
+      row  max over the ROWS (Gaussians) of  max_c |a - b| / max(max_c |b_row|, floor * column scale)  -- a relative
+           error per Gaussian, with an absolute floor so that Gaussians whose gradient is below `floor` of the
+           largest one are measured against that floor rather than against their own near-zero value.
+
+    a, b: arrays whose leading `rows` dimension indexes Gaussians (default: first axis)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    n = a.shape[0] if rows is None else rows
+    a, b = a.reshape(n, -1), b.reshape(n, -1)
+    d = np.abs(a - b)
+    colmax = np.abs(b).max(axis=0)
+    nz = colmax > 0
+    col = float((d[:, nz].max(axis=0) / colmax[nz]).max()) if nz.any() else float(d.max())
+    # rows: each component normalised by its column scale first, so that components of different magnitude
+    # (xyz vs the 27 SH coefficients) are commensurable inside one row
+    scale = np.where(nz, colmax, 1.0)
+    dn, bn = d / scale, np.abs(b) / scale
+    row = float((dn.max(axis=1) / np.maximum(bn.max(axis=1), floor)).max())
+    return {"col": col, "row": row}
+
+
+# ------------------------------------------------------------------------------- conditioning-aware gradient checker
+GRAD_TOL = 1e-4        # north_star bar, applied per gradient COMPONENT and per GAUSSIAN (grad_errors), not per tensor
+NOISE_MULT = 4.0       # ... or within this factor of the reference algorithm's own fp32 rounding noise
+ROW_FLOOR = 0.1
+
+
+class OracleRun:
+    """The checker side of a backward parity test, on the OpenMP oracle (deterministic, double accumulation):
+    forward of the K subframes, the unstable-pixel masks, and the backward twice -- accumulating in double (the value
+    the HIP result is compared with) and in emulated fp32 (same order; |fp32 - double| is the rounding noise the
+    reference algorithm itself has on each gradient component, which is large exactly where the component is
+    ill-conditioned: scale / rotation / cov-chain part of dL_dmeans3D / view matrix)."""
+
+    def __init__(self, scene, K, **kw):
+        self.scene, self.K, self.kw = scene, K, kw
+        oracle.use_openmp(True)
+        try:
+            self.states = [oracle_forward(scene, k, **kw) for k in range(K)]
+            self.unstable = [oracle.unstable(st) for st in self.states]
+        finally:
+            oracle.use_openmp(False)
+        for st in self.states:
+            st.pop("keys_unsorted", None)
+            st.pop("vals_unsorted", None)
+
+    def subset(self, idx):
+        r = OracleRun.__new__(OracleRun)
+        r.scene, r.K, r.kw = self.scene, len(idx), self.kw
+        r.states, r.unstable = [self.states[i] for i in idx], [self.unstable[i] for i in idx]
+        return r
+
+    def mask(self, gC, gD=None):
+        """Zero the upstream gradients on the unstable pixels: a pair sitting on one of the reference's thresholds may
+        legitimately be blended by one implementation and skipped by the other; with no gradient flowing through those
+        pixels every remaining gradient term is held to the bar."""
+        gC = gC.copy()
+        gD = None if gD is None else gD.copy()
+        for k, un in enumerate(self.unstable):
+            gC[k][:, un] = 0.0
+            if gD is not None:
+                gD[k][:, un] = 0.0
+        return gC, gD
+
+    def backward(self, gC, gD=None):
+        out = {}
+        oracle.use_openmp(True)
+        try:
+            for mode in ("double", "f32"):
+                oracle.set_accum_f32(mode == "f32")
+                gs = [oracle.backward(st, gC[k], None if gD is None else gD[k]) for k, st in enumerate(self.states)]
+                r = {}
+                for name, key in (("dL_dmeans3D", "dL_dmeans3D"), ("dL_dopacities", "dL_dopacity"), ("dL_dsh", "dL_dsh"),
+                                  ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations"),
+                                  ("dL_dcolors_precomp", "dL_dcolors"), ("dL_dcov3D_precomp", "dL_dcov3D")):
+                    r[name] = sum(g[key].astype(np.float64) for g in gs)
+                for name in ("dL_dmeans2D", "dL_dviewmatrix", "dL_dprojmatrix"):
+                    r[name] = np.stack([g[name] for g in gs]).astype(np.float64)
+                out[mode] = r
+        finally:
+            oracle.set_accum_f32(False)
+            oracle.use_openmp(False)
+        return out
+
+
+def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, mult=NOISE_MULT, floor=ROW_FLOOR, report=None):
+    """hip[key] against ora["double"][key] with the bar max(tol, mult x noise), noise = the same error metric evaluated
+    on ora["f32"] (the oracle's own fp32-accumulation result).  Per-Gaussian tensors: per column AND per row
+    (grad_errors); pose matrices: per [4,4] matrix relative to its largest entry."""
+    for key in keys:
+        b, n = ora["double"][key], ora["f32"][key]
+        a = np.asarray(hip[key], np.float64).reshape(b.shape)
+        assert np.isfinite(a).all(), key
+        if key in ("dL_dviewmatrix", "dL_dprojmatrix"):
+            for k in range(b.shape[0]):
+                e, en = relerr(a[k], b[k]), relerr(n[k], b[k])
+                if report is not None:
+                    report.append((key, k, e, en))
+                assert e <= max(tol, mult * en), f"{key}[{k}]: {e:.2e} (noise {en:.2e})"
+            continue
+        rows = a.shape[0]
+        if key == "dL_dmeans2D":
+            rows = a.shape[0] * a.shape[1]
+            a, b, n = a[..., :2], b[..., :2], n[..., :2]
+        e, en = grad_errors(a, b, rows=rows, floor=floor), grad_errors(n, b, rows=rows, floor=floor)
+        if report is not None:
+            report.append((key, e, en))
+        for m in ("col", "row"):
+            assert e[m] <= max(tol, mult * en[m]), f"{key} {m}: {e[m]:.2e} (noise {en[m]:.2e})"
+
+
+# ------------------------------------------------------------------------- the product path exactly as bench.py runs it
+def cloud_grads_from_activated(scene, ora_res):
+    """Chain rule from the oracle's gradients (w.r.t. the activated values the reference rasteriser takes) to the raw
+    parameters of the cloud (scene/gaussian_activation.py:29-52, torch.nn.functional.normalize): log-scale, raw
+    quaternion, clamped opacity, dc | rest SH split.  float64."""
+    sc = scene["scales"].astype(np.float64)
+    q = scene["rotations"].astype(np.float64)
+    nq = np.linalg.norm(q, axis=1, keepdims=True)
+    qn = q / nq
+    op = scene["opacities"].astype(np.float64)
+    out = {}
+    for mode in ("double", "f32"):
+        r = ora_res[mode]
+        g_rot = r["dL_drotations"]
+        out[mode] = dict(
+            xyz=r["dL_dmeans3D"], f_dc=r["dL_dsh"][:, :1], f_rest=r["dL_dsh"][:, 1:],
+            opacity=r["dL_dopacities"] * ((op >= 0.0) & (op <= 1.0)),
+            scaling=r["dL_dscales"] * sc,
+            rotation=(g_rot - qn * (qn * g_rot).sum(axis=1, keepdims=True)) / nq,
+            dL_dmeans2D=r["dL_dmeans2D"], dL_dviewmatrix=r["dL_dviewmatrix"], dL_dprojmatrix=r["dL_dprojmatrix"])
+    return out
+
+
+def hip_cloud_forward_backward(scene, K, dL_dcolor, dL_ddepth=None, cull=True, keep_on_device=False):
+    """The path bench.py times: GaussianCloud (raw parameters) -> gaussian_renderer.render_subframes ->
+    rasterize_cloud_subframes (DgsProblem.raw_params = 1, activations inside the kernels) with tile culling as given,
+    loss = <colour, dL_dcolor> (+ <depth, dL_ddepth>), autograd backward."""
+    import torch
+    from deblurgs_amd import gaussian_renderer
+    from deblurgs_amd.cloud import GaussianCloud
+    from deblurgs_amd.motion import RefCamera
+    dev = "cuda"
+    cloud = GaussianCloud.from_scene(scene, dev)
+    assert cloud.fused_activations
+    ref = RefCamera(scene["W"], scene["H"], scene["FoVx"], scene["FoVy"], device=dev)
+    view = _t(scene["viewmatrix"][:K]).requires_grad_(True)
+    proj = _t(scene["projmatrix"][:K]).requires_grad_(True)
+    with tile_cull(cull):
+        pkg = gaussian_renderer.render_subframes(view, proj, _t(scene["campos"][:K]), ref, cloud, _t(scene["bg"]))
+        loss = (pkg["render"] * _t(dL_dcolor)).sum()
+        if dL_ddepth is not None:
+            loss = loss + (pkg["depth"] * _t(dL_ddepth)).sum()
+        loss.backward()
+    torch.cuda.synchronize()
+    get = (lambda t: t.detach()) if keep_on_device else (lambda t: t.detach().cpu().numpy())
+    out = dict(color=get(pkg["render"]), depth=get(pkg["depth"]), radii=get(pkg["radii"]),
+               dL_dmeans2D=get(pkg["viewspace_points"].grad), dL_dviewmatrix=get(view.grad), dL_dprojmatrix=get(proj.grad),
+               xyz=get(cloud._xyz.grad), f_dc=get(cloud._features_dc.grad), f_rest=get(cloud._features_rest.grad),
+               opacity=get(cloud._opacity.grad), scaling=get(cloud._scaling.grad), rotation=get(cloud._rotation.grad))
+    return out
+
+
+CLOUD_KEYS = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "dL_dmeans2D", "dL_dviewmatrix",
+              "dL_dprojmatrix"]
+
+
+def hip_state_on_device(scene, K, cull=True, raw=True):
+    """Forward through the C ABI; returns the outputs and the carved state arrays as torch views ON THE DEVICE (for
+    full-size property checks without multi-GB host copies).  raw=True: the cloud's raw parameters, as benchmarked."""
+    import torch
+    from deblurgs_amd import _lib
+    from deblurgs_amd import diff_gaussian_rasterization as dgr
+    from deblurgs_amd.cloud import GaussianCloud
+    rs = hip_settings(scene, K)._replace(campos=_t(scene["campos"][:K]))
+    view, proj, cam = _t(scene["viewmatrix"][:K]), _t(scene["projmatrix"][:K]), _t(scene["campos"][:K])
+    with tile_cull(cull), torch.no_grad():
+        if raw:
+            c = GaussianCloud.from_scene(scene, "cuda")
+            R, color, depth, radii, geom, binning, image = dgr._forward_impl(
+                K, c._xyz, c._features_dc, None, c._opacity.reshape(-1), c._scaling, c._rotation, None, view, proj, cam,
+                rs, raw={"scale_lb": 0.0, "sh_rest": c._features_rest if c._features_rest.shape[1] > 0 else None})
+        else:
+            R, color, depth, radii, geom, binning, image = dgr._forward_impl(
+                K, _t(scene["means3D"]), _t(scene["sh"]), None, _t(scene["opacities"]).reshape(-1), _t(scene["scales"]),
+                _t(scene["rotations"]), None, view, proj, cam, rs)
+    torch.cuda.synchronize()
+    P, W, H = scene["P"], scene["W"], scene["H"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    L = _lib.layout(P, W, H, K, R)
+    v = lambda blob, off, nbytes, dtype, shape: blob[off:off + nbytes].view(dtype).reshape(shape)
+    return dict(R=int(R), K=K, T=T, sort_bits=L.sort_bits, sort_passes=L.sort_passes, color=color, depth=depth,
+                radii=radii, _blobs=(geom, binning, image),
+                tiles_touched=v(geom, L.tiles_touched, K * P * 4, torch.int32, (K, P)),
+                tt_tight=v(geom, L.tt_tight, K * P * 4, torch.int32, (K * P,)),
+                rows=v(geom, L.geom_rows, K * P * 48, torch.float32, (K, P, 12)),
+                final_T=v(image, L.final_T, K * W * H * 4, torch.float32, (K, H * W)),
+                n_contrib=v(image, L.n_contrib, K * W * H * 4, torch.int32, (K, H * W)),
+                ranges=v(image, L.ranges, K * T * 8, torch.int32, (K * T, 2)),
+                keys=v(binning, L.keys_sorted, R * 8, torch.int64, (R,)),
+                point_list=v(binning, L.point_list, R * 4, torch.int32, (R,)))

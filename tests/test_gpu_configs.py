@@ -1,0 +1,209 @@
+"""BASELINE.json's configurations through the product path EXACTLY AS bench.py RUNS IT -- GaussianCloud raw parameters ->
+render_subframes -> rasterize_cloud_subframes (DgsProblem.raw_params = 1), tile culling on, all K subframes in one
+fused launch chain -- at full size:
+
+  metric  1M Gaussians, 1920x1080, K=15          (the headline number)
+  cfg3    1M Gaussians, 1600x1200, K=15
+  cfg5    5M Gaussians, 3840x2160, K=31          (stress: 17+ tile bits, hundreds of millions of duplicates)
+
+For each: size-independent properties of the fused binning at full size (sortedness, range/key consistency, a checksum
+of the duplicate lists, key width per rasterizer_impl.cu:306-314), tile_cull = 0 (the reference's lists) against
+tile_cull = 1 (the benchmarked lists) bit for bit, and forward + backward against the OpenMP oracle (deterministic,
+double accumulation) with the conditioning-aware bars of helpers.assert_grads_close.  The oracle is fed the activated
+values the kernels themselves use (dgs_cloud_activations), so radii / tile counts / point lists compare bit for bit."""
+import time
+
+import numpy as np
+import pytest
+
+from helpers import (CLOUD_KEYS, GRAD_TOL, OracleRun, assert_grads_close, cloud_grads_from_activated,
+                     hip_cloud_forward_backward, hip_state_on_device, synthetic)
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 1e-4
+KEY_BITS_K1 = {"cfg2": 44, "cfg3": 45, "metric": 45, "cfg5": 47}     # 32 + getHigherMsb(T)
+
+
+def kernel_activated_scene(sc):
+    """The scene with scales / rotations / opacities replaced by what the raw-parameter kernels compute from the
+    cloud's raw tensors (log-scale -> exp, normalise, clamp): the values the oracle must see for bit-exact integers."""
+    from deblurgs_amd.cloud import GaussianCloud
+    cloud = GaussianCloud.from_scene(sc, "cuda")
+    s, r, o = cloud.device_activations()
+    out = dict(sc)
+    out["scales"], out["rotations"], out["opacities"] = s.cpu().numpy(), r.cpu().numpy(), o.cpu().numpy()
+    return out
+
+
+def check_fused_binning_properties(st, cull, name):
+    """Full-size invariants of the fused K-subframe binning, evaluated on the device."""
+    import torch
+    K, T, R = st["K"], st["T"], st["R"]
+    keys, pl = st["keys"], st["point_list"].long()
+    assert R == keys.shape[0] and R > 0
+    tile = keys >> 32
+    assert bool((tile >= 0).all()) and int(tile.max()) < K * T
+    # stable sort on the tile bits of a list generated in (k, depth, index) order: the tile word is non-decreasing, and
+    # inside a tile the low word (depth bits with the reference's lists, emission index with tile culling) ascends too
+    assert bool((keys[1:] >= keys[:-1]).all()), "sorted keys"
+    counts = torch.bincount(tile, minlength=K * T)
+    rng = st["ranges"].long()
+    assert torch.equal(rng[:, 1] - rng[:, 0], counts), "tile ranges vs keys"
+    nonempty = counts > 0
+    starts = torch.cumsum(counts, 0) - counts
+    assert torch.equal(rng[nonempty, 0], starts[nonempty]), "range starts"
+    # every duplicate belongs to a visible (k, Gaussian) whose rectangle contains the tile
+    k_of = tile // T
+    rad = st["radii"].long()[k_of, pl]
+    assert bool((rad > 0).all())
+    rows = st["rows"][k_of, pl]
+    tl = tile - k_of * T
+    gx = (st["W"] + 15) // 16
+    tx, ty = (tl % gx).float(), (tl // gx).float()
+    x, y, r = rows[:, 0], rows[:, 1], rad.float()
+    inside = (tx * 16 <= x + r + 15) & (tx * 16 + 15 >= x - r - 15) & (ty * 16 <= y + r + 15) & (ty * 16 + 15 >= y - r - 15)
+    assert bool(inside.all()), "a duplicate outside its Gaussian's tile rectangle"
+    # checksums: per (k, Gaussian) duplicate counts against the counts the expansion was sized with
+    per_pair = torch.bincount(k_of * st["P"] + pl, minlength=K * st["P"])
+    if cull:
+        u = keys & 0xFFFFFFFF
+        assert int(u.max()) == R - 1 and int(torch.bincount(u, minlength=R).max()) == 1, "emission indices = permutation"
+        assert bool((per_pair <= st["tiles_touched"].long().reshape(-1)).all())
+    else:
+        assert torch.equal(per_pair, st["tiles_touched"].long().reshape(-1)), "duplicates per (k, Gaussian)"
+        assert R == int(st["tiles_touched"].long().sum())
+    from oracle import oracle
+    assert st["sort_bits"] == 32 + oracle.higher_msb(K * T), name
+
+
+def forward_against_oracle(st_color, st_depth, st_ncontrib, st_finalT, run, sc, ks):
+    worst_frac = 0.0
+    for k in ks:
+        o, un = run.states[k], run.unstable[k]
+        frac = float(un.mean())
+        worst_frac = max(worst_frac, frac)
+        assert frac < 0.01, f"unstable pixel fraction {frac}"          # exempted pixels are counted, not assumed rare
+        dc = np.abs(st_color[k] - o["color"]).max(axis=0)
+        dd = np.abs(st_depth[k][0] - o["depth"][0]) / sc["z_far"]
+        assert dc[~un].max() <= IMG_TOL, f"colour k={k}: {dc[~un].max()}"
+        assert dd[~un].max() <= IMG_TOL, f"depth k={k}: {dd[~un].max()}"
+        assert dc.max() <= 2e-2 and dd.max() <= 2e-2
+        s = ~un.reshape(-1)
+        assert np.array_equal(st_ncontrib[k][s], o["n_contrib"][s]), "n_contrib"
+        assert np.abs(st_finalT[k][s] - o["final_T"][s]).max() <= 1e-5
+    return worst_frac
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "metric", "cfg3"])
+def test_config_as_benchmarked(gpu, cfg):
+    import torch
+    t0 = time.time()
+    sc = synthetic.make_config(cfg)
+    K, P, W, H = sc["K"], sc["P"], sc["W"], sc["H"]
+    assert K == (9 if cfg == "cfg2" else 15)
+    act = kernel_activated_scene(sc)
+    assert np.abs(act["scales"] / sc["scales"] - 1).max() < 1e-6       # exp(log(s)): a few ulps at most
+
+    # ---- (1) binning properties at full size, both duplicate rules, and their images bit for bit
+    st1 = hip_state_on_device(sc, K, cull=True, raw=True)
+    st1.update(P=P, W=W, H=H)
+    check_fused_binning_properties(st1, True, cfg)
+    st0 = hip_state_on_device(sc, K, cull=False, raw=True)
+    st0.update(P=P, W=W, H=H)
+    check_fused_binning_properties(st0, False, cfg)
+    for key in ("color", "depth", "radii", "final_T", "n_contrib", "tiles_touched"):
+        assert torch.equal(st0[key], st1[key]), f"tile_cull 0 vs 1: {key}"
+    assert 0.3 < st1["R"] / st0["R"] < 0.9
+    # key width (rasterizer_impl.cu:306-314): one subframe needs 32 + getHigherMsb(T) bits, the fused launch K*T tiles
+    from deblurgs_amd import _lib
+    assert _lib.layout(P, W, H, 1, 0).sort_bits == KEY_BITS_K1[cfg]
+    # the reference's lists are subframe-major: the K=1 reference keys are the fused keys minus k*T in the tile word
+    R0 = st0["R"]
+
+    # ---- (2) forward of ALL K subframes against the oracle (kernel-activated parameters)
+    run = OracleRun(act, K)
+    radii = st1["radii"].cpu().numpy()
+    tt = st0["tiles_touched"].cpu().numpy().view(np.uint32)
+    off = 0
+    for k in range(K):
+        o = run.states[k]
+        assert np.array_equal(radii[k], o["radii"]), f"radii k={k}"
+        assert np.array_equal(tt[k], o["tiles_touched"]), f"tiles_touched k={k}"
+        Rk = o["num_rendered"]
+        assert torch.equal(st0["point_list"][off:off + Rk].cpu(), torch.from_numpy(o["point_list"].view(np.int32)))
+        keys_k = st0["keys"][off:off + Rk].cpu().numpy().view(np.uint64) - (np.uint64(k * st0["T"]) << np.uint64(32))
+        assert np.array_equal(keys_k, o["keys"]), f"sort keys k={k}"
+        off += Rk
+    assert off == R0
+    frac = forward_against_oracle(st1["color"].cpu().numpy(), st1["depth"].cpu().numpy(),
+                                  st1["n_contrib"].cpu().numpy().view(np.uint32), st1["final_T"].cpu().numpy(), run, sc,
+                                  range(K))
+    del st0, st1
+    torch.cuda.empty_cache()
+
+    # ---- (3) backward as benchmarked (raw parameters, tile culling, K fused) against the oracle
+    rng = np.random.default_rng(3)
+    gC = rng.normal(size=(K, 3, H, W)).astype(np.float32)
+    gC, _ = run.mask(gC)
+    hip = hip_cloud_forward_backward(sc, K, gC, cull=True)
+    ora = cloud_grads_from_activated(act, run.backward(gC))
+    report = []
+    assert_grads_close(hip, ora, CLOUD_KEYS, report=report)
+    # ---- (4) the reference's lists give the same gradients bit for bit at this size
+    hip0 = hip_cloud_forward_backward(sc, K, gC, cull=False)
+    for key in CLOUD_KEYS + ["color", "depth"]:
+        assert np.array_equal(hip0[key], hip[key]), f"tile_cull 0 vs 1: {key}"
+    print(f"\n[{cfg}] unstable fraction {frac:.2e}; errors (key, hip, oracle-fp32-noise):")
+    for r in report:
+        print("   ", r)
+    print(f"[{cfg}] {time.time() - t0:.0f} s")
+
+
+def test_cfg5_stress_as_benchmarked(gpu):
+    """5M Gaussians, 3840x2160, K=31, curve order 5: properties of the benchmarked variant at full size, then the first,
+    middle and last subframe forward and the middle subframe's backward against the oracle."""
+    import torch
+    t0 = time.time()
+    sc = synthetic.make_config("cfg5")
+    K, P, W, H = sc["K"], sc["P"], sc["W"], sc["H"]
+    assert (K, P, W, H) == (31, 5_000_000, 3840, 2160)
+    act = kernel_activated_scene(sc)
+    st = hip_state_on_device(sc, K, cull=True, raw=True)
+    st.update(P=P, W=W, H=H)
+    check_fused_binning_properties(st, True, "cfg5")
+    from deblurgs_amd import _lib
+    assert _lib.layout(P, W, H, 1, 0).sort_bits == KEY_BITS_K1["cfg5"]
+    assert st["sort_bits"] == 32 + 20 and st["sort_passes"] == 3        # K*T = 1 004 400 tiles -> 20 tile bits
+    ks = [0, K // 2, K - 1]
+    sub = dict(act)
+    for name in ("viewmatrix", "projmatrix", "campos"):
+        sub[name] = act[name][ks]
+    run = OracleRun(sub, len(ks))
+    radii = st["radii"][ks].cpu().numpy()
+    for i in range(len(ks)):
+        assert np.array_equal(radii[i], run.states[i]["radii"])
+    frac = forward_against_oracle(st["color"][ks].cpu().numpy(), st["depth"][ks].cpu().numpy(),
+                                  st["n_contrib"][ks].cpu().numpy().view(np.uint32), st["final_T"][ks].cpu().numpy(),
+                                  run, sc, range(len(ks)))
+    R = st["R"]
+    del st
+    torch.cuda.empty_cache()
+    # backward: upstream gradient on the middle subframe only, so the per-Gaussian sums are that subframe's
+    rng = np.random.default_rng(4)
+    g_mid = rng.normal(size=(1, 3, H, W)).astype(np.float32)
+    g_mid[0][:, run.unstable[1]] = 0.0
+    gC = np.zeros((K, 3, H, W), np.float32)
+    gC[K // 2] = g_mid[0]
+    hip = hip_cloud_forward_backward(sc, K, gC, cull=True)
+    ora = cloud_grads_from_activated(act, run.subset([1]).backward(g_mid))
+    for key in ("dL_dmeans2D", "dL_dviewmatrix", "dL_dprojmatrix"):
+        rest = np.delete(hip[key], K // 2, axis=0)
+        assert not rest.any(), f"{key}: subframes without upstream gradient must get exact zeros"
+        hip[key] = hip[key][K // 2:K // 2 + 1]
+    report = []
+    assert_grads_close(hip, ora, CLOUD_KEYS, report=report)
+    print(f"\n[cfg5] R = {R}, unstable fraction {frac:.2e}; errors:")
+    for r in report:
+        print("   ", r)
+    print(f"[cfg5] {time.time() - t0:.0f} s")

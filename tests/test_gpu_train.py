@@ -319,3 +319,44 @@ def test_fused_activations_equal_the_getter_path(gpu, deg, scale_lb):
     assert not b["g"][3][::7].any() and not b["g"][3][3::11].any()      # clamp: no gradient outside [0, 1]
     for key in ("view", "proj", "m2d"):
         assert np.abs(a[key] - b[key]).max() <= 2e-5 * np.abs(a[key]).max(), key
+
+
+# ------------------------------------------------------------------------------------ N-rank path on the one-GPU box
+def _run(cmd, env, timeout=900):
+    import subprocess
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, f"{cmd}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    return r.stdout
+
+
+@pytest.mark.parametrize("mode", ["views", "subframes"])
+def test_two_ranks_on_one_gpu(gpu, mode, tmp_path):
+    """The N-rank code path end to end with two ranks sharing this box's GPU (gloo collectives staged through the host:
+    a functional check, not a measurement; RCCL itself needs the driver's multi-GPU run):
+      * tools/dist_training_check.py: TrainingLoop(distributed=mode) through densification -- the cloud AND the trajectory
+        parameters stay bit-identical on both ranks (views: the ranks draw different cam_idx from one shared module);
+      * subframes: the two-rank result equals the single-process step up to summation order;
+      * bench.py --gpus 2 launches its two ranks itself and reports what the process group saw."""
+    import json
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DGS_DIST_BACKEND="gloo", DGS_DIST_ONE_DEVICE="1", PYTHONPATH=root)
+    tool = os.path.join(root, "tools", "dist_training_check.py")
+    out = _run([sys.executable, tool, "--ranks", "2", "--mode", mode], env)
+    assert "identical: True" in out and "densified: True" in out, out
+    if mode == "subframes":
+        a, b = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+        _run([sys.executable, tool, "--ranks", "1", "--mode", mode, "--no-densify", "--iters", "8", "--out", a], env)
+        _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--no-densify", "--iters", "8", "--out", b], env)
+        pa, pb = torch.load(a)["params"], torch.load(b)["params"]
+        for x, y in zip(pa, pb):
+            assert x.shape == y.shape
+            assert float((x - y).abs().max()) <= 2e-5 * (float(x.abs().max()) + 1e-12), float((x - y).abs().max())
+    out = _run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "cfg2", "--steps", "3",
+                "--warmup", "1", "--no-cpu-baseline", "--shard", mode], env)
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_in_process_group"] == 2
+    assert line["scaling"] == ("weak" if mode == "views" else "strong") and line["config"]["sharding"] == mode
+    assert line["config"]["allreduce_ms_per_step"] is not None and line["value"] > 0

@@ -33,6 +33,78 @@ def test_pose_path_matches_reference_se3_exp_map():
     assert np.abs(back.numpy() - g["exp64"]).max() <= 1e-9
 
 
+def test_se3_log_map_matches_reference():
+    """pose.se3_log_map against the reference's own se3_log_map outputs (utils/pytorch3d_functions.py:462-540, golden
+    `log_of_exp64`), including the exact-zero, near-zero (Taylor branch of phi / 2 sin phi) and large-angle rows."""
+    from deblurgs_amd import pose
+    g = load("pose_golden.npz")
+    T64 = torch.tensor(g["exp64"])
+    assert np.abs(pose.se3_log_map(T64).numpy() - g["log_of_exp64"]).max() <= 1e-12
+    lg32 = pose.se3_log_map(torch.tensor(g["exp32"])).numpy()
+    assert np.abs(lg32 - g["log_of_exp64"]).max() <= 2e-3           # acos near 1 in float32, as in the reference
+    big = np.linalg.norm(g["se3"][:, 3:], axis=1) > 0.05
+    assert np.abs(lg32[big] - g["log_of_exp64"][big]).max() <= 2e-5
+    with pytest.raises(ValueError):
+        bad = T64.clone()
+        bad[0, 0, 3] = 0.5
+        pose.se3_log_map(bad)
+
+
+def test_motion_module_initialises_from_camera_poses_with_the_real_log():
+    """scene/motion.py:196-205: the curve's control points start at se3_log_map of the dataset pose (far from the
+    identity here), so that every subframe camera of the fresh module reproduces that pose."""
+    from deblurgs_amd import pose
+    from deblurgs_amd.motion import CameraMotionModule, RefCamera
+    g = load("pose_golden.npz")
+    torch.manual_seed(0)
+    c2w = torch.tensor(g["exp64"]).float()                       # row-vector [[R,0],[T,1]]
+    rot, trans = c2w[:, :3, :3].transpose(-2, -1), c2w[:, 3, :3]   # what the reference reads from CameraInfo
+    ref = RefCamera(64, 48, 1.0, 0.8, device="cpu")
+    m = CameraMotionModule(ref, torch.zeros(c2w.shape[0], 3, 4, 4), curve_order=3, num_subframes=5, device="cpu",
+                           init_c2w=(rot, trans))
+    want = torch.tensor(g["log_of_exp64"]).float()
+    assert (m._rot._control_points - want[:, None, 3:]).abs().max() <= 6e-3       # + N(0, 0.001) initial noise
+    assert (m._trans._control_points - want[:, None, :3]).abs().max() <= 6e-3
+    for i in (2, 5, 11):
+        wv, _, cc = m.get_trajectory_matrices(i, fused=False)
+        assert (wv[:, :3, :3] - rot[i]).abs().max() <= 1e-2 and (cc - trans[i]).abs().max() <= 1e-2
+
+
+def test_quaternion_curve_type_against_scipy():
+    """curve_type="quarternion_cartesian" (scene/motion.py:191-194,242-246) without `roma`: the two conversions are the
+    published SciPy algorithm roma adapts (XYZW, no sign canonicalisation), pinned here against scipy itself."""
+    from scipy.spatial.transform import Rotation
+    from deblurgs_amd import pose
+    from deblurgs_amd.motion import CameraMotionModule, RefCamera
+    Rm = Rotation.random(300, random_state=1).as_matrix()
+    Rm[0] = np.eye(3)
+    Rm[1] = Rotation.from_rotvec([np.pi - 1e-6, 0, 0]).as_matrix()          # trace ~ -1: pivot on a diagonal entry
+    Rm[2] = Rotation.from_rotvec([0, np.pi * 0.9999, 0]).as_matrix()
+    Rm[3] = Rotation.from_rotvec([0.3, 0.2, np.pi * 0.99]).as_matrix()
+    q = pose.rotmat_to_unitquat(torch.tensor(Rm))
+    assert np.abs(q.numpy() - Rotation.from_matrix(Rm).as_quat()).max() <= 1e-14
+    assert np.abs(pose.unitquat_to_rotmat(q).numpy() - Rm).max() <= 1e-14
+    assert np.abs(pose.unitquat_to_rotmat(q.float()).numpy() - Rotation.from_quat(q.numpy()).as_matrix()).max() <= 1e-6
+    # the module: control points = the pose's quaternion (+ noise), positions in Cartesian space
+    torch.manual_seed(1)
+    rot, trans = torch.tensor(Rm[:6]).float(), torch.randn(6, 3)
+    ref = RefCamera(64, 48, 1.0, 0.8, device="cpu")
+    m = CameraMotionModule(ref, torch.zeros(6, 3, 4, 4), curve_order=4, num_subframes=7, device="cpu",
+                           curve_type="quarternion_cartesian", init_c2w=(rot, trans))
+    assert m._rot._control_points.shape == (6, 5, 4) and m._trans._control_points.shape == (6, 5, 3)
+    with torch.no_grad():                                   # no noise: every sample must be the initial pose exactly
+        m._rot._control_points.copy_(pose.rotmat_to_unitquat(rot)[:, None, :].expand(-1, 5, -1))
+        m._trans._control_points.copy_(trans[:, None, :].expand(-1, 5, -1))
+    r, t = m._sample_c2w_from_nu(3)
+    assert (r - rot[3]).abs().max() <= 1e-6 and (t - trans[3]).abs().max() <= 1e-6
+    wv, fp, cc = m.get_trajectory_matrices(3)
+    assert (wv[:, :3, :3] - rot[3]).abs().max() <= 1e-6 and (cc - trans[3]).abs().max() <= 1e-5
+    (wv.sum() + fp.sum()).backward()
+    assert m._rot._control_points.grad.abs().sum() > 0 and m._nu.grad.abs().sum() > 0
+    with pytest.raises(NotImplementedError):
+        CameraMotionModule(ref, torch.zeros(1, 3, 4, 4), device="cpu", curve_type="spline")
+
+
 def test_sh_colour_matches_reference_eval_sh():
     g = load("sh_golden.npz")
     dirs, sh = torch.tensor(g["dirs"]), torch.tensor(g["sh"])

@@ -1,59 +1,122 @@
-"""Functional check of the data-parallel training loop on a ONE-GPU box: every rank trains on its own blurry view
-(TrainingLoop(distributed=True)), with densification, and the replicas must stay bit-identical.
-    DGS_DIST_BACKEND=gloo DGS_DIST_ONE_DEVICE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \\
-        --master-addr 127.0.0.1 --master-port 29541 tools/dist_training_check.py
-"""
-import os, sys
-import torch
-import torch.distributed as dist
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-from deblurgs_amd import sharding, synthetic
-from deblurgs_amd.cloud import GaussianCloud
-from deblurgs_amd.motion import CameraMotionModule, RefCamera
-from deblurgs_amd.training import TrainingLoop, default_optimization_params
+"""Functional check of the sharded training loop (TrainingLoop(distributed="views" | "subframes")) with N ranks.  Works
+on a ONE-GPU box too (all ranks on cuda:0, gloo collectives staged through the host):
 
-rank, world, local = sharding.init_distributed("cuda")
-dev = torch.device("cuda", 0)
-sc = synthetic.make_scene(3000, 128, 96, K=5, seed=21, sigma_px=3.0)
-cloud = GaussianCloud.from_scene(sc, dev)
-ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device=dev)
-torch.manual_seed(100 + rank)
-gt = torch.rand(1, 3, sc["H"], sc["W"], device=dev) * 0.5
-m = CameraMotionModule(ref, gt, curve_order=3, num_subframes=5, device=dev)
-with torch.no_grad():
-    m._trans._control_points.copy_(torch.from_numpy(sc["ctrl_trans"])[None].to(dev) + 0.01 * rank)
-    m._rot._control_points.copy_(torch.from_numpy(sc["ctrl_rot"])[None].to(dev))
-opt = default_optimization_params(iterations=40, curve_start_iter=2, densify_from_iter=5, densification_interval=6,
-                                  densify_until_iter=30, densify_grad_threshold_init=2e-5, densify_grad_threshold_final=1e-5,
-                                  opacity_reset_interval=1000)
-loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=world > 1)
-sizes = []
-for it in range(1, 31):
-    torch.manual_seed(it)              # same random background on every rank
-    out = loop.step(it, 0)
-    sizes.append(out["num_points"])
-inplace = []
-_orig = sharding.flat_allreduce_grads
-def _spy(params, **kw):
-    r = _orig(params, **kw)
-    inplace.append(sharding._shared_flat([p.grad for p in params]) is not None)
-    return r
-sharding.flat_allreduce_grads = _spy
-for it in range(31, 34):
-    torch.manual_seed(it)
-    loop.step(it, 0)
-P = cloud._xyz.shape[0]
-sig = torch.stack([p.detach().double().sum() for p in cloud.hot_parameters()] + [torch.tensor(float(P), device=dev, dtype=torch.float64)])
-if world > 1:
-    allsig = [torch.zeros_like(sig) for _ in range(world)]
-    dist.all_gather(allsig, sig)
-    same = all(torch.equal(allsig[0], s) for s in allsig)
-else:
+    DGS_DIST_BACKEND=gloo DGS_DIST_ONE_DEVICE=1 python tools/dist_training_check.py --ranks 2 --mode views
+    DGS_DIST_BACKEND=gloo DGS_DIST_ONE_DEVICE=1 python tools/dist_training_check.py --ranks 2 --mode subframes
+
+Started plainly it launches the ranks itself (fresh child processes, before any GPU call).  Checks:
+  views      ranks draw DIFFERENT cam_idx from one shared CameraMotionModule, with densification; afterwards the cloud
+             AND the trajectory parameters (_rot / _trans control points, _nu) are bit-identical on every rank, and the
+             per-Gaussian gradient bucket was reduced in place.
+  subframes  every rank takes the same cam_idx and renders its share of the K subframes; replicas bit-identical, and
+             with --out the final parameters are saved so that the caller can compare them with a --ranks 1 run (the
+             sharded step is the single-process step up to summation order).
+"""
+import argparse
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ranks", type=int, default=2)
+    ap.add_argument("--mode", default="views", choices=["views", "subframes"])
+    ap.add_argument("--iters", type=int, default=33)
+    ap.add_argument("--no-densify", action="store_true")
+    ap.add_argument("--out", default=None)
+    return ap.parse_args()
+
+
+def launch(args):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    return 0 if all(rc == 0 for rc in rcs) else 1
+
+
+def main():
+    args = parse()
+    if args.ranks > 1 and "RANK" not in os.environ:
+        sys.exit(launch(args))
+    import torch
+    import torch.distributed as dist
+    from deblurgs_amd import sharding, synthetic
+    from deblurgs_amd.cloud import GaussianCloud
+    from deblurgs_amd.motion import CameraMotionModule, RefCamera
+    from deblurgs_amd.training import TrainingLoop, default_optimization_params
+
+    rank, world, local = sharding.init_distributed("cuda")
+    dev = torch.device("cuda", 0 if os.environ.get("DGS_DIST_ONE_DEVICE", "0") == "1" else local)
+    torch.cuda.set_device(dev)
+    K = 5
+    sc = synthetic.make_scene(3000, 128, 96, K=K, seed=21, sigma_px=3.0)
+    cloud = GaussianCloud.from_scene(sc, dev)
+    ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device=dev)
+    n_views = max(world, 2)
+    torch.manual_seed(100)                        # the SAME module (ground truths, curves) on every rank
+    gt = torch.rand(n_views, 3, sc["H"], sc["W"], device=dev) * 0.5
+    m = CameraMotionModule(ref, gt, curve_order=3, num_subframes=K, device=dev)
+    with torch.no_grad():
+        base = torch.from_numpy(sc["ctrl_trans"])[None].to(dev)
+        m._trans._control_points.copy_(base + 0.01 * torch.arange(n_views, device=dev).reshape(-1, 1, 1))
+        m._rot._control_points.copy_(torch.from_numpy(sc["ctrl_rot"])[None].to(dev).expand(n_views, -1, -1))
+    far = 10 ** 9
+    opt = default_optimization_params(
+        iterations=args.iters + 10, curve_start_iter=2, densify_from_iter=far if args.no_densify else 5,
+        densification_interval=6, densify_until_iter=args.iters - 3, densify_grad_threshold_init=2e-5,
+        densify_grad_threshold_final=1e-5, opacity_reset_interval=1000, curve_alignment_lr=1e-3, curve_alignment_start=4)
+    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=args.mode if world > 1 else False)
+    inplace = []
+    _orig = sharding.flat_allreduce_grads
+
+    def _spy(params, **kw):
+        r = _orig(params, **kw)
+        inplace.append(sharding._shared_flat([p.grad for p in params]) is not None)
+        return r
+    sharding.flat_allreduce_grads = _spy
+    sizes = []
+    for it in range(1, args.iters + 1):
+        torch.manual_seed(it)                     # same random background on every rank
+        cam = (it + rank) % n_views if args.mode == "views" else it % n_views
+        out = loop.step(it, cam)
+        sizes.append(out["num_points"])
+    tensors = list(cloud.hot_parameters()) + list(m.parameters())
+    sig = torch.stack([p.detach().double().sum() for p in tensors] +
+                      [p.detach().double().abs().sum() for p in tensors] +
+                      [torch.tensor(float(cloud._xyz.shape[0]), device=dev, dtype=torch.float64)])
     same = True
-if rank == 0:
-    print("ranks", world, "points", sizes[0], "->", sizes[-1], "densified:", len(set(sizes)) > 1, "replicas identical:", same,
-          "gradient bucket reduced in place:", inplace)
-    assert same and len(set(sizes)) > 1 and (world == 1 or all(inplace))
-if world > 1:
-    dist.barrier()
-    dist.destroy_process_group()
+    if world > 1:
+        allsig = [torch.zeros_like(sig) for _ in range(world)]
+        dist.all_gather(allsig, sig)
+        same = all(torch.equal(allsig[0], s) for s in allsig)
+    moved = [float((p.detach() - q).abs().max()) for p, q in
+             zip(m.parameters(), [torch.zeros_like(p) for p in m.parameters()])]
+    if rank == 0:
+        print(f"mode {args.mode} ranks {world} points {sizes[0]} -> {sizes[-1]} densified: {len(set(sizes)) > 1} "
+              f"replicas (cloud + trajectory) identical: {same} bucket reduced in place: "
+              f"{all(inplace) if inplace else None} curve state steps: "
+              f"{float(cloud.optimizer.state[m._trans._control_points]['step'])}", flush=True)
+        assert same, "replicas diverged"
+        assert args.no_densify or len(set(sizes)) > 1, "densify_and_prune never changed the cloud"
+        assert world == 1 or not inplace or all(inplace[1:]), "the gradient bucket must be reduced in place"
+        assert cloud.optimizer.state[m._nu]["step"] > 0 and moved[0] > 0
+        if args.out:
+            torch.save({"params": [p.detach().cpu() for p in tensors], "sizes": sizes}, args.out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
