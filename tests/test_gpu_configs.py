@@ -103,7 +103,7 @@ def test_config_as_benchmarked(gpu, cfg):
     K, P, W, H = sc["K"], sc["P"], sc["W"], sc["H"]
     assert K == (9 if cfg == "cfg2" else 15)
     act = kernel_activated_scene(sc)
-    assert np.abs(act["scales"] / sc["scales"] - 1).max() < 1e-6       # exp(log(s)): a few ulps at most
+    assert np.abs(act["scales"] / sc["scales"] - 1).max() < 5e-6       # exp(log(s)): a few ulps of log(s)
 
     # ---- (1) binning properties at full size, both duplicate rules, and their images bit for bit
     st1 = hip_state_on_device(sc, K, cull=True, raw=True)

@@ -350,10 +350,16 @@ def test_two_ranks_on_one_gpu(gpu, mode, tmp_path):
         a, b = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
         _run([sys.executable, tool, "--ranks", "1", "--mode", mode, "--no-densify", "--iters", "8", "--out", a], env)
         _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--no-densify", "--iters", "8", "--out", b], env)
-        pa, pb = torch.load(a)["params"], torch.load(b)["params"]
-        for x, y in zip(pa, pb):
-            assert x.shape == y.shape
-            assert float((x - y).abs().max()) <= 2e-5 * (float(x.abs().max()) + 1e-12), float((x - y).abs().max())
+        da, db = torch.load(a), torch.load(b)
+        # the sharded step IS the single-process step: same gradients up to the order of the cross-rank sums ...
+        for x, y in zip(da["grads_it3"], db["grads_it3"]):
+            assert (x is None) == (y is None)
+            if x is not None and x.numel():
+                assert float((x - y).abs().max()) <= 1e-5 * (float(x.abs().max()) + 1e-30), float((x - y).abs().max())
+        # ... and the trained parameters stay together (Adam's g / sqrt(v) turns rounding-level differences of
+        # near-zero gradients into differences of a fraction of one learning-rate step; 8 steps were taken)
+        for x, y in zip(da["params"], db["params"]):
+            assert x.shape == y.shape and float((x - y).abs().max()) <= 2e-3 * (float(x.abs().max()) + 1e-12)
     out = _run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "cfg2", "--steps", "3",
                 "--warmup", "1", "--no-cpu-baseline", "--shard", mode], env)
     line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])

@@ -86,7 +86,17 @@ def main():
         return r
     sharding.flat_allreduce_grads = _spy
     sizes = []
+    snap = {}
+    _step = cloud.optimizer.step
+
+    def _step_spy(*a, **kw):          # the gradients the optimiser sees at iteration 3 (first steps with all K subframes)
+        if snap.get("it") == 3:
+            snap["grads"] = [None if p.grad is None else p.grad.detach().cpu().clone()
+                             for p in list(cloud.hot_parameters()) + list(m.parameters())]
+        return _step(*a, **kw)
+    cloud.optimizer.step = _step_spy
     for it in range(1, args.iters + 1):
+        snap["it"] = it
         torch.manual_seed(it)                     # same random background on every rank
         cam = (it + rank) % n_views if args.mode == "views" else it % n_views
         out = loop.step(it, cam)
@@ -112,7 +122,8 @@ def main():
         assert world == 1 or not inplace or all(inplace[1:]), "the gradient bucket must be reduced in place"
         assert cloud.optimizer.state[m._nu]["step"] > 0 and moved[0] > 0
         if args.out:
-            torch.save({"params": [p.detach().cpu() for p in tensors], "sizes": sizes}, args.out)
+            torch.save({"params": [p.detach().cpu() for p in tensors], "sizes": sizes, "grads_it3": snap.get("grads")},
+                       args.out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
