@@ -90,7 +90,8 @@ def forward_against_oracle(st_color, st_depth, st_ncontrib, st_finalT, run, sc, 
         assert dd[~un].max() <= IMG_TOL, f"depth k={k}: {dd[~un].max()}"
         assert dc.max() <= 2e-2 and dd.max() <= 2e-2
         s = ~un.reshape(-1)
-        assert np.array_equal(st_ncontrib[k][s], o["n_contrib"][s]), "n_contrib"
+        if st_ncontrib is not None:      # positions in the reference's (tile_cull = 0) lists
+            assert np.array_equal(st_ncontrib[k][s], o["n_contrib"][s]), "n_contrib"
         assert np.abs(st_finalT[k][s] - o["final_T"][s]).max() <= 1e-5
     return worst_frac
 
@@ -112,8 +113,10 @@ def test_config_as_benchmarked(gpu, cfg):
     st0 = hip_state_on_device(sc, K, cull=False, raw=True)
     st0.update(P=P, W=W, H=H)
     check_fused_binning_properties(st0, False, cfg)
-    for key in ("color", "depth", "radii", "final_T", "n_contrib", "tiles_touched"):
+    for key in ("color", "depth", "radii", "final_T", "tiles_touched"):
         assert torch.equal(st0[key], st1[key]), f"tile_cull 0 vs 1: {key}"
+    # (n_contrib is a position in the tile's list: with culling it counts the surviving entries only)
+    assert bool((st1["n_contrib"] <= st0["n_contrib"]).all())
     assert 0.3 < st1["R"] / st0["R"] < 0.9
     # key width (rasterizer_impl.cu:306-314): one subframe needs 32 + getHigherMsb(T) bits, the fused launch K*T tiles
     from deblurgs_amd import _lib
@@ -137,7 +140,7 @@ def test_config_as_benchmarked(gpu, cfg):
         off += Rk
     assert off == R0
     frac = forward_against_oracle(st1["color"].cpu().numpy(), st1["depth"].cpu().numpy(),
-                                  st1["n_contrib"].cpu().numpy().view(np.uint32), st1["final_T"].cpu().numpy(), run, sc,
+                                  st0["n_contrib"].cpu().numpy().view(np.uint32), st1["final_T"].cpu().numpy(), run, sc,
                                   range(K))
     del st0, st1
     torch.cuda.empty_cache()
@@ -183,9 +186,8 @@ def test_cfg5_stress_as_benchmarked(gpu):
     radii = st["radii"][ks].cpu().numpy()
     for i in range(len(ks)):
         assert np.array_equal(radii[i], run.states[i]["radii"])
-    frac = forward_against_oracle(st["color"][ks].cpu().numpy(), st["depth"][ks].cpu().numpy(),
-                                  st["n_contrib"][ks].cpu().numpy().view(np.uint32), st["final_T"][ks].cpu().numpy(),
-                                  run, sc, range(len(ks)))
+    frac = forward_against_oracle(st["color"][ks].cpu().numpy(), st["depth"][ks].cpu().numpy(), None,
+                                  st["final_T"][ks].cpu().numpy(), run, sc, range(len(ks)))
     R = st["R"]
     del st
     torch.cuda.empty_cache()

@@ -29,6 +29,7 @@ def parse():
     ap.add_argument("--iters", type=int, default=33)
     ap.add_argument("--no-densify", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--curve-start", type=int, default=2, help="curve_start_iter (all K subframes from this iteration)")
     return ap.parse_args()
 
 
@@ -73,7 +74,7 @@ def main():
         m._rot._control_points.copy_(torch.from_numpy(sc["ctrl_rot"])[None].to(dev).expand(n_views, -1, -1))
     far = 10 ** 9
     opt = default_optimization_params(
-        iterations=args.iters + 10, curve_start_iter=2, densify_from_iter=far if args.no_densify else 5,
+        iterations=args.iters + 10, curve_start_iter=args.curve_start, densify_from_iter=far if args.no_densify else 5,
         densification_interval=6, densify_until_iter=args.iters - 3, densify_grad_threshold_init=2e-5,
         densify_grad_threshold_final=1e-5, opacity_reset_interval=1000, curve_alignment_lr=1e-3, curve_alignment_start=4)
     loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=args.mode if world > 1 else False)
@@ -89,8 +90,8 @@ def main():
     snap = {}
     _step = cloud.optimizer.step
 
-    def _step_spy(*a, **kw):          # the gradients the optimiser sees at iteration 3 (first steps with all K subframes)
-        if snap.get("it") == 3:
+    def _step_spy(*a, **kw):          # the gradients the optimiser sees at the first iteration with all K subframes
+        if snap.get("it") == args.curve_start:
             snap["grads"] = [None if p.grad is None else p.grad.detach().cpu().clone()
                              for p in list(cloud.hot_parameters()) + list(m.parameters())]
         return _step(*a, **kw)
@@ -122,7 +123,7 @@ def main():
         assert world == 1 or not inplace or all(inplace[1:]), "the gradient bucket must be reduced in place"
         assert cloud.optimizer.state[m._nu]["step"] > 0 and moved[0] > 0
         if args.out:
-            torch.save({"params": [p.detach().cpu() for p in tensors], "sizes": sizes, "grads_it3": snap.get("grads")},
+            torch.save({"params": [p.detach().cpu() for p in tensors], "sizes": sizes, "grads_first": snap.get("grads")},
                        args.out)
     if world > 1:
         dist.barrier()
