@@ -41,15 +41,15 @@ void make_layout(int P, int W, int H, int K, uint64_t R, DgsLayout* L) {
   L->point_offsets = o;  o += up(KP * 4);
   L->scan_tmp = o;       o += up(dgs_scan_tmp_words(KP) * 4);
   L->num_rendered = o;   o += up(16);
-  L->gsort_keys = o;     o += up(KP * 8);
-  L->gsort_keys_alt = o; o += up(KP * 8);
+  L->gsort_keys = o;     o += up(KP * 4);
+  L->gsort_keys_alt = o; o += up(KP * 4);
   L->gsort_vals = o;     o += up(KP * 4);
   L->gsort_vals_alt = o; o += up(KP * 4);
   L->tt_sorted = o;      o += up(KP * 4);
   L->offs_sorted = o;    o += up(KP * 4);
   L->tt_tight = o;       o += up(KP * 4);
   L->offs_tight = o;     o += up(KP * 4);
-  L->gsort_tmp = o;      o += up(dgs_sort_tmp_words(KP) * 4);
+  L->gsort_tmp = o;      o += up(dgs_depth_sort_tmp_words(K, (uint32_t)P) * 4);
   L->geom_total = o;
   o = 0;
   L->final_T = o;        o += up((size_t)K * N * 4);
@@ -124,8 +124,8 @@ void carve(const DgsProblem* p, const DgsLayout& L, DgsCarve* c) {
   c->point_offsets = reinterpret_cast<uint32_t*>(g + L.point_offsets);
   c->scan_tmp = reinterpret_cast<uint32_t*>(g + L.scan_tmp);
   c->num_rendered = reinterpret_cast<uint32_t*>(g + L.num_rendered);
-  c->gsort_keys = reinterpret_cast<uint64_t*>(g + L.gsort_keys);
-  c->gsort_keys_alt = reinterpret_cast<uint64_t*>(g + L.gsort_keys_alt);
+  c->gsort_keys = reinterpret_cast<uint32_t*>(g + L.gsort_keys);
+  c->gsort_keys_alt = reinterpret_cast<uint32_t*>(g + L.gsort_keys_alt);
   c->gsort_vals = reinterpret_cast<uint32_t*>(g + L.gsort_vals);
   c->gsort_vals_alt = reinterpret_cast<uint32_t*>(g + L.gsort_vals_alt);
   c->tt_sorted = reinterpret_cast<uint32_t*>(g + L.tt_sorted);
@@ -380,13 +380,11 @@ int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, DgsLayout
   return DGS_OK;
 }
 
-static int depth_order_bits(const DgsProblem* p) {
-  return 32 + (p->K > 1 ? (int)dgs_higher_msb((uint32_t)p->K) : 0);
-}
-// order the (k, Gaussian) pairs by (k, depth bits, index): stable sort of the keys preprocess wrote
-static hipError_t launch_depth_order(const DgsProblem* p, const DgsCarve& c, int* in_alt, hipStream_t s) {
-  return dgs_launch_sort(c.gsort_keys, c.gsort_vals, c.gsort_keys_alt, c.gsort_vals_alt, (uint64_t)p->K * p->P, 0,
-                         depth_order_bits(p), c.gsort_tmp, in_alt, s);
+// order the (k, Gaussian) pairs by (k, depth bits, index): segmented stable sort of the depth keys preprocess wrote;
+// the result (flat indices) lands in c.gsort_vals
+static hipError_t launch_depth_order(const DgsProblem* p, const DgsCarve& c, hipStream_t s) {
+  return dgs_launch_depth_sort(c.gsort_keys, c.gsort_keys_alt, c.gsort_vals, c.gsort_vals_alt, p->K, (uint32_t)p->P,
+                               c.gsort_tmp, s);
 }
 
 int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stream_t stream) {
@@ -417,9 +415,8 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
   } else {
     // tile_cull: R is the number of surviving duplicates, known only after the depth ordering and the per-slot
     // test; the overflow word still comes from the rectangle total, whose u32 offsets drive the expansion
-    int g_in_alt = 0;
-    DGS_STAGE(DGS_STAGE_DEPTH_ORDER, "depth order", launch_depth_order(p, c, &g_in_alt, s));
-    const uint32_t* order = g_in_alt ? c.gsort_vals_alt : c.gsort_vals;
+    DGS_STAGE(DGS_STAGE_DEPTH_ORDER, "depth order", launch_depth_order(p, c, s));
+    const uint32_t* order = c.gsort_vals;
     DGS_STAGE(DGS_STAGE_TILE_CULL, "tile cull count",
               dgs_launch_tight_count(v, c, order, c.num_rendered, c.num_rendered + 2, s));
     e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
@@ -461,15 +458,14 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t R
     }
     if (!v.tile_cull) {
       // (1) order the (k, Gaussian) pairs by (k, depth bits, index)
-      int g_in_alt = 0;
-      DGS_STAGE(DGS_STAGE_DEPTH_ORDER, "depth order", launch_depth_order(p, c, &g_in_alt, s));
-      const uint32_t* order = g_in_alt ? c.gsort_vals_alt : c.gsort_vals;
+      DGS_STAGE(DGS_STAGE_DEPTH_ORDER, "depth order", launch_depth_order(p, c, s));
+      const uint32_t* order = c.gsort_vals;
       // (2) duplicate in that order, (3) stable sort on the tile bits only
       DGS_STAGE(DGS_STAGE_DUPLICATE, "duplicateWithKeys",
                 dgs_launch_duplicate_sorted(v, cd, order, c.tt_sorted, c.offs_sorted, c.scan_tmp, s));
     } else {
       // the ordering and the surviving-tile offsets were produced by dgs_forward_geometry
-      const uint32_t* order = (dgs_sort_num_passes(0, depth_order_bits(p)) & 1) ? c.gsort_vals_alt : c.gsort_vals;
+      const uint32_t* order = c.gsort_vals;
       DGS_STAGE(DGS_STAGE_DUPLICATE, "duplicateWithKeys", dgs_launch_duplicate_tight(v, cd, order, s));
     }
     int in_alt = 0;

@@ -160,7 +160,6 @@ duplicate_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __restric
   const float x = row->x, y = row->y;
   const int radius = row->radius;
   uint32_t off = offsets[i];
-  row->dup_offset = off;
   int minx, miny, maxx, maxy;
   dgs_get_rect(x, y, radius, v.gx, v.gy, minx, miny, maxx, maxy);
   const uint32_t dbits = __float_as_uint(row->depth);
@@ -220,8 +219,8 @@ duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __
     if (nt != 0) {
       const uint32_t k = i / (uint32_t)v.P;
       g = i - k * (uint32_t)v.P;
-      DgsRow* row = rows + i;
-      row->dup_offset = off;
+      const DgsRow* row = rows + i;
+      point_offsets[i] = off;   // first duplicate of this (k, Gaussian): read by the backward (natural index)
       int minx, miny, maxx, maxy;
       dgs_get_rect(row->x, row->y, row->radius, v.gx, v.gy, minx, miny, maxx, maxy);
       wide = (uint32_t)(maxx - minx);
@@ -276,10 +275,11 @@ duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __
 // bits, which the tile-bits-only stable sort never looks at.
 template <bool EMIT>
 __global__ void __launch_bounds__(256)
-tight_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __restrict__ order,
+tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restrict__ order,
              const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ offs_sorted,
              uint32_t* __restrict__ tt_tight, const uint32_t* __restrict__ offs_tight,
-             const uint32_t* __restrict__ total_full, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+             const uint32_t* __restrict__ total_full, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+             uint32_t* __restrict__ dup_off) {
   // the rectangle total overflowed 32 bits: the offsets are meaningless (the host raises on the overflow word)
   if (total_full[1] != 0u) {
     const uint64_t jj = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -309,7 +309,7 @@ tight_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __restrict__ 
     if (nt != 0) {
       const uint32_t k = i / (uint32_t)v.P;
       g = i - k * (uint32_t)v.P;
-      DgsRow* row = rows + i;
+      const DgsRow* row = rows + i;
       const float4 A = reinterpret_cast<const float4*>(row)[0];  // x, y, cx, cy
       const float4 B = reinterpret_cast<const float4*>(row)[1];  // cz, op, ...
       int minx, miny, maxx, maxy;
@@ -323,7 +323,10 @@ tight_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __restrict__ 
       fl = (cg.always ? 1u : 0u) | (cg.never ? 2u : 0u);
       if (EMIT) {
         otight = offs_tight[j];
-        row->dup_offset = tt_tight[j] != 0 ? otight : 0xFFFFFFFFu;  // no surviving tile: geometry_bwd reads zeros
+        // first contribution row of this (k, Gaussian), by natural index: a 4-byte store into a K*P-word array that stays
+        // cache-resident (stamping it into the 48-byte geometry row cost a read-modify-write of a line per pair);
+        // no surviving tile: geometry_bwd reads zeros
+        dup_off[i] = tt_tight[j] != 0 ? otight : 0xFFFFFFFFu;
       }
     } else if (EMIT) {
       otight = offs_tight[j];
@@ -799,6 +802,162 @@ onesweep_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __
   }
 }
 
+// ---------------------------------------------------------------------- depth order: segmented 32-bit sort
+// The (k, depth, index) ordering of the K*P (subframe, Gaussian) pairs is K independent sorts of P 32-bit depth keys
+// (positive floats order like their bit patterns; invisible pairs carry 0xFFFFFFFF and sort last): a segmented stable
+// LSD radix sort, four 8-bit passes, one launch chain for all K segments.  Against sorting (k << 32 | depth, index)
+// pairs with the generic 64-bit sort this moves 20 bytes per pair and pass instead of 32 (4-byte keys, the first pass
+// generates the indices instead of reading them, the last pass does not write keys).  A block owns DS_TILE consecutive
+// pairs of ONE segment; the stable order inside a block is (wave, round, lane) as in the generic sort.
+constexpr int DS_THREADS = 256;
+constexpr int DS_ITEMS = 16;
+constexpr int DS_TILE = DS_THREADS * DS_ITEMS;  // 4096 pairs per block
+constexpr int DS_BINS = 256;
+constexpr int DS_CHUNK = 32;  // blocks per column-scan chunk
+
+__global__ void __launch_bounds__(DS_THREADS)
+dsort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t P, uint32_t nb, int shift, uint32_t* __restrict__ table) {
+  __shared__ uint32_t h[DS_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t k = blockIdx.x / nb, b = blockIdx.x - k * nb;
+  const uint32_t* seg = keys + (size_t)k * P;
+#pragma unroll 4
+  for (int r = 0; r < DS_ITEMS; r++) {
+    const uint32_t i = b * DS_TILE + (uint32_t)r * DS_THREADS + threadIdx.x;
+    if (i < P) atomicAdd(&h[(seg[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  table[(size_t)blockIdx.x * DS_BINS + threadIdx.x] = h[threadIdx.x];
+}
+
+// (segment, chunk): per digit, exclusive running count over the chunk's blocks (in place) and the chunk total
+__global__ void __launch_bounds__(DS_BINS)
+dsort_colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nb, uint32_t nch, uint32_t* __restrict__ ctot) {
+  const uint32_t k = blockIdx.x / nch, c = blockIdx.x - k * nch;
+  const uint32_t t0 = c * DS_CHUNK, t1 = min(t0 + (uint32_t)DS_CHUNK, nb);
+  uint32_t* base = table + ((size_t)k * nb) * DS_BINS + threadIdx.x;
+  uint32_t run = 0;
+  constexpr int U = 8;
+  for (uint32_t t = t0; t < t1; t += U) {
+    uint32_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = (t + u < t1) ? base[(size_t)(t + u) * DS_BINS] : 0u;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (t + u < t1) base[(size_t)(t + u) * DS_BINS] = run;
+      run += v[u];
+    }
+  }
+  ctot[(size_t)blockIdx.x * DS_BINS + threadIdx.x] = run;
+}
+
+// segment k: chunk totals -> exclusive chunk bases per digit, plus the digit's base inside the segment and k * P
+__global__ void __launch_bounds__(DS_BINS)
+dsort_colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nch, uint32_t P) {
+  __shared__ uint32_t lds[8];
+  uint32_t* base = ctot + ((size_t)blockIdx.x * nch) * DS_BINS + threadIdx.x;
+  uint32_t run = 0;
+  for (uint32_t c = 0; c < nch; c++) {
+    const uint32_t v = base[(size_t)c * DS_BINS];
+    base[(size_t)c * DS_BINS] = run;
+    run += v;
+  }
+  uint32_t tot;
+  const uint32_t pre = block_excl_scan(run, &tot, lds) + blockIdx.x * P;
+  for (uint32_t c = 0; c < nch; c++) base[(size_t)c * DS_BINS] += pre;
+}
+
+// FIRST: the values are generated (flat index k * P + i) instead of read.  LAST: keys are not written.
+template <bool FIRST, bool LAST>
+__global__ void __launch_bounds__(DS_THREADS)
+dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t P, uint32_t nb,
+                     uint32_t nch, int shift, const uint32_t* __restrict__ table, const uint32_t* __restrict__ ctot) {
+  __shared__ uint32_t lds_k[DS_TILE];
+  __shared__ uint32_t lds_v[DS_TILE];
+  __shared__ uint32_t whist[DS_THREADS / 64][DS_BINS];
+  __shared__ uint32_t gb[DS_BINS];
+  __shared__ uint32_t s_scan[8];
+  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  const uint32_t k = blockIdx.x / nb, b = blockIdx.x - k * nb;
+#pragma unroll
+  for (int i = 0; i < DS_BINS / 64; i++) whist[w][lane + 64 * i] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t wbase = b * DS_TILE + (uint32_t)w * (64 * DS_ITEMS);  // index inside the segment
+  const size_t sbase = (size_t)k * P;
+  uint32_t key[DS_ITEMS], val[DS_ITEMS], rank[DS_ITEMS];
+  volatile uint32_t* wh = whist[w];
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < DS_ITEMS; r++) {
+    const uint32_t i = wbase + (uint32_t)r * 64 + lane;
+    const bool valid = i < P;
+    key[r] = valid ? keys_in[sbase + i] : 0xFFFFFFFFu;
+    val[r] = FIRST ? (uint32_t)(sbase + i) : (valid ? vals_in[sbase + i] : 0u);
+  }
+#pragma unroll
+  for (int r = 0; r < DS_ITEMS; r++) {
+    const bool valid = (wbase + (uint32_t)r * 64 + lane) < P;
+    const uint32_t d = (key[r] >> shift) & 255u;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+      const uint64_t m = __ballot((d >> bit) & 1u);
+      peers &= ((d >> bit) & 1u) ? m : ~m;
+    }
+    const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
+    uint32_t pre = 0;
+    if (valid) pre = wh[d];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && below == 0) wh[d] = pre + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    rank[r] = pre + below;
+  }
+  __syncthreads();
+  // thread t owns digit t: block total, per-wave exclusive offsets, start of the digit inside the block
+  uint32_t cnt = 0;
+  {
+    const int d = threadIdx.x;
+#pragma unroll
+    for (int ww = 0; ww < DS_THREADS / 64; ww++) {
+      const uint32_t c = whist[ww][d];
+      whist[ww][d] = cnt;
+      cnt += c;
+    }
+  }
+  uint32_t tot;
+  const uint32_t dstart = block_excl_scan(cnt, &tot, s_scan);
+  // global position of block-local slot i holding digit d:  gb[d] + i
+  gb[threadIdx.x] = table[(size_t)blockIdx.x * DS_BINS + threadIdx.x] +
+                    ctot[((size_t)k * nch + b / DS_CHUNK) * DS_BINS + threadIdx.x] - dstart;
+  __shared__ uint32_t s_dstart[DS_BINS];
+  s_dstart[threadIdx.x] = dstart;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < DS_ITEMS; r++) {
+    if ((wbase + (uint32_t)r * 64 + lane) < P) {
+      const uint32_t d = (key[r] >> shift) & 255u;
+      const uint32_t slot = s_dstart[d] + whist[w][d] + rank[r];
+      lds_k[slot] = key[r];
+      lds_v[slot] = val[r];
+    }
+  }
+  __syncthreads();
+  const uint32_t nvalid = min((uint32_t)DS_TILE, P - b * DS_TILE);
+#pragma unroll
+  for (int r = 0; r < DS_ITEMS; r++) {
+    const uint32_t i = (uint32_t)r * DS_THREADS + threadIdx.x;
+    if (i < nvalid) {
+      const uint32_t kk = lds_k[i];
+      const uint32_t pos = gb[(kk >> shift) & 255u] + i;
+      if (!LAST) keys_out[pos] = kk;
+      vals_out[pos] = lds_v[i];
+    }
+  }
+}
+
 struct PassPlan {
   int n;
   int shift[16];
@@ -970,7 +1129,7 @@ hipError_t dgs_launch_tight_count(const DgsView& v, const DgsCarve& c, const uin
   hipError_t e = dgs_launch_scan(c.tt_sorted, c.offs_sorted, n, c.scan_tmp, total_full, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tight_kernel<false>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
-                     c.tt_tight, c.offs_tight, total_full, (uint64_t*)nullptr, (uint32_t*)nullptr);
+                     c.tt_tight, c.offs_tight, total_full, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
   return dgs_launch_scan(c.tt_tight, c.offs_tight, n, c.scan_tmp, total_tight, s);
 }
 
@@ -978,7 +1137,7 @@ hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const
   const uint64_t n = (uint64_t)v.K * v.P;
   const dim3 grid((uint32_t)((n + 255) / 256));
   hipLaunchKernelGGL(tight_kernel<true>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
-                     c.tt_tight, c.offs_tight, c.num_rendered, c.keys_unsorted, c.vals_unsorted);
+                     c.tt_tight, c.offs_tight, c.num_rendered, c.keys_unsorted, c.vals_unsorted, c.point_offsets);
   return hipGetLastError();
 }
 
@@ -986,5 +1145,45 @@ hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hi
   hipError_t e = hipMemsetAsync(c.ranges, 0, (size_t)v.K * v.T * sizeof(uint2), s);
   if (e != hipSuccess) return e;
   if (R > 0) hipLaunchKernelGGL(ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, c.keys_sorted, c.ranges);
+  return hipGetLastError();
+}
+
+size_t dgs_depth_sort_tmp_words(int K, uint32_t P) {
+  const uint64_t nb = ((uint64_t)P + DS_TILE - 1) / DS_TILE;
+  const uint64_t nch = (nb + DS_CHUNK - 1) / DS_CHUNK;
+  return (size_t)((uint64_t)K * (nb + nch) * DS_BINS + 256);
+}
+
+// keys [K*P] u32 (destroyed), order out [K*P] u32 = flat (k, Gaussian) indices in (k, key, index) order.  Four passes:
+// the result always lands in `order` (the first of the two value buffers).
+hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
+                                 uint32_t P, uint32_t* tmp, hipStream_t s) {
+  if (K <= 0 || P == 0) return hipSuccess;
+  const uint32_t nb = (P + DS_TILE - 1) / DS_TILE;
+  const uint32_t nch = (nb + DS_CHUNK - 1) / DS_CHUNK;
+  uint32_t* table = tmp;
+  uint32_t* ctot = tmp + (size_t)K * nb * DS_BINS;
+  const dim3 grid((uint32_t)K * nb), cgrid((uint32_t)K * nch);
+  uint32_t* kin = keys;
+  uint32_t* kout = keys_alt;
+  uint32_t* vin = order;       // pass 0 generates the values and writes order_alt, pass 3 writes order
+  uint32_t* vout = order_alt;
+  for (int pass = 0; pass < 4; pass++) {
+    const int shift = 8 * pass;
+    hipLaunchKernelGGL(dsort_hist_kernel, grid, dim3(DS_THREADS), 0, s, kin, P, nb, shift, table);
+    hipLaunchKernelGGL(dsort_colscan_chunk_kernel, cgrid, dim3(DS_BINS), 0, s, table, nb, nch, ctot);
+    hipLaunchKernelGGL(dsort_colscan_top_kernel, dim3((uint32_t)K), dim3(DS_BINS), 0, s, ctot, nch, P);
+    if (pass == 0)
+      hipLaunchKernelGGL((dsort_scatter_kernel<true, false>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P, nb,
+                         nch, shift, table, ctot);
+    else if (pass == 3)
+      hipLaunchKernelGGL((dsort_scatter_kernel<false, true>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P, nb,
+                         nch, shift, table, ctot);
+    else
+      hipLaunchKernelGGL((dsort_scatter_kernel<false, false>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P,
+                         nb, nch, shift, table, ctot);
+    uint32_t* tk = kin; kin = kout; kout = tk;
+    uint32_t* tv = vin; vin = vout; vout = tv;
+  }
   return hipGetLastError();
 }

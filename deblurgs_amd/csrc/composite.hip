@@ -198,7 +198,8 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
                      const DgsRow* __restrict__ rows,
                      const float* __restrict__ bg, const float* __restrict__ final_T,
                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                     const float* __restrict__ dL_ddepth, float* __restrict__ contrib) {
+                     const float* __restrict__ dL_ddepth, const uint32_t* __restrict__ dup_off,
+                     float* __restrict__ contrib) {
   __shared__ float4 s_row[CW][64 * 3];  // (x, y, A, B | C, op, r, g | b, depth, -, -) per list entry
   __shared__ float4 s_acc[CW][64][3];  // per-duplicate gradient rows of the current batch
   TileCtx t;
@@ -284,7 +285,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         // index of this (tile, Gaussian) duplicate in duplicate order: row-major inside the Gaussian's tile rect
         int minx, miny, maxx, maxy;
         dgs_get_rect(A.x, A.y, __float_as_int(Cc.w), v.gx, v.gy, minx, miny, maxx, maxy);
-        u = __float_as_uint(Cc.z) + (uint32_t)((t.ty - miny) * (maxx - minx) + (t.tx - minx));
+        u = dup_off[(size_t)t.k * v.P + g] + (uint32_t)((t.ty - miny) * (maxx - minx) + (t.tx - minx));
       }
     }
     uint64_t m[4] = {0, 0, 0, 0};
@@ -425,7 +426,7 @@ hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const f
   if (per == 0) return hipSuccess;
 #define DGS_CBWD(TI, HD)                                                                                            \
   hipLaunchKernelGGL((composite_bwd_kernel<TI, HD>), dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list, \
-                     c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth, contrib)
+                     c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth, c.point_offsets, contrib)
   if (v.tile_cull) {
     if (dL_ddepth != nullptr) DGS_CBWD(true, true); else DGS_CBWD(true, false);
   } else {

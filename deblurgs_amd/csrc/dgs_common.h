@@ -17,7 +17,7 @@ struct __attribute__((aligned(16))) DgsRow {
   float x, y;            // pixel-space mean (ndc2Pix)
   float cx, cy, cz, op;  // conic (a, b, c of the inverse 2-D covariance) and opacity
   float r, g, b, depth;  // activated colour, view-space depth
-  uint32_t dup_offset;   // first duplicate index of this (k, Gaussian): exclusive scan of tiles_touched
+  uint32_t dup_offset;   // unused (the first-duplicate offsets live in DgsCarve::point_offsets, by natural index)
   int32_t radius;        // ceil(3 sigma_max) in pixels
 };
 static_assert(sizeof(DgsRow) == 4 * DGS_ROW_F, "row must be 48 bytes");
@@ -30,9 +30,9 @@ struct DgsCarve {  // resolved device pointers of the three blobs
   uint32_t* point_offsets;
   uint32_t* scan_tmp;
   uint32_t* num_rendered;
-  uint64_t* gsort_keys;      // (k << 32 | depth_bits) per (k, Gaussian), and its ping-pong buffer
-  uint64_t* gsort_keys_alt;
-  uint32_t* gsort_vals;      // flat (k, Gaussian) index; sorted = (k, depth, index) order
+  uint32_t* gsort_keys;      // depth bits per (k, Gaussian) (0xFFFFFFFF = invisible), and the sort's ping-pong buffer
+  uint32_t* gsort_keys_alt;
+  uint32_t* gsort_vals;      // flat (k, Gaussian) indices in (k, depth, index) order (the depth sort's result)
   uint32_t* gsort_vals_alt;
   uint32_t* tt_sorted;       // tiles_touched in that order, and its exclusive scan
   uint32_t* offs_sorted;
@@ -225,6 +225,9 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
 hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t,
                                 const float* scale, float* blur, float* dsub, float* losses, hipStream_t s);
 
+hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
+                                 uint32_t P, uint32_t* tmp, hipStream_t s);
+size_t dgs_depth_sort_tmp_words(int K, uint32_t P);
 size_t dgs_scan_tmp_words(uint64_t n);
 size_t dgs_sort_tmp_words(uint64_t n);
 int dgs_sort_num_passes(int begin_bit, int end_bit);

@@ -143,8 +143,8 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     }
   }
 
-  // Software pipeline over the subframes: the loads of one (subframe, Gaussian) are three dependent hops
-  // (tiles_touched -> geometry row -> contribution row at the row's duplicate offset) and this kernel runs at two
+  // Software pipeline over the subframes: the loads of one (subframe, Gaussian) are dependent hops
+  // (tiles_touched / duplicate offset -> contribution row at that offset) and this kernel runs at two
   // waves per SIMD, so they are issued ahead: row of k+2 and contribution row of k+1 are in flight while k computes.
   struct RowPf {
     uint32_t nt, doff;
@@ -157,7 +157,7 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     r.nt = valid ? tiles_touched[o] : 0u;
     r.ga = rowp[0];   // unconditional (no dependent hop); rows of invisible pairs are never used
     r.gb = rowp[1];
-    r.doff = __float_as_uint(rowp[2].z);
+    r.doff = valid ? offsets[o] : 0u;   // first contribution row of the pair (written by the duplication pass)
     return r;
   };
   struct SumPf {

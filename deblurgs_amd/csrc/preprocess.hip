@@ -54,7 +54,7 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
                       const float* __restrict__ projm, const float* __restrict__ campos, DgsRow* __restrict__ rows,
                       float* __restrict__ cov3Ds, float* __restrict__ pre_sigmoid,
                       uint32_t* __restrict__ tiles_touched, int32_t* __restrict__ radii,
-                      uint64_t* __restrict__ gkeys, uint32_t* __restrict__ gvals) {
+                      uint32_t* __restrict__ dkeys) {
   // Row and colour-mask stores are transposed through LDS per wave: a lane's 48-byte row becomes three
   // wave-wide 1 KB stores (64 consecutive float4) instead of three 16-byte stores at a 48-byte lane stride.
   __shared__ float4 s_row[4][3 * 64];
@@ -246,8 +246,7 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
       tiles_touched[o] = out_tiles;
       // sort key of the (k, Gaussian) pair for the depth-ordered duplication (binning.hip): invisible pairs sort
       // to the end of their subframe and emit nothing
-      gkeys[o] = ((uint64_t)k << 32) | (out_tiles ? __float_as_uint(row.depth) : 0xFFFFFFFFu);
-      gvals[o] = (uint32_t)o;
+      dkeys[o] = out_tiles ? __float_as_uint(row.depth) : 0xFFFFFFFFu;
     }
     // wave-transposed stores of the 64 rows / colour masks of this (wave, k); invisible pairs store zeros
     {
@@ -293,7 +292,7 @@ hipError_t dgs_launch_preprocess(const DgsProblem& p, const DgsView& v, const Dg
 #define DGS_PRE(DEG)                                                                                                  \
   hipLaunchKernelGGL(preprocess_fwd_kernel<DEG>, dim3(blocks), dim3(256), 0, s, v, p.means3D, p.scales, p.rotations, \
                      p.opacities, p.shs, p.shs_rest, p.cov3D_precomp, p.colors_precomp, p.viewmatrix, p.projmatrix, p.campos,     \
-                     c.rows, c.cov3D, c.pre_sigmoid, c.tiles_touched, radii, c.gsort_keys, c.gsort_vals)
+                     c.rows, c.cov3D, c.pre_sigmoid, c.tiles_touched, radii, c.gsort_keys)
   const int deg = (p.colors_precomp != nullptr) ? 0 : v.D;
   if (deg <= 0)
     DGS_PRE(0);

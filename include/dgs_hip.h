@@ -117,7 +117,7 @@ typedef struct DgsBackwardIO {
 } DgsBackwardIO;
 
 /* Byte offsets of the sub-arrays inside the three blobs (for debuggers and the parity tests).
- * Element types: rows f32[12] = {x, y, conic.x, conic.y, conic.z, opacity, r, g, b, depth, u32 dup_offset,
+ * Element types: rows f32[12] = {x, y, conic.x, conic.y, conic.z, opacity, r, g, b, depth, u32 (unused),
  * i32 radius}; keys u64 = ((k*T + tile) << 32) | depth_bits; ranges uint2 per (k, tile). */
 typedef struct DgsLayout {
   /* geometry blob */
@@ -125,13 +125,14 @@ typedef struct DgsLayout {
   size_t cov3D;          /* f32 [P,6] */
   size_t pre_sigmoid;    /* f32 [K,P,3]  pre-activation colour (sigmoid) or 0/1 clamp mask (relu) */
   size_t tiles_touched;  /* u32 [K*P] */
-  size_t point_offsets;  /* u32 [K*P] exclusive prefix sum of tiles_touched in [K,P] order (its total is R); the
-                          * duplicate offsets actually used live in the geometry rows (depth order) */
+  size_t point_offsets;  /* u32 [K*P] by natural (k, Gaussian) index: index of the pair's first duplicate = first
+                          * contribution row of the backward (duplicates are laid out in (k, depth, index) order;
+                          * 0xFFFFFFFF = visible but every tile culled; undefined for invisible pairs) */
   size_t scan_tmp;       /* u32 scan block sums */
   size_t num_rendered;   /* u32 [4] device copy of R (+ spare) */
-  size_t gsort_keys;     /* u64 [K*P] (k << 32) | depth_bits: the (k, depth, index) ordering of the Gaussians */
-  size_t gsort_keys_alt; /* u64 [K*P] */
-  size_t gsort_vals;     /* u32 [K*P] flat (k, Gaussian) indices */
+  size_t gsort_keys;     /* u32 [K,P] depth bits (0xFFFFFFFF = invisible): keys of the segmented depth sort */
+  size_t gsort_keys_alt; /* u32 [K,P] its ping-pong buffer */
+  size_t gsort_vals;     /* u32 [K*P] flat (k, Gaussian) indices in (k, depth, index) order (the sort's result) */
   size_t gsort_vals_alt; /* u32 [K*P] */
   size_t tt_sorted;      /* u32 [K*P] tiles_touched in (k, depth, index) order */
   size_t offs_sorted;    /* u32 [K*P] its exclusive prefix sum */

@@ -251,8 +251,8 @@ vec3 computeColorFromSH(int idx, int deg, int max_coeffs, const float* means, ve
 
 }  // namespace
 
-// OpenMP build only: 1 = round every accumulation of the compositing backward to fp32 (same deterministic order as the
-// double accumulation).  The difference between the two modes is the fp32 rounding noise of THAT summation structure
+// OpenMP build only: 1 = round every accumulation of the compositing backward AND of the pose sums to fp32 (same
+// deterministic order as the double accumulation).  The difference between the two modes is the fp32 rounding noise of THAT summation structure
 // (per duplicate, then per Gaussian over duplicates -- the structure the HIP path uses too); the parity tests use it as
 // the noise floor next to the 1e-4 bar.
 bool g_accum_f32 = false;
@@ -683,6 +683,10 @@ void dgs_oracle_preprocess_backward(int P, int D, int M, int W, int H, const flo
     dL_dview_matrix_acc[12] += dL_dtx;
     dL_dview_matrix_acc[13] += dL_dty;
     dL_dview_matrix_acc[14] += dL_dtz;
+#ifdef _OPENMP
+    if (g_accum_f32)
+      for (int i = 0; i < 16; i++) dL_dview_matrix_acc[i] = (double)(float)dL_dview_matrix_acc[i];
+#endif
   }
   }
   // ---- preprocessCUDA (bwd)
@@ -851,14 +855,26 @@ void dgs_oracle_preprocess_backward(int P, int D, int M, int W, int H, const flo
     dL_dview_matrix_acc[6] += dL_ddepth[idx] * m.y;
     dL_dview_matrix_acc[10] += dL_ddepth[idx] * m.z;
     dL_dview_matrix_acc[14] += dL_ddepth[idx];
+#ifdef _OPENMP
+    if (g_accum_f32)
+      for (int i = 0; i < 16; i++) {
+        dL_dview_matrix_acc[i] = (double)(float)dL_dview_matrix_acc[i];
+        dL_dproj_acc[i] = (double)(float)dL_dproj_acc[i];
+      }
+#endif
   }
   }
 #ifdef _OPENMP
   for (int i = 0; i < 16; i++) {
     double v = 0.0, pj = 0.0;
-    for (int c = 0; c < 2 * nchunks; c++) v += part_view[(size_t)c * 16 + i];
-    for (int c = 0; c < nchunks; c++) pj += part_proj[(size_t)c * 16 + i];
-    // (the fp32-emulation mode does not cover the pose sums: their noise floor is reported by the term norms below)
+    for (int c = 0; c < 2 * nchunks; c++) {
+      v += part_view[(size_t)c * 16 + i];
+      if (g_accum_f32) v = (double)(float)v;
+    }
+    for (int c = 0; c < nchunks; c++) {
+      pj += part_proj[(size_t)c * 16 + i];
+      if (g_accum_f32) pj = (double)(float)pj;
+    }
     dL_dview_matrix[i] += (float)v;
     dL_dproj[i] += (float)pj;
   }

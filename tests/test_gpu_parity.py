@@ -116,7 +116,8 @@ def test_binning_bit_exact(scene_states):
     offs = np.zeros(order.size, np.uint64)
     offs[order] = np.concatenate([[0], np.cumsum(flat_tt[order])[:-1]])
     vis_flat = flat_tt > 0
-    assert np.array_equal(hip["rows_u32"].reshape(-1, 12)[vis_flat, 10], offs[vis_flat].astype(np.uint32))
+    # (the first-duplicate offset of every visible pair lives in the K*P-word side array, by natural index)
+    assert np.array_equal(hip["point_offsets"].reshape(-1)[vis_flat], offs[vis_flat].astype(np.uint32))
     off = 0
     for k, o in enumerate(ora):
         R = Rs[k]
@@ -299,13 +300,13 @@ def test_tile_cull_lists_are_the_contributing_subset(gpu, seed, sigma):
     # the low key word is the duplicate's emission index: a permutation of [0, R), segment by segment
     u = (cul["keys"] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     assert np.array_equal(np.sort(u), np.arange(cul["R"]))
-    flat = cul["rows_u32"].reshape(-1, 12)
+    flat_off = cul["point_offsets"].reshape(-1)
     gi = (cul["keys"] >> np.uint64(32)).astype(np.int64) // cul["T"] * P + cul["point_list"]
-    doff = flat[gi, 10].astype(np.int64)
+    doff = flat_off[gi].astype(np.int64)
     cnt = np.bincount(gi, minlength=K * P)
     assert np.all((u >= doff) & (u < doff + cnt[gi])), "contribution-row slot inside the pair's segment"
     vis = cul["tiles_touched"].reshape(-1) > 0
-    assert np.all(flat[vis & (cnt == 0), 10] == 0xFFFFFFFF)
+    assert np.all(flat_off[vis & (cnt == 0)] == 0xFFFFFFFF)
     rng = cul["ranges"].reshape(-1, 2).astype(np.int64)
     assert np.array_equal(rng[:, 1] - rng[:, 0], np.bincount((cul["keys"] >> np.uint64(32)).astype(np.int64),
                                                              minlength=rng.shape[0]))
