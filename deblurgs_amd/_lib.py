@@ -49,7 +49,7 @@ class DgsBackwardIO(ctypes.Structure):
         ("dL_dsh_rest", ctypes.c_void_p),
         ("dL_dcolors", ctypes.c_void_p), ("dL_dopacity", ctypes.c_void_p), ("dL_dscales", ctypes.c_void_p),
         ("dL_drotations", ctypes.c_void_p), ("dL_dcov3D", ctypes.c_void_p), ("dL_dviewmatrix", ctypes.c_void_p),
-        ("dL_dprojmatrix", ctypes.c_void_p),
+        ("dL_dprojmatrix", ctypes.c_void_p), ("opacity_hinge_scale", ctypes.c_float),
     ]
 
 
@@ -106,9 +106,12 @@ EXPORTS = {
                                              ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p]),
     "dgs_densify_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
-                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p]),
     "dgs_adam_step": (ctypes.c_int, [ctypes.POINTER(DgsAdamGroup), ctypes.c_int32, ctypes.c_double, ctypes.c_double,
-                                     ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),
+                                     ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    "dgs_forward": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsForwardOut), ctypes.c_uint32,
+                                   ctypes.c_void_p]),
     "dgs_densify_tmp_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dgs_densify_plan": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_float] * 4 +
                          [ctypes.c_void_p] * 6),
@@ -118,6 +121,10 @@ EXPORTS = {
     "dgs_knn_tmp_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dgs_knn_mean_dist2": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p]),
+    "dgs_alignment_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "dgs_alignment_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dgs_pose_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dgs_pose_forward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 4),
     "dgs_pose_backward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32]

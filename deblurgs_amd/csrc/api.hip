@@ -40,7 +40,7 @@ void make_layout(int P, int W, int H, int K, uint64_t R, DgsLayout* L) {
   L->tiles_touched = o;  o += up(KP * 4);
   L->point_offsets = o;  o += up(KP * 4);
   L->scan_tmp = o;       o += up(dgs_scan_tmp_words(KP) * 4);
-  L->num_rendered = o;   o += up(16);
+  L->num_rendered = o;   o += up(32);
   L->gsort_keys = o;     o += up(KP * 4);
   L->gsort_keys_alt = o; o += up(KP * 4);
   L->gsort_vals = o;     o += up(KP * 4);
@@ -295,7 +295,9 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
 // train.py:188-193 + scene/gaussian_model.py:456-458 for the K subframes of one step, in subframe order
 __global__ void __launch_bounds__(256)
 densify_stats_kernel(const float* __restrict__ vgrad, const int32_t* __restrict__ radii, int K, int K_total, int P,
-                     float* __restrict__ max_radii2D, float* __restrict__ accum, float* __restrict__ denom) {
+                     float* __restrict__ max_radii2D, float* __restrict__ accum, float* __restrict__ denom,
+                     const uint32_t* __restrict__ skip) {
+  if (skip != nullptr && skip[0] != 0u) return;
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= P) return;
   float mr = max_radii2D[g], ac = accum[g], dn = denom[g];
@@ -405,8 +407,9 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
   DgsCarve c;
   carve(p, L, &c);
   const DgsView v = make_view(p);
+  hipError_t e = hipMemsetAsync(c.num_rendered, 0, 32, s);
+  if (e != hipSuccess) return fail_hip(e, "clear status");
   DGS_STAGE(DGS_STAGE_PREPROCESS, "preprocess", dgs_launch_preprocess(*p, v, c, out->radii, s));
-  hipError_t e;
   if (!v.tile_cull) {
     DGS_STAGE(DGS_STAGE_SCAN, "scan",
               dgs_launch_scan(c.tiles_touched, c.point_offsets, (uint64_t)p->K * p->P, c.scan_tmp, c.num_rendered, s));
@@ -427,8 +430,10 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
   return DGS_OK;
 }
 
-int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t R, dgs_stream_t stream) {
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+// R = the exact duplicate count (two-phase forward), or the capacity of the duplicate arrays when `speculative`
+// (then the kernels read the count from c.num_rendered[4], set by finalize_count)
+static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, uint32_t R, bool speculative,
+                               hipStream_t s) {
   int rc = check_problem(p);
   if (rc != DGS_OK) return rc;
   if (out == nullptr || out->out_color == nullptr || out->out_depth == nullptr)
@@ -448,6 +453,7 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t R
   DgsCarve c;
   carve(p, L, &c);
   const DgsView v = make_view(p);
+  const uint32_t* n_dev = speculative ? c.num_rendered + 4 : nullptr;
   if (R > 0 || v.tile_cull) {  // tile_cull with R == 0 still marks the visible pairs as "no surviving tile"
     // choose the sort's input pair so that the result always lands in keys_sorted / point_list
     DgsCarve cd = c;
@@ -462,23 +468,49 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t R
       const uint32_t* order = c.gsort_vals;
       // (2) duplicate in that order, (3) stable sort on the tile bits only
       DGS_STAGE(DGS_STAGE_DUPLICATE, "duplicateWithKeys",
-                dgs_launch_duplicate_sorted(v, cd, order, c.tt_sorted, c.offs_sorted, c.scan_tmp, s));
+                dgs_launch_duplicate_sorted(v, cd, order, c.tt_sorted, c.offs_sorted, c.scan_tmp, R, s));
     } else {
       // the ordering and the surviving-tile offsets were produced by dgs_forward_geometry
       const uint32_t* order = c.gsort_vals;
-      DGS_STAGE(DGS_STAGE_DUPLICATE, "duplicateWithKeys", dgs_launch_duplicate_tight(v, cd, order, s));
+      DGS_STAGE(DGS_STAGE_DUPLICATE, "duplicateWithKeys", dgs_launch_duplicate_tight(v, cd, order, R, s));
     }
     int in_alt = 0;
     uint64_t* kalt = even ? c.keys_unsorted : c.keys_sorted;
     uint32_t* valt = even ? c.vals_unsorted : c.point_list;
     DGS_STAGE(DGS_STAGE_SORT, "radix sort",
               dgs_launch_sort(cd.keys_unsorted, cd.vals_unsorted, kalt, valt, R, 32, L.sort_bits, c.sort_tmp, &in_alt,
-                              s));
+                              s, n_dev));
   }
-  DGS_STAGE(DGS_STAGE_RANGES, "identifyTileRanges", dgs_launch_ranges(v, c, R, s));
+  DGS_STAGE(DGS_STAGE_RANGES, "identifyTileRanges", dgs_launch_ranges(v, c, R, s, n_dev));
   DGS_STAGE(DGS_STAGE_COMPOSITE_FWD, "composite forward",
             dgs_launch_composite_fwd(v, c, p->bg, out->out_color, out->out_depth, s));
   return DGS_OK;
+}
+
+int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t R, dgs_stream_t stream) {
+  return forward_render_impl(p, out, R, false, reinterpret_cast<hipStream_t>(stream));
+}
+
+int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = dgs_forward_geometry(p, out, stream);   // includes the async copy of the counts to num_rendered_host[0..1]
+  if (rc != DGS_OK) return rc;
+  if (p->P > 0) {
+    DgsLayout L;
+    make_layout(p->P, p->W, p->H, p->K, 0, &L);
+    DgsCarve c;
+    carve(p, L, &c);
+    hipError_t e = dgs_launch_finalize_count(c, p->tile_cull != 0, capacity, s);
+    if (e == hipSuccess)   // [2] = overflow flag, [3] = the count the lists were built with (0 on overflow)
+      e = hipMemcpyAsync(out->num_rendered_host + 2, c.num_rendered + 5, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(out->num_rendered_host + 3, c.num_rendered + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return fail_hip(e, "finalize count");
+  } else {
+    out->num_rendered_host[2] = 0;
+    out->num_rendered_host[3] = 0;
+  }
+  return forward_render_impl(p, out, capacity, true, s);
 }
 
 int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream) {
@@ -575,14 +607,15 @@ int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32
 }
 
 int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t K_total, int32_t P,
-                      float* max_radii2D, float* xyz_gradient_accum, float* denom, dgs_stream_t stream) {
+                      float* max_radii2D, float* xyz_gradient_accum, float* denom, const uint32_t* skip_flag,
+                      dgs_stream_t stream) {
   if (K_total <= 0) K_total = K;
   if (K < 1 || K_total < K || P < 0 || (P > 0 && (viewspace_grad == nullptr || radii == nullptr || max_radii2D == nullptr ||
                                    xyz_gradient_accum == nullptr || denom == nullptr)))
     return fail(DGS_E_ARG, "densify_stats: bad argument");
   if (P == 0) return DGS_OK;
   hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     viewspace_grad, radii, K, K_total, P, max_radii2D, xyz_gradient_accum, denom);
+                     viewspace_grad, radii, K, K_total, P, max_radii2D, xyz_gradient_accum, denom, skip_flag);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DGS_OK : fail_hip(e, "densify_stats");
 }

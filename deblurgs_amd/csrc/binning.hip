@@ -144,37 +144,6 @@ scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, u
   }
 }
 
-// ------------------------------------------------------------------------------------------- duplicate
-// One thread per (subframe, Gaussian).  Also stamps the duplicate offset into the geometry row so that the
-// backward compositing can address its contribution rows without an inverse permutation.
-__global__ void __launch_bounds__(256)
-duplicate_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __restrict__ tiles_touched,
-                 const uint32_t* __restrict__ offsets, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint64_t n = (uint64_t)v.K * v.P;
-  if (i >= n) return;
-  if (tiles_touched[i] == 0) return;  // radii > 0 <=> tiles_touched > 0 (forward.cu:246-249,267)
-  const uint32_t k = (uint32_t)(i / (uint64_t)v.P);
-  const uint32_t g = (uint32_t)(i - (uint64_t)k * v.P);
-  DgsRow* row = rows + i;
-  const float x = row->x, y = row->y;
-  const int radius = row->radius;
-  uint32_t off = offsets[i];
-  int minx, miny, maxx, maxy;
-  dgs_get_rect(x, y, radius, v.gx, v.gy, minx, miny, maxx, maxy);
-  const uint32_t dbits = __float_as_uint(row->depth);
-  const uint32_t tbase = k * (uint32_t)v.T;
-  for (int ty = miny; ty < maxy; ty++)
-    for (int tx = minx; tx < maxx; tx++) {
-      uint64_t key = (uint64_t)(tbase + (uint32_t)ty * (uint32_t)v.gx + (uint32_t)tx);
-      key <<= 32;
-      key |= dbits;
-      keys[off] = key;
-      vals[off] = g;
-      off++;
-    }
-}
-
 // ------------------------------------------------------------------------------ depth-ordered duplication
 // The duplicates only need a STABLE sort by (k, tile) if they are generated in (k, depth, index) order: the
 // low 32 key bits (depth) are then already in order inside every (k, tile) group, exactly as if the LSD passes
@@ -199,7 +168,7 @@ __global__ void __launch_bounds__(256)
 duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __restrict__ order,
                         const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ offs_sorted,
                         uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
-                        uint32_t* __restrict__ vals) {
+                        uint32_t* __restrict__ vals, uint32_t cap) {
   __shared__ uint32_t s_off[4][64];    // segment start relative to the wave's first duplicate
   __shared__ uint32_t s_rect[4][64];   // minx | miny << 12 | width << 24  (grid <= 4095 tiles per side, width <= 255)
   __shared__ uint32_t s_wide[4][64];   // full width for rectangles wider than 255 tiles
@@ -258,8 +227,10 @@ duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __
     const uint32_t rect = s_rect[w][lo];
     const uint32_t ry = local / width, rx = local - ry * width;
     const uint32_t tile = s_tb[w][lo] + ((rect >> 12) + ry) * (uint32_t)v.gx + (rect & 0xFFFu) + rx;
-    keys[base + d] = ((uint64_t)tile << 32) | s_db[w][lo];
-    vals[base + d] = s_g[w][lo];
+    if (base + d < cap) {   // cap = capacity of the duplicate arrays (the exact count unless the caller sized them ahead)
+      keys[base + d] = ((uint64_t)tile << 32) | s_db[w][lo];
+      vals[base + d] = s_g[w][lo];
+    }
   }
 }
 
@@ -279,7 +250,7 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
              const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ offs_sorted,
              uint32_t* __restrict__ tt_tight, const uint32_t* __restrict__ offs_tight,
              const uint32_t* __restrict__ total_full, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-             uint32_t* __restrict__ dup_off) {
+             uint32_t* __restrict__ dup_off, uint32_t cap) {
   // the rectangle total overflowed 32 bits: the offsets are meaningless (the host raises on the overflow word)
   if (total_full[1] != 0u) {
     const uint64_t jj = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -383,8 +354,10 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
     if (EMIT) {
       if (hit) {
         const uint32_t pos = obase + run + (uint32_t)__builtin_popcountll(hm & lt);
-        keys[pos] = ((uint64_t)tile << 32) | pos;
-        vals[pos] = s_g[w][lo];
+        if (pos < cap) {
+          keys[pos] = ((uint64_t)tile << 32) | pos;
+          vals[pos] = s_g[w][lo];
+        }
       }
       run += (uint32_t)__builtin_popcountll(hm);
     } else {
@@ -408,9 +381,22 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
   }
 }
 
+// Capacity mode (dgs_forward): the duplicate arrays were sized by the caller before the count was known.  Words of
+// c.num_rendered: [0] rectangle total, [1] its high half (u32 overflow), [2] surviving total (tile_cull), [4] the count
+// the sort / ranges kernels use = min(count, capacity), [5] overflow flag (the lists are truncated: every consumer that
+// indexes by duplicate offset returns early, the caller re-runs with a larger capacity).
+__global__ void finalize_count_kernel(uint32_t* __restrict__ nr, int cull, uint32_t cap) {
+  const uint32_t n = cull ? nr[2] : nr[0];
+  const bool bad = (nr[1] != 0u) || (n > cap);
+  nr[4] = bad ? 0u : n;
+  nr[5] = bad ? 1u : 0u;
+}
+
 // ---------------------------------------------------------------------------------------------- ranges
 __global__ void __launch_bounds__(256)
-ranges_kernel(uint32_t L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+ranges_kernel(uint32_t L, const uint32_t* __restrict__ n_dev, const uint64_t* __restrict__ keys,
+              uint2* __restrict__ ranges) {
+  if (n_dev != nullptr) L = min(L, n_dev[0]);
   const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= L) return;
   const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
@@ -528,7 +514,11 @@ sort_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __rest
 constexpr int CS_CHUNK = 64;  // tiles per column-scan chunk
 
 __global__ void __launch_bounds__(SORT_THREADS)
-sort_hist_rows_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift, int rb, uint32_t* __restrict__ table) {
+sort_hist_rows_kernel(const uint64_t* __restrict__ keys, uint64_t n, const uint32_t* __restrict__ n_dev, int shift,
+                      int rb, uint32_t* __restrict__ table) {
+  // n_dev (optional): the pair count lives in device memory and n is only the capacity the grid was sized for
+  if (n_dev != nullptr) n = min(n, (uint64_t)n_dev[0]);
+  if ((uint64_t)blockIdx.x * SORT_TILE >= n) return;
   __shared__ uint32_t h[SORT_MAX_BINS];
   for (int i = threadIdx.x; i < SORT_MAX_BINS; i += SORT_THREADS) h[i] = 0;
   __syncthreads();
@@ -546,8 +536,11 @@ sort_hist_rows_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift, 
 
 // chunk c: per digit, exclusive running count over the chunk's tiles (in place) and the chunk total
 __global__ void __launch_bounds__(256)
-colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nblocks, uint32_t* __restrict__ ctot) {
+colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nblocks, const uint32_t* __restrict__ n_dev,
+                     uint32_t* __restrict__ ctot) {
+  if (n_dev != nullptr) nblocks = min(nblocks, (uint32_t)(((uint64_t)n_dev[0] + SORT_TILE - 1) / SORT_TILE));
   const uint32_t t0 = blockIdx.x * CS_CHUNK;
+  if (t0 >= nblocks) return;
   const uint32_t t1 = min(t0 + CS_CHUNK, nblocks);
   uint32_t run0 = 0, run1 = 0;
   for (uint32_t t = t0; t < t1; t++) {
@@ -566,7 +559,11 @@ colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nblocks, uint32_t* _
 // The chunk loop is latency-bound (one block, dependent only through the running sums), so rows are fetched
 // eight at a time before the serial prefix is applied.
 __global__ void __launch_bounds__(256)
-colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nchunks) {
+colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nchunks, const uint32_t* __restrict__ n_dev) {
+  if (n_dev != nullptr) {
+    const uint32_t nb = (uint32_t)(((uint64_t)n_dev[0] + SORT_TILE - 1) / SORT_TILE);
+    nchunks = min(nchunks, (nb + CS_CHUNK - 1) / CS_CHUNK);
+  }
   __shared__ uint32_t lds[8];
   constexpr int U = 8;
   uint32_t run0 = 0, run1 = 0;
@@ -666,7 +663,11 @@ __global__ void __launch_bounds__(SORT_THREADS)
 onesweep_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                         uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint64_t n, int shift, int rb,
                         const uint32_t* __restrict__ gbase, uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
-                        uint32_t nblocks) {
+                        uint32_t nblocks, const uint32_t* __restrict__ n_dev) {
+  if (!LOOKBACK && n_dev != nullptr) {
+    n = min(n, (uint64_t)n_dev[0]);
+    if ((uint64_t)blockIdx.x * SORT_TILE >= n) return;  // block-uniform, before any barrier
+  }
   __shared__ uint64_t lds_k[SORT_TILE];  // 32 KB; re-used for the values
   __shared__ uint32_t whist[SORT_THREADS / 64][SORT_MAX_BINS];
   __shared__ uint32_t dstart[SORT_MAX_BINS];
@@ -982,6 +983,11 @@ PassPlan plan_passes(int begin_bit, int end_bit) {
 
 }  // namespace
 
+hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, hipStream_t s) {
+  hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, s, c.num_rendered, cull, cap);
+  return hipGetLastError();
+}
+
 size_t dgs_scan_tmp_words(uint64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 64; }
 
 hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, uint32_t* total,
@@ -1019,11 +1025,15 @@ static int sort_mode() {
   return v;
 }
 
+// n_dev (optional): device word holding the actual pair count (<= n); every launch is then sized by the capacity n and
+// the kernels read the count themselves (no host read of num_rendered between duplication and sort)
 hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
-                           int begin_bit, int end_bit, uint32_t* tmp, int* result_in_alt, hipStream_t s) {
+                           int begin_bit, int end_bit, uint32_t* tmp, int* result_in_alt, hipStream_t s,
+                           const uint32_t* n_dev) {
   const PassPlan plan = plan_passes(begin_bit, end_bit);
   *result_in_alt = plan.n & 1;
   if (n == 0) return hipSuccess;
+  if (n_dev != nullptr && sort_mode() != 1) return hipErrorInvalidValue;  // device-side counts: default path only
   const uint32_t nblocks = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
   if (sort_mode() == 2 && n < (1ull << 30) && plan.n <= OS_MAX_PASSES) {
     // tmp layout: [status: nblocks*512][ghist: passes*512][tickets: passes]
@@ -1049,7 +1059,8 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
       e = hipMemsetAsync(status, 0, (size_t)nblocks * SORT_MAX_BINS * 4, s);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(onesweep_scatter_kernel<true>, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout,
-                         n, plan.shift[p], plan.rb[p], ghist + (size_t)p * SORT_MAX_BINS, status, tickets + p, nblocks);
+                         n, plan.shift[p], plan.rb[p], ghist + (size_t)p * SORT_MAX_BINS, status, tickets + p, nblocks,
+                         (const uint32_t*)nullptr);
       uint64_t* tk = kin;
       kin = kout;
       kout = tk;
@@ -1069,12 +1080,12 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
     const uint32_t nchunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
     uint32_t* ctot = scan_tmp;  // [nchunks][512]
     for (int p = 0; p < plan.n; p++) {
-      hipLaunchKernelGGL(sort_hist_rows_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, plan.shift[p],
+      hipLaunchKernelGGL(sort_hist_rows_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, n_dev, plan.shift[p],
                          plan.rb[p], table);
-      hipLaunchKernelGGL(colscan_chunk_kernel, dim3(nchunks), dim3(256), 0, s, table, nblocks, ctot);
-      hipLaunchKernelGGL(colscan_top_kernel, dim3(1), dim3(256), 0, s, ctot, nchunks);
+      hipLaunchKernelGGL(colscan_chunk_kernel, dim3(nchunks), dim3(256), 0, s, table, nblocks, n_dev, ctot);
+      hipLaunchKernelGGL(colscan_top_kernel, dim3(1), dim3(256), 0, s, ctot, nchunks, n_dev);
       hipLaunchKernelGGL(onesweep_scatter_kernel<false>, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout,
-                         n, plan.shift[p], plan.rb[p], table, ctot, nullptr, nblocks);
+                         n, plan.shift[p], plan.rb[p], table, ctot, nullptr, nblocks, n_dev);
       uint64_t* tk = kin;
       kin = kout;
       kout = tk;
@@ -1102,22 +1113,15 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
   return hipGetLastError();
 }
 
-hipError_t dgs_launch_duplicate(const DgsView& v, const DgsCarve& c, hipStream_t s) {
-  const uint64_t n = (uint64_t)v.K * v.P;
-  hipLaunchKernelGGL(duplicate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, v, c.rows, c.tiles_touched,
-                     c.point_offsets, c.keys_unsorted, c.vals_unsorted);
-  return hipGetLastError();
-}
-
 hipError_t dgs_launch_duplicate_sorted(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* tt_sorted,
-                                       uint32_t* offs_sorted, uint32_t* scan_tmp, hipStream_t s) {
+                                       uint32_t* offs_sorted, uint32_t* scan_tmp, uint32_t cap, hipStream_t s) {
   const uint64_t n = (uint64_t)v.K * v.P;
   const dim3 grid((uint32_t)((n + 255) / 256));
   hipLaunchKernelGGL(gather_u32_kernel, grid, dim3(256), 0, s, n, order, c.tiles_touched, tt_sorted);
   hipError_t e = dgs_launch_scan(tt_sorted, offs_sorted, n, scan_tmp, nullptr, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(duplicate_sorted_kernel, grid, dim3(256), 0, s, v, c.rows, order, tt_sorted, offs_sorted,
-                     c.point_offsets, c.keys_unsorted, c.vals_unsorted);
+                     c.point_offsets, c.keys_unsorted, c.vals_unsorted, cap);
   return hipGetLastError();
 }
 
@@ -1129,22 +1133,24 @@ hipError_t dgs_launch_tight_count(const DgsView& v, const DgsCarve& c, const uin
   hipError_t e = dgs_launch_scan(c.tt_sorted, c.offs_sorted, n, c.scan_tmp, total_full, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tight_kernel<false>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
-                     c.tt_tight, c.offs_tight, total_full, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                     c.tt_tight, c.offs_tight, total_full, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
   return dgs_launch_scan(c.tt_tight, c.offs_tight, n, c.scan_tmp, total_tight, s);
 }
 
-hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const uint32_t* order, hipStream_t s) {
+hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t cap,
+                                      hipStream_t s) {
   const uint64_t n = (uint64_t)v.K * v.P;
   const dim3 grid((uint32_t)((n + 255) / 256));
   hipLaunchKernelGGL(tight_kernel<true>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
-                     c.tt_tight, c.offs_tight, c.num_rendered, c.keys_unsorted, c.vals_unsorted, c.point_offsets);
+                     c.tt_tight, c.offs_tight, c.num_rendered, c.keys_unsorted, c.vals_unsorted, c.point_offsets, cap);
   return hipGetLastError();
 }
 
-hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s) {
+hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s, const uint32_t* n_dev) {
   hipError_t e = hipMemsetAsync(c.ranges, 0, (size_t)v.K * v.T * sizeof(uint2), s);
   if (e != hipSuccess) return e;
-  if (R > 0) hipLaunchKernelGGL(ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, c.keys_sorted, c.ranges);
+  if (R > 0)
+    hipLaunchKernelGGL(ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, n_dev, c.keys_sorted, c.ranges);
   return hipGetLastError();
 }
 

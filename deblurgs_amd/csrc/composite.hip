@@ -387,7 +387,8 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         uc += dgs_dpp<0x128, 0xf>(uc);  // row_ror:8
         float tot = dgs_quad_sum(dgs_fold4(dgs_fold8(ua, ub), uc));
         asm volatile("" : "+v"(tot));  // finish the last DPP add here, not inside the store's exec branch
-        if (wslot >= 0) reinterpret_cast<float*>(&s_acc[w][j][0])[wslot] = tot;
+        // (32-bit LDS index: the generic float* arithmetic compiled to a quarter-rate v_mad_u64_u32)
+        if (wslot >= 0) reinterpret_cast<float*>(&s_acc[w][0][0])[j * DGS_CONTRIB_F + wslot] = tot;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

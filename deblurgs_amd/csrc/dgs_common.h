@@ -205,17 +205,20 @@ hipError_t dgs_launch_mark_visible(int P, const float* means3D, const float* vie
 hipError_t dgs_launch_cloud_activations(int P, const float* scales, const float* rotations, const float* opacities,
                                         float scale_lb, float* out_scales, float* out_rotations, float* out_opacities,
                                         hipStream_t s);
-hipError_t dgs_launch_duplicate(const DgsView& v, const DgsCarve& c, hipStream_t s);
-hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s);
+hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, hipStream_t s);
+hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s,
+                             const uint32_t* n_dev = nullptr);
 hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, uint32_t* total,
                            hipStream_t s);
 hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
-                           int begin_bit, int end_bit, uint32_t* tmp, int* result_in_alt, hipStream_t s);
+                           int begin_bit, int end_bit, uint32_t* tmp, int* result_in_alt, hipStream_t s,
+                           const uint32_t* n_dev = nullptr);
 hipError_t dgs_launch_duplicate_sorted(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* tt_sorted,
-                                       uint32_t* offs_sorted, uint32_t* scan_tmp, hipStream_t s);
+                                       uint32_t* offs_sorted, uint32_t* scan_tmp, uint32_t cap, hipStream_t s);
 hipError_t dgs_launch_tight_count(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* total_full,
                                   uint32_t* total_tight, hipStream_t s);
-hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const uint32_t* order, hipStream_t s);
+hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t cap,
+                                      hipStream_t s);
 hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,
                                     float* out_depth, hipStream_t s);
 hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const float* bg, const float* dL_dpix,

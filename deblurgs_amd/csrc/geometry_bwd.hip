@@ -55,8 +55,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // the dependent row loop is latency-hidden by sheer thread count (it was the bottleneck when it lived inside
 // the 180-VGPR geometry kernel).
 __global__ void __launch_bounds__(256)
-contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ offsets,
-                      float* __restrict__ contrib) {
+contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ status, const uint32_t* __restrict__ tiles_touched,
+                      const uint32_t* __restrict__ offsets, float* __restrict__ contrib) {
+  if (status[5] != 0u) return;  // capacity mode, truncated lists: the offsets point past the rows that were written
   // four lanes per (subframe, Gaussian): lane part p in {0,1,2} owns the p-th float4 of every row of the segment
   // (part 3 idles), so a quad reads each 48-byte row with one contiguous access and no cross-lane sum is needed
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -102,12 +103,14 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
                     const uint32_t* __restrict__ offsets, const DgsRow* __restrict__ rows,
                     const float* __restrict__ cov3Ds,
                     const float* __restrict__ pre_sigmoid, const uint32_t* __restrict__ tiles_touched,
-                    const float* __restrict__ contrib, float* __restrict__ dL_dmeans3D,
+                    const float* __restrict__ contrib, const uint32_t* __restrict__ status, float hinge_scale,
+                    float* __restrict__ dL_dmeans3D,
                     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dsh, float* __restrict__ dL_dsh_rest,
                     float* __restrict__ dL_dcolors,
                     float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales, float* __restrict__ dL_drots,
                     float* __restrict__ dL_dcov3D_out, float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float s_part[];  // [waves][K][NMAT]
+  if (status[5] != 0u) return;  // capacity mode, truncated lists (see contrib_reduce_kernel); the caller discards the step
   const int idx = blockIdx.x * GB_THREADS + threadIdx.x;
   const bool valid = idx < v.P;
   const int gi = valid ? idx : 0;
@@ -421,7 +424,14 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     dL_dmeans3D[3 * idx + 1] = a_mean[1];
     dL_dmeans3D[3 * idx + 2] = a_mean[2];
     // raw parameters: torch.clamp passes the gradient where 0 <= x <= 1
-    dL_dopacity[idx] = (v.raw_params && !(opacities_raw[idx] >= 0.0f && opacities_raw[idx] <= 1.0f)) ? 0.0f : a_op;
+    float g_op = (v.raw_params && !(opacities_raw[idx] >= 0.0f && opacities_raw[idx] <= 1.0f)) ? 0.0f : a_op;
+    if (v.raw_params && hinge_scale != 0.0f) {
+      // the opacity hinge of the training loss (utils/loss_utils.py:96-104: mean(x^2 [x <= 0] + (x - 1)^2 [x >= 1]),
+      // train.py:156-163) differentiated here: hinge_scale = lambda_hinge * upstream / numel
+      const float x = opacities_raw[idx];
+      g_op += hinge_scale * ((x <= 0.0f) ? 2.0f * x : ((x >= 1.0f) ? 2.0f * (x - 1.0f) : 0.0f));
+    }
+    dL_dopacity[idx] = g_op;
     dL_dcolors[3 * idx + 0] = a_col[0];
     dL_dcolors[3 * idx + 1] = a_col[1];
     dL_dcolors[3 * idx + 2] = a_col[2];
@@ -594,14 +604,15 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
   // (tt_sorted / offs_sorted only exist when the forward produced duplicates)
   if (io.num_rendered > 0)
     hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((4 * kp + 255) / 256)), dim3(256), 0, s, kp,
-                       v.tile_cull ? c.tt_tight : c.tt_sorted, v.tile_cull ? c.offs_tight : c.offs_sorted,
+                       c.num_rendered, v.tile_cull ? c.tt_tight : c.tt_sorted, v.tile_cull ? c.offs_tight : c.offs_sorted,
                        const_cast<float*>(contrib));
 #define DGS_GB_LAUNCH(MAXC)                                                                                          \
   hipLaunchKernelGGL(geometry_bwd_kernel<MAXC>, dim3(blocks), dim3(GB_THREADS), lds, s, v, p.means3D, p.shs,         \
                      p.shs_rest, p.opacities,                                                                        \
                      p.scales, p.rotations, p.cov3D_precomp, p.viewmatrix, p.projmatrix, p.campos, c.point_offsets, c.rows,       \
                      c.cov3D,  \
-                     c.pre_sigmoid, c.tiles_touched, contrib, io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh,             \
+                     c.pre_sigmoid, c.tiles_touched, contrib, c.num_rendered, io.opacity_hinge_scale, io.dL_dmeans3D,  \
+                     io.dL_dmeans2D, io.dL_dsh,                                                                       \
                      io.dL_dsh_rest,                                                                                 \
                      io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations, io.dL_dcov3D, partials)
   if (ncoef <= 1)

@@ -23,6 +23,7 @@ struct AdamArgs {
   uint8_t vec4[DGS_ADAM_MAX_GROUPS];         // all four pointers 16-byte aligned: float4 accesses
   int n;
   float beta2, w1, w2, eps, clip;  // w1 = 1 - beta1, w2 = 1 - beta2
+  const uint32_t* skip;            // optional device word: non-zero = leave everything untouched
 };
 
 constexpr int ADAM_THREADS = 256;
@@ -38,6 +39,7 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(AdamArgs a) {
+  if (a.skip != nullptr && a.skip[0] != 0u) return;   // the gradients come from a truncated (overflowed) forward
   int gi = 0;
 #pragma unroll
   for (int i = 0; i < DGS_ADAM_MAX_GROUPS - 1; i++)
@@ -187,7 +189,7 @@ extern int dgs_fail_hip(hipError_t e, const char* where);
 extern "C" {
 
 int dgs_adam_step(const DgsAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps,
-                  double clip_value, dgs_stream_t stream) {
+                  double clip_value, const uint32_t* skip_flag, dgs_stream_t stream) {
   if (n_groups < 0 || n_groups > DGS_ADAM_MAX_GROUPS || (n_groups > 0 && groups == nullptr))
     return dgs_fail_arg("adam_step: 0..DGS_ADAM_MAX_GROUPS groups");
   AdamArgs a;
@@ -225,6 +227,7 @@ int dgs_adam_step(const DgsAdamGroup* groups, int32_t n_groups, double beta1, do
   a.w2 = (float)(1.0 - beta2);
   a.eps = (float)eps;
   a.clip = (float)clip_value;
+  a.skip = skip_flag;
   hipLaunchKernelGGL(adam_kernel, dim3((uint32_t)blocks), dim3(ADAM_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? DGS_OK : dgs_fail_hip(e, "adam_step");

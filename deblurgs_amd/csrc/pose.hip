@@ -222,9 +222,72 @@ __global__ void pose_ctrl_grad_kernel(int C, int K, const double* __restrict__ c
     dL_dctrl_rot[3 * c + d - 3] = (float)acc;
 }
 
+// Subframe times of one view from its alignment parameters (scene/motion.py:209-219):
+//   nu = sort(clamp(cat(0, sigmoid(raw) [+ u / f - 1 / (2 f)], 1), 0, 1))
+// raw is the view's row of CameraMotionModule._nu (f - 2 values), u optional uniform samples (curve_random_sample).
+// One block; thread i owns candidate i (0 and f-1 are the fixed end points), its rank is the number of candidates that
+// sort before it (value, then index: a stable ascending sort), nu[rank] = value, src[rank] = i.
+__global__ void alignment_fwd_kernel(int f, int n_sub, const float* __restrict__ raw, const float* __restrict__ u,
+                                     float* __restrict__ nu, int32_t* __restrict__ src) {
+  __shared__ float vals[DGS_MAX_K];
+  const int i = threadIdx.x;
+  if (i < f) {
+    float v = 0.0f;
+    if (i == f - 1 && f > 1) v = 1.0f;
+    if (i > 0 && i < f - 1) {
+      v = 1.0f / (1.0f + expf(-raw[i - 1]));
+      if (u != nullptr) v = v + u[i - 1] / (float)n_sub - (1.0f / (float)(2 * n_sub));
+    }
+    vals[i] = fminf(1.0f, fmaxf(0.0f, v));
+  }
+  __syncthreads();
+  if (i < f) {
+    const float v = vals[i];
+    int rank = 0;
+    for (int j = 0; j < f; j++) rank += (vals[j] < v || (vals[j] == v && j < i)) ? 1 : 0;
+    nu[rank] = v;
+    src[rank] = i;
+  }
+}
+
+// dL/draw[i-1] = dL/dnu[rank(i)] * [0 <= pre-clamp value <= 1] * sigmoid'(raw[i-1])   (torch: sort -> clamp -> cat ->
+// sigmoid backward); the end points have no parameter
+__global__ void alignment_bwd_kernel(int f, int n_sub, const float* __restrict__ raw, const float* __restrict__ u,
+                                     const int32_t* __restrict__ src, const float* __restrict__ dL_dnu,
+                                     float* __restrict__ dL_draw) {
+  const int r = threadIdx.x;
+  if (r >= f) return;
+  const int i = src[r];
+  if (i <= 0 || i >= f - 1) return;
+  const float sg = 1.0f / (1.0f + expf(-raw[i - 1]));
+  float v = sg;
+  if (u != nullptr) v = v + u[i - 1] / (float)n_sub - (1.0f / (float)(2 * n_sub));
+  const float pass = (v >= 0.0f && v <= 1.0f) ? 1.0f : 0.0f;
+  dL_draw[i - 1] = dL_dnu[r] * pass * (sg * (1.0f - sg));
+}
+
 }  // namespace
 
 extern "C" {
+
+int dgs_alignment_forward(const float* raw, const float* uniform, int32_t f, int32_t n_subframes, float* nu,
+                          int32_t* src, dgs_stream_t stream) {
+  if (f < 1 || f > DGS_MAX_K || n_subframes < 1 || (f > 2 && raw == nullptr) || nu == nullptr || src == nullptr)
+    return DGS_E_ARG;
+  hipLaunchKernelGGL(alignment_fwd_kernel, dim3(1), dim3(DGS_MAX_K), 0, reinterpret_cast<hipStream_t>(stream), f,
+                     n_subframes, raw, uniform, nu, src);
+  return hipGetLastError() == hipSuccess ? DGS_OK : DGS_E_HIP;
+}
+
+int dgs_alignment_backward(const float* raw, const float* uniform, int32_t f, int32_t n_subframes, const int32_t* src,
+                           const float* dL_dnu, float* dL_draw, dgs_stream_t stream) {
+  if (f < 1 || f > DGS_MAX_K || n_subframes < 1 || src == nullptr || dL_dnu == nullptr || (f > 2 && (raw == nullptr || dL_draw == nullptr)))
+    return DGS_E_ARG;
+  if (f <= 2) return DGS_OK;
+  hipLaunchKernelGGL(alignment_bwd_kernel, dim3(1), dim3(DGS_MAX_K), 0, reinterpret_cast<hipStream_t>(stream), f,
+                     n_subframes, raw, uniform, src, dL_dnu, dL_draw);
+  return hipGetLastError() == hipSuccess ? DGS_OK : DGS_E_HIP;
+}
 
 size_t dgs_pose_scratch_bytes(int32_t K) { return (size_t)K * (6 + MAX_ORDER + 1) * sizeof(double) + 256; }
 

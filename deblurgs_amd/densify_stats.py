@@ -14,7 +14,8 @@ from . import _lib
 
 
 @torch.no_grad()
-def add_densification_stats_subframes(viewspace_points, radii, max_radii2D, xyz_gradient_accum, denom, K_total=0):
+def add_densification_stats_subframes(viewspace_points, radii, max_radii2D, xyz_gradient_accum, denom, K_total=0,
+                                      skip_flag_ptr=None):
     """In-place update of max_radii2D [P], xyz_gradient_accum [P,1] and denom [P,1] (float32, device tensors).
     K_total: number of subframes of the whole view when `radii` holds only this rank's share of them."""
     grad = viewspace_points.grad if viewspace_points.grad is not None else viewspace_points
@@ -26,4 +27,5 @@ def add_densification_stats_subframes(viewspace_points, radii, max_radii2D, xyz_
     st = ctypes.c_void_p(torch.cuda.current_stream(grad.device).cuda_stream)
     _lib.check(_lib.lib().dgs_densify_stats(grad.data_ptr(), radii.contiguous().data_ptr(), K, int(K_total), P,
                                             max_radii2D.data_ptr(), xyz_gradient_accum.data_ptr(), denom.data_ptr(),
-                                            st), "dgs_densify_stats")
+                                            ctypes.c_void_p(skip_flag_ptr) if skip_flag_ptr else None, st),
+               "dgs_densify_stats")

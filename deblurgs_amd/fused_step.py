@@ -1,0 +1,253 @@
+"""The device work of one training iteration enqueued straight through the C ABI -- no torch autograd graph, no
+elementwise torch glue, no host synchronisation:
+
+    alignment (nu = sort(clamp(cat(0, sigmoid(_nu[view]), 1)))            dgs_alignment_forward
+    -> Bezier / se3_exp_map / K cameras                                   dgs_pose_forward
+    -> fused K-subframe rasterisation of the cloud's raw parameters       dgs_forward (capacity sized ahead) or the
+                                                                          two-phase dgs_forward_geometry / _render
+    -> blur image, L1 + temporal-smoothness values and dL/dsubframes      dgs_blur_loss_grad (one pass)
+    -> rasteriser backward (+ the opacity-hinge gradient)                 dgs_backward
+    -> camera gradients back to the control points and alignment          dgs_pose_backward, dgs_alignment_backward
+
+i.e. scene/motion.py:78-160 + train.py:143-165 of the reference for one blurry view.  The gradients are left in `.grad`
+of the cloud's and the motion module's parameters exactly where `loss.backward()` of the autograd path
+(CameraMotionModule.query + losses.blur_l1_smooth + losses.hinge_l2) leaves them -- the six per-Gaussian ones as views
+of one flat bucket -- so the optimiser step, the sharded all-reduce and the densification statistics that follow are
+unchanged.  tests/test_gpu_train.py checks the two paths against each other.
+
+Why: at DeblurGS's real scene sizes (1e4..1e5 Gaussians) the autograd path is host-bound -- ~45 small torch launches,
+autograd bookkeeping and one blocking read of num_rendered per step cost more than the kernels.  Here a step is ~12
+ctypes calls.
+
+Sizing ahead (`speculative=True`): the duplicate arrays of step t are sized from the duplicate counts observed in earlier
+steps (+25 %), which are read from pinned memory only once their copy has completed -- never blocking.  If a step's count
+exceeds its capacity the kernels set a device flag instead of writing out of bounds; the flag makes the optimiser step
+and the densification statistics of THAT step no-ops (FusedAdam.skip_flag_ptr), so a truncated gradient is never
+applied: the iteration is dropped like a skipped mini-batch, the capacity grows, `dropped` counts it.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from . import diff_gaussian_rasterization as dgr
+
+
+def _ptr(t, offset_elems=0):
+    return None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * offset_elems)
+
+
+class _Pending:
+    __slots__ = ("host", "event", "capacity", "speculative")
+
+
+class FusedStep:
+    def __init__(self, cloud, motion, lambda_hinge=0.0, speculative=True, tile_cull=None):
+        if motion.curve_type != "se3":
+            raise NotImplementedError("FusedStep covers curve_type='se3' (use CameraMotionModule.query otherwise)")
+        if not getattr(cloud, "fused_activations", False):
+            raise NotImplementedError("FusedStep needs a cloud with fused_activations")
+        self.cloud, self.motion = cloud, motion
+        self.lambda_hinge = float(lambda_hinge)
+        self.speculative = bool(speculative)
+        self.tile_cull = tile_cull
+        self.dropped = 0            # steps whose duplicate count exceeded the capacity (their update was skipped)
+        self._seen = []             # recent duplicate counts
+        self._pending = []          # forwards whose counts have not been read back yet
+        self._free_hosts = []
+        self._keep = None           # buffers of the last step (the skip flag lives in its geometry blob)
+        self.last_capacity = None
+
+    # ------------------------------------------------------------------------------------------ capacity policy
+    def _poll(self, block=False):
+        still = []
+        for pnd in self._pending:
+            if block:
+                pnd.event.synchronize()
+            if pnd.event.query():
+                R, hi, overflow = (int(x) & 0xFFFFFFFF for x in pnd.host[:3].tolist())
+                if hi != 0:
+                    raise RuntimeError("num_rendered exceeds 32 bits: render fewer subframes per call")
+                if pnd.speculative and overflow:
+                    self.dropped += 1
+                self._seen = (self._seen + [R])[-16:]
+                self._free_hosts.append(pnd.host)
+            else:
+                still.append(pnd)
+        self._pending = still
+
+    def _capacity(self):
+        if not self._seen:
+            return None
+        need = max(self._seen)
+        return need + need // 4 + 16384
+
+    def _host_words(self):
+        if self._free_hosts:
+            h = self._free_hosts.pop()
+            h.zero_()
+            return h
+        return torch.zeros(4, dtype=torch.int32).pin_memory()
+
+    # ------------------------------------------------------------------------------------------------- the step
+    @torch.no_grad()
+    def run(self, cam_idx, lambda_t, gt, background, subframe_indice="all", need_blur=False, uniform=None):
+        """gt: [3,H,W] ground truth of view cam_idx (already tone-mapped / noised by the caller); background: [3].
+        Returns a dict: 'losses' (device float32 [2]: L1(blur, gt), smoothness -- no host read), 'blur' ([3,H,W] if
+        need_blur), 'radii' [K,P] int32, 'viewspace_grad' [K,P,3], 'K', 'skip_flag_ptr' (int or None)."""
+        L = _lib.lib()
+        cloud, m = self.cloud, self.motion
+        dev = cloud._xyz.device
+        stream_obj = torch.cuda.current_stream(dev)
+        stream = ctypes.c_void_p(stream_obj.cuda_stream)
+        f32 = dict(dtype=torch.float32, device=dev)
+        f = m.n_subframes
+        cam = int(cam_idx)
+
+        # ---- alignment -> nu (all f candidates), then the requested subset
+        nu_raw = m._nu
+        nu_all = torch.empty(f, **f32)
+        src = torch.empty(f, dtype=torch.int32, device=dev)
+        nrow = nu_raw.shape[1] if nu_raw.ndim == 2 else 0
+        raw_ptr = _ptr(nu_raw, cam * nrow) if nrow > 0 else None
+        if uniform is None and m.curve_random_sample and nrow > 0:
+            uniform = torch.rand(nrow, **f32)
+        _lib.check(L.dgs_alignment_forward(raw_ptr, _ptr(uniform), f, f, _ptr(nu_all), _ptr(src), stream),
+                   "dgs_alignment_forward")
+        sel = None
+        if isinstance(subframe_indice, str) and subframe_indice == "all":
+            nu = nu_all
+        else:
+            if isinstance(subframe_indice, int):     # scene/motion.py:129-131 (1 selects index 0)
+                sel = torch.linspace(0, f - 1, subframe_indice, device=dev).long()
+            else:
+                sel = torch.as_tensor(subframe_indice, device=dev).long()
+            nu = nu_all[sel].contiguous()
+        K = nu.shape[0]
+
+        # ---- cameras
+        ct_all, cr_all = m._trans._control_points, m._rot._control_points
+        C = ct_all.shape[1] - 1
+        row = cam * (C + 1) * 3
+        proj = m.ref_cam.projection_matrix
+        view = torch.empty((K, 4, 4), **f32)
+        full = torch.empty((K, 4, 4), **f32)
+        campos = torch.empty((K, 3), **f32)
+        _lib.check(L.dgs_pose_forward(_ptr(ct_all, row), _ptr(cr_all, row), _ptr(nu), _ptr(proj), C, K, _ptr(view),
+                                      _ptr(full), _ptr(campos), stream), "dgs_pose_forward")
+
+        # ---- forward
+        P = cloud._xyz.shape[0]
+        H, W = int(m.ref_cam.image_height), int(m.ref_cam.image_width)
+        rest = cloud._features_rest if cloud._features_rest.shape[1] > 0 else None
+        Mr = 0 if rest is None else rest.shape[1]
+        color = torch.empty((K, 3, H, W), **f32)
+        depth = torch.empty((K, 1, H, W), **f32)
+        radii = torch.empty((K, P), dtype=torch.int32, device=dev)
+        geom = torch.empty(L.dgs_geom_state_bytes(P, K), dtype=torch.uint8, device=dev)
+        image = torch.empty(L.dgs_image_state_bytes(W, H, K), dtype=torch.uint8, device=dev)
+        bg = background.to(dev, torch.float32).contiguous()
+        cull = dgr.TILE_CULL if self.tile_cull is None else bool(self.tile_cull)
+        prob = _lib.DgsProblem()
+        prob.P, prob.D, prob.M, prob.W, prob.H, prob.K = P, int(cloud.active_sh_degree), 1 + Mr, W, H, K
+        prob.tanfovx, prob.tanfovy = math.tan(m.ref_cam.FoVx * 0.5), math.tan(m.ref_cam.FoVy * 0.5)
+        prob.scale_modifier, prob.z_near, prob.z_far = 1.0, float(cloud.z_near), float(cloud.z_far)
+        prob.use_sigmoid, prob.prefiltered, prob.debug = int(bool(cloud.use_sigmoid)), 0, 0
+        prob.tile_cull, prob.raw_params, prob.scale_lb = int(cull), 1, float(cloud.scale_lower_bound)
+        prob.means3D, prob.shs, prob.shs_rest = _ptr(cloud._xyz), _ptr(cloud._features_dc), _ptr(rest)
+        prob.opacities, prob.scales, prob.rotations = _ptr(cloud._opacity), _ptr(cloud._scaling), _ptr(cloud._rotation)
+        prob.viewmatrix, prob.projmatrix, prob.campos, prob.bg = _ptr(view), _ptr(full), _ptr(campos), _ptr(bg)
+        prob.geom_state, prob.geom_bytes = ctypes.c_void_p(geom.data_ptr()), geom.numel()
+        prob.image_state, prob.image_bytes = ctypes.c_void_p(image.data_ptr()), image.numel()
+        out = _lib.DgsForwardOut()
+        out.out_color, out.out_depth, out.radii = _ptr(color), _ptr(depth), ctypes.c_void_p(radii.data_ptr())
+        host = self._host_words()
+        out.num_rendered_host = ctypes.c_void_p(host.data_ptr())
+
+        self._poll()
+        cap = self._capacity() if self.speculative else None
+        pnd = _Pending()
+        pnd.host, pnd.speculative = host, cap is not None
+        if cap is not None:
+            binning = torch.empty(L.dgs_binning_state_bytes(cap, W, H, K), dtype=torch.uint8, device=dev)
+            prob.binning_state, prob.binning_bytes = ctypes.c_void_p(binning.data_ptr()), binning.numel()
+            _lib.check(L.dgs_forward(ctypes.byref(prob), ctypes.byref(out), cap, stream), "dgs_forward")
+            R = cap
+            skip_ptr = geom.data_ptr() + _lib.layout(P, W, H, K, 0).num_rendered + 20
+        else:   # exact two-phase forward: one blocking read of the count (also how the first capacity is learnt)
+            _lib.check(L.dgs_forward_geometry(ctypes.byref(prob), ctypes.byref(out), stream), "dgs_forward_geometry")
+            stream_obj.synchronize()
+            if int(host[1].item()) != 0:
+                raise RuntimeError("num_rendered exceeds 32 bits: render fewer subframes per call")
+            R = int(host[0].item()) & 0xFFFFFFFF
+            binning = torch.empty(L.dgs_binning_state_bytes(R, W, H, K), dtype=torch.uint8, device=dev)
+            prob.binning_state, prob.binning_bytes = ctypes.c_void_p(binning.data_ptr()), binning.numel()
+            _lib.check(L.dgs_forward_render(ctypes.byref(prob), ctypes.byref(out), R, stream), "dgs_forward_render")
+            skip_ptr = None
+        pnd.capacity = R
+        pnd.event = torch.cuda.Event()
+        pnd.event.record(stream_obj)
+        self._pending.append(pnd)
+        self.last_capacity = R
+
+        # ---- loss: blur, both values and dL/dsubframes in one pass (train.py:143-165 image terms)
+        gtc = gt.to(dev, torch.float32).contiguous()
+        blur = torch.empty((3, H, W), **f32)
+        dsub = torch.empty((K, 3, H, W), **f32)
+        losses = torch.empty(2, **f32)
+        _lib.check(L.dgs_blur_loss_grad(_ptr(color), _ptr(gtc), K, 3, H * W, float(lambda_t), None, _ptr(blur),
+                                        _ptr(dsub), _ptr(losses), stream), "dgs_blur_loss_grad")
+
+        # ---- backward: one flat gradient bucket in optimiser-group order (as _RasterizeCloudK.backward)
+        sizes = [3 * P, 3 * P, 3 * Mr * P, P, 3 * P, 4 * P]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + (n + 3) // 4 * 4)
+        flat = torch.empty(offs[-1], **f32)
+        seg = lambda i, shape: flat[offs[i]:offs[i] + sizes[i]].view(shape)
+        g_xyz, g_dc, g_op, g_sc, g_rot = (seg(0, (P, 3)), seg(1, cloud._features_dc.shape), seg(3, cloud._opacity.shape),
+                                          seg(4, (P, 3)), seg(5, (P, 4)))
+        g_rest = seg(2, cloud._features_rest.shape)
+        g_means2D = torch.empty((K, P, 3), **f32)
+        g_colors = torch.empty((P, 3), **f32)
+        g_cov3D = torch.empty((P, 6), **f32)
+        g_view, g_proj = torch.empty((K, 4, 4), **f32), torch.empty((K, 4, 4), **f32)
+        scratch = torch.empty(L.dgs_backward_scratch_bytes(R, P, K), dtype=torch.uint8, device=dev)
+        io = _lib.DgsBackwardIO()
+        io.num_rendered = R
+        io.radii, io.dL_dout_color, io.dL_dout_depth = ctypes.c_void_p(radii.data_ptr()), _ptr(dsub), None
+        io.scratch, io.scratch_bytes = ctypes.c_void_p(scratch.data_ptr()), scratch.numel()
+        io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh = _ptr(g_xyz), _ptr(g_means2D), _ptr(g_dc)
+        io.dL_dsh_rest = _ptr(g_rest) if Mr > 0 else None
+        io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations = _ptr(g_colors), _ptr(g_op), _ptr(g_sc), _ptr(g_rot)
+        io.dL_dcov3D, io.dL_dviewmatrix, io.dL_dprojmatrix = _ptr(g_cov3D), _ptr(g_view), _ptr(g_proj)
+        io.opacity_hinge_scale = self.lambda_hinge / max(P, 1)
+        _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward")
+        if P == 0:
+            flat.zero_()
+            g_means2D.zero_()
+        cloud._xyz.grad, cloud._features_dc.grad, cloud._features_rest.grad = g_xyz, g_dc, g_rest
+        cloud._opacity.grad, cloud._scaling.grad, cloud._rotation.grad = g_op, g_sc, g_rot
+
+        # ---- cameras -> control points and alignment (only while the trajectory is being optimised)
+        if m.is_optimizing():
+            d_ct_all, d_cr_all = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
+            d_nu = torch.empty(K, **f32)
+            pscratch = torch.empty(L.dgs_pose_scratch_bytes(K), dtype=torch.uint8, device=dev)
+            _lib.check(L.dgs_pose_backward(_ptr(ct_all, row), _ptr(cr_all, row), _ptr(nu), _ptr(proj), C, K, _ptr(g_view),
+                                           _ptr(g_proj), ctypes.c_void_p(pscratch.data_ptr()), _ptr(d_ct_all, row),
+                                           _ptr(d_cr_all, row), _ptr(d_nu), stream), "dgs_pose_backward")
+            m._trans._control_points.grad, m._rot._control_points.grad = d_ct_all, d_cr_all
+            if nrow > 0:
+                d_raw_all = torch.zeros_like(nu_raw)
+                if sel is not None:                      # gradients of the selected subframes back to all f slots
+                    d_full = torch.zeros(f, **f32)
+                    d_full.index_add_(0, sel, d_nu)
+                    d_nu = d_full
+                _lib.check(L.dgs_alignment_backward(raw_ptr, _ptr(uniform), f, f, _ptr(src), _ptr(d_nu),
+                                                    _ptr(d_raw_all, cam * nrow), stream), "dgs_alignment_backward")
+                m._nu.grad = d_raw_all
+        self._keep = (geom, image, binning, scratch, color, depth, dsub, view, full, campos, nu, gtc, bg, flat)
+        return {"losses": losses, "blur": blur if need_blur else None, "radii": radii, "viewspace_grad": g_means2D,
+                "K": K, "subframes": color, "depths": depth, "skip_flag_ptr": skip_ptr}

@@ -32,6 +32,9 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clip_value=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, **self._ADAM_DEFAULTS))
         self.clip_value = float(clip_value)   # > 0: fused torch.nn.utils.clip_grad_value_ (train.py:204-205)
+        # optional device pointer (int) of a flag word: when non-zero at kernel time the step leaves everything
+        # untouched (include/dgs_hip.h, dgs_forward: gradients of a forward whose duplicate capacity overflowed)
+        self.skip_flag_ptr = None
 
     def _check_group(self, group):
         for key, default in self._ADAM_DEFAULTS.items():
@@ -75,8 +78,9 @@ class FusedAdam(torch.optim.Optimizer):
             for i in range(0, len(gs), _lib.ADAM_MAX_GROUPS):
                 chunk = gs[i:i + _lib.ADAM_MAX_GROUPS]
                 arr = (_lib.DgsAdamGroup * len(chunk))(*chunk)
-                _lib.check(L.dgs_adam_step(arr, len(chunk), beta1, beta2, eps, self.clip_value, _stream(device)),
-                           "dgs_adam_step")
+                _lib.check(L.dgs_adam_step(arr, len(chunk), beta1, beta2, eps, self.clip_value,
+                                           ctypes.c_void_p(self.skip_flag_ptr) if self.skip_flag_ptr else None,
+                                           _stream(device)), "dgs_adam_step")
         return loss
 
 

@@ -28,7 +28,7 @@ def default_optimization_params(**overrides):
 
 class TrainingLoop:
     def __init__(self, gaussians, cam_motion_module, opt, cameras_extent, white_background=False, spatial_lr_scale=None,
-                 distributed=False, tone_mapping=None):
+                 distributed=False, tone_mapping=None, fused_step="auto", speculative=True, log_losses=True):
         """distributed = "views" (or True): every rank steps on its own view (the caller passes each rank its cam_idx);
         the per-Gaussian AND trajectory gradients are averaged over ranks (one flat all-reduce + one few-KB one) before
         the Adam step and the densification statistics are combined before every densify_and_prune, so the replicas
@@ -40,6 +40,11 @@ class TrainingLoop:
         tone_mapping: the scene's ToneMapping (losses.ToneMapping("gamma"), arguments/__init__.py:71); its inverse is
         applied to the ground truth as train.py:141-145 does every iteration (here once per image, cached).  None =
         the ground-truth images are already linear.
+        fused_step: "auto" (default) enqueues the iteration's device work through deblurgs_amd.fused_step.FusedStep (no
+        autograd graph, no host synchronisation; `speculative` sizes the duplicate arrays ahead, see that module) whenever
+        the configuration allows it (se3 curves, fused activations, no depth-TV term, not "subframes" sharding), and falls
+        back to the autograd path (CameraMotionModule.query + losses) otherwise; False forces the autograd path.
+        log_losses=False skips forming the scalar "loss" entry of step()'s result (two tiny launches).
         Not carried over from train.py: logging / visualiser / checkpoint-saving calls and `args.flag`."""
         self.gaussians, self.motion, self.opt, self.extent = gaussians, cam_motion_module, opt, cameras_extent
         self.mode = {True: "views", False: None, None: None}.get(distributed, distributed)
@@ -65,6 +70,17 @@ class TrainingLoop:
                                             step_warmup=getattr(opt, "curve_alignment_start", 30_000),
                                             step_final=opt.iterations)                  # train.py:90-94
         cam_motion_module.alternate_optimization()      # train.py:102, unconditional: curve gradients off at the start
+        self.log_losses = log_losses
+        self._fused = None
+        if fused_step and self.mode != "subframes" and opt.lambda_depth_tv <= 0.0:
+            try:
+                from .fused_step import FusedStep
+                if gaussians._xyz.device.type == "cuda":
+                    self._fused = FusedStep(gaussians, cam_motion_module, lambda_hinge=max(opt.lambda_hinge, 0.0),
+                                            speculative=speculative)
+            except NotImplementedError:
+                if fused_step is True:
+                    raise
 
     def _ground_truth(self, cam_idx, gt, iteration):
         """train.py:141-145: gt = tone_mapping.inverse()(gt) + randn * noise(iteration)."""
@@ -92,6 +108,8 @@ class TrainingLoop:
         # The opacity hinge is built BEFORE the render: autograd then runs its backward AFTER the rasteriser's, so the
         # rasteriser's gradient (a view of the flat gradient buffer) becomes `_opacity.grad` and the hinge term is added
         # into it in place -- the six gradients stay one contiguous bucket for the all-reduce.
+        if self._fused is not None:
+            return self._step_fused(iteration, cam_idx, subframe_indice, lambda_t_smooth, densification_threshold)
         L_hinge = losses.hinge_l2(g._opacity) if opt.lambda_hinge > 0.0 else None
         if self.mode == "subframes":
             return self._step_subframe_sharded(iteration, cam_idx, subframe_indice, lambda_t_smooth, L_hinge,
@@ -114,6 +132,34 @@ class TrainingLoop:
                                           extra=[p for p in self.motion.parameters() if p.requires_grad])
         self._tail(iteration, r, densification_threshold)
         return {"loss": loss.detach(), "l1": Ll1, "smooth": L_t, "hinge": L_hinge, "num_points": g._xyz.shape[0]}
+
+    def _step_fused(self, iteration, cam_idx, subframe_indice, lambda_t_smooth, densification_threshold):
+        """The same iteration with its device work enqueued by FusedStep (module docstring there)."""
+        g = self.gaussians
+        dev = g._xyz.device
+        gt = self._ground_truth(cam_idx, self.motion.get_gt_image(cam_idx), iteration)
+        bg = torch.rand(3, device=dev)                                   # scene/motion.py:112-113
+        fr = self._fused.run(cam_idx, lambda_t_smooth, gt, bg, subframe_indice)
+        skip = fr["skip_flag_ptr"]
+        if self.distributed:
+            from . import sharding
+            import torch.distributed as dist
+            if skip is not None:
+                # a rank whose duplicate capacity overflowed holds a meaningless gradient: every rank must drop the step
+                off = skip - self._fused._keep[0].data_ptr()
+                flag = self._fused._keep[0][off:off + 4].view(torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            sharding.flat_allreduce_grads(g.hot_parameters(), average=True,
+                                          extra=[p for p in self.motion.parameters() if p.requires_grad])
+        g.optimizer.skip_flag_ptr = skip
+        r = {"viewspace_points_all": fr["viewspace_grad"], "radii_all": fr["radii"], "K_total": fr["K"],
+             "skip_flag_ptr": skip}
+        self._tail(iteration, r, densification_threshold)
+        out = {"l1": fr["losses"][0], "smooth": fr["losses"][1], "hinge": None, "num_points": g._xyz.shape[0],
+               "loss": None}
+        if self.log_losses:
+            out["loss"] = fr["losses"][0] + lambda_t_smooth * fr["losses"][1]    # (without the hinge term's value)
+        return out
 
     def _step_subframe_sharded(self, iteration, cam_idx, subframe_indice, lambda_t_smooth, L_hinge,
                                densification_threshold):
@@ -148,7 +194,8 @@ class TrainingLoop:
                     self._stat_prev = (g.xyz_gradient_accum.clone(), g.denom.clone())
                 if r["radii_all"].shape[0] > 0:
                     add_densification_stats_subframes(r["viewspace_points_all"], r["radii_all"], g.max_radii2D,
-                                                      g.xyz_gradient_accum, g.denom, K_total=r["K_total"])
+                                                      g.xyz_gradient_accum, g.denom, K_total=r["K_total"],
+                                                      skip_flag_ptr=r.get("skip_flag_ptr"))
                 if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
                     if self.distributed:
                         sharding.allreduce_densification_stats(g, self._stat_prev)
@@ -158,10 +205,14 @@ class TrainingLoop:
                         gen = torch.Generator(device=g._xyz.device)
                         gen.manual_seed(1_000_003 * int(iteration) + 17)
                     g.densify_and_prune(densification_threshold, self.extent, generator=gen)
+                    if self._fused is not None:      # the cloud changed size: learn the duplicate count afresh
+                        self._fused._seen = []
                 if iteration % opt.opacity_reset_interval == 0 or (self.white_background and
                                                                    iteration == opt.densify_from_iter):
                     g.reset_opacity()
             if iteration < opt.iterations:
                 g.optimizer.step()                      # clip_grad_value_ is fused into the step (FusedAdam.clip_value)
                 g.optimizer.zero_grad(set_to_none=True)
+            if hasattr(g.optimizer, "skip_flag_ptr"):
+                g.optimizer.skip_flag_ptr = None
 

@@ -114,6 +114,10 @@ typedef struct DgsBackwardIO {
   float* dL_dcov3D;    /* [P,6] */
   float* dL_dviewmatrix; /* [K,4,4] */
   float* dL_dprojmatrix; /* [K,4,4] */
+  /* raw_params = 1 only: adds opacity_hinge_scale * d/dx hinge_l2 terms to dL_dopacity, i.e. the gradient of the
+   * training loss's lambda_hinge * hinge_l2(_opacity) (utils/loss_utils.py:96-104, train.py:156-163) with
+   * opacity_hinge_scale = lambda_hinge / P; 0 = off.  Saves the caller a dozen elementwise launches per step. */
+  float opacity_hinge_scale;
 } DgsBackwardIO;
 
 /* Byte offsets of the sub-arrays inside the three blobs (for debuggers and the parity tests).
@@ -171,6 +175,16 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
 /* Replaces the rest of Rasterizer::forward (rasterizer_impl.cu:289-345): duplicateWithKeys, the stable
  * radix sort, identifyTileRanges and the per-tile alpha compositing, for all K subframes. */
 int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t num_rendered, dgs_stream_t stream);
+/* Single-call forward for callers that size the duplicate arrays AHEAD of the count (from the previous step's count,
+ * say): dgs_forward_geometry + dgs_forward_render without the host read in between.  binning_state must hold
+ * dgs_binning_state_bytes(capacity, ...).  num_rendered_host (pinned, >= 4 words) receives asynchronously
+ * [0] the true duplicate count, [1] its u32-overflow word, [2] overflow flag (count > capacity or [1] != 0: the lists
+ * were NOT built, the outputs are meaningless and dgs_backward on this state returns garbage-but-in-bounds results;
+ * re-run with a larger capacity), [3] the count the lists were built with.  The same flag is the device word at
+ * geom_state + DgsLayout.num_rendered + 20 bytes, which dgs_adam_step / dgs_densify_stats accept as `skip_flag` so that
+ * a whole training step can be enqueued without any host synchronisation and still never apply a truncated gradient.
+ * dgs_backward takes num_rendered = capacity for such a state. */
+int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream);
 /* Replaces Rasterizer::backward (rasterizer_impl.cu:350-463). */
 int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream);
 /* Replaces Rasterizer::markVisible (rasterizer_impl.cu:141-153); present is bool[P] as bytes. */
@@ -207,7 +221,8 @@ int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32
  * K_total = len(render_pkgs) of the whole view (train.py:192): K itself (pass 0) unless the view's subframes are
  * split over ranks and this call covers only a rank's share. */
 int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t K_total, int32_t P,
-                      float* max_radii2D, float* xyz_gradient_accum, float* denom, dgs_stream_t stream);
+                      float* max_radii2D, float* xyz_gradient_accum, float* denom, const uint32_t* skip_flag,
+                      dgs_stream_t stream);
 
 /* ---- optimiser step and densification of the Gaussian cloud ----------------------------------
  * Multi-tensor Adam: all parameter groups in one launch.  Replaces torch.optim.Adam(l, lr=0.0, eps=1e-15).step()
@@ -215,7 +230,8 @@ int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t
  * (torch/optim/adam.py, single-tensor path: lerp, mul+addcmul, sqrt/div/add, addcdiv; bias corrections in double).
  * `step` is the 1-based count of THIS update (state["step"] after its increment).  A group whose grad is NULL is
  * skipped, like a parameter whose .grad is None.  clip_value > 0 clamps the gradient first
- * (torch.nn.utils.clip_grad_value_, train.py:204-205); the gradient buffer itself is left untouched. */
+ * (torch.nn.utils.clip_grad_value_, train.py:204-205); the gradient buffer itself is left untouched.
+ * skip_flag (optional device word, see dgs_forward): non-zero = the launch leaves parameters and moments untouched. */
 #define DGS_ADAM_MAX_GROUPS 16
 typedef struct DgsAdamGroup {
   float* param;
@@ -227,7 +243,7 @@ typedef struct DgsAdamGroup {
   int32_t step;
 } DgsAdamGroup;
 int dgs_adam_step(const DgsAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps,
-                  double clip_value, dgs_stream_t stream);
+                  double clip_value, const uint32_t* skip_flag, dgs_stream_t stream);
 
 /* densify_and_prune (scene/gaussian_model.py:436-448 = densify_and_clone :419-434, densify_and_split :389-417,
  * prune_points :336-349 with the optimiser-state surgery of :315-334 / :359-387) as plan + apply.
@@ -272,6 +288,15 @@ int dgs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* 
  * utils/pytorch3d_functions.py:373-457, scene/motion.py:248-294, scene/cameras.py:63-74 -- as one kernel, and its
  * backward from dL/d{world_view, full_proj} to the control points and nu.  ctrl_* are [C+1,3] (one curve),
  * proj is the transposed projection matrix [4,4] (row-vector convention), outputs are [K,4,4], [K,4,4], [K,3]. */
+/* Subframe times of one view from its alignment parameters (scene/motion.py:209-219):
+ * nu = sort(clamp(cat(0, sigmoid(raw) [+ uniform / n_subframes - 1 / (2 n_subframes)], 1), 0, 1)), f values from the
+ * f - 2 raw ones (uniform: optional [f-2] samples of U(0,1), the reference's curve_random_sample); src[r] = index of
+ * the candidate that landed at sorted position r (stable ascending sort).  Backward: dL/draw from dL/dnu (zero where
+ * the clamp was active, end points carry no parameter).  f <= DGS_MAX_K. */
+int dgs_alignment_forward(const float* raw, const float* uniform, int32_t f, int32_t n_subframes, float* nu,
+                          int32_t* src, dgs_stream_t stream);
+int dgs_alignment_backward(const float* raw, const float* uniform, int32_t f, int32_t n_subframes, const int32_t* src,
+                           const float* dL_dnu, float* dL_draw, dgs_stream_t stream);
 size_t dgs_pose_scratch_bytes(int32_t K);
 int dgs_pose_forward(const float* ctrl_trans, const float* ctrl_rot, const float* nu, const float* proj, int32_t C,
                      int32_t K, float* view, float* full, float* campos, dgs_stream_t stream);

@@ -330,20 +330,43 @@ class OracleRun:
         return out
 
 
+CHAIN_KEYS = {"dL_dmeans3D", "xyz", "dL_dscales", "scaling", "dL_drotations", "rotation", "dL_dcov3D_precomp",
+              "dL_dviewmatrix"}
+HARD_CAP = 5e-3        # no noise argument lifts a bar above this
+
+
 def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, mult=NOISE_MULT, floor=ROW_FLOOR, report=None, row_tol=ROW_TOL):
-    """hip[key] against ora["double"][key] with the bar max(tol, mult x noise), noise = the same error metric evaluated
-    on ora["f32"] (the oracle's own fp32-accumulation result).  Per-Gaussian tensors: per column AND per row
-    (grad_errors); pose matrices: per [4,4] matrix relative to its largest entry."""
+    """hip[key] against ora["double"][key].  Per-Gaussian tensors are measured per column AND per row (grad_errors),
+    pose matrices per [4,4] matrix relative to its largest entry.  Bars:
+
+      * the direct outputs of the compositing backward and what is linear in them (dL_dmeans2D, opacity, SH / colours,
+        dL_dprojmatrix): max(tol, mult x noise), noise = the same metric for ora["f32"], the oracle's own result with
+        fp32 accumulation;
+      * the outputs behind the covariance chain (conic -> cov2D -> cov3D -> scale / rotation, the cov part of the mean
+        gradient, the view matrix: CHAIN_KEYS), whose error is an amplified INPUT error: the oracle pair measures the
+        amplification (noise_out for its input noise), and this implementation's input deviation is measured directly on
+        dL_dmeans2D (v_exp_f32 / v_rcp_f32 / FMA contraction put it at a few 1e-6, ~10x the pure accumulation noise,
+        and it is itself held to `tol`), so the bar is max(tol, mult x noise x max(1, dev_in / noise_in)).
+    Never above HARD_CAP."""
+    amp = 1.0
+    if "dL_dmeans2D" in keys:
+        b, n = ora["double"]["dL_dmeans2D"], ora["f32"]["dL_dmeans2D"]
+        a = np.asarray(hip["dL_dmeans2D"], np.float64).reshape(b.shape)
+        rows = a.shape[0] * a.shape[1]
+        dev_in = grad_errors(a[..., :2], b[..., :2], rows=rows, floor=floor)["col"]
+        noise_in = grad_errors(n[..., :2], b[..., :2], rows=rows, floor=floor)["col"]
+        amp = max(1.0, dev_in / max(noise_in, 1e-12))
     for key in keys:
         b, n = ora["double"][key], ora["f32"][key]
         a = np.asarray(hip[key], np.float64).reshape(b.shape)
         assert np.isfinite(a).all(), key
+        m_eff = mult * (amp if key in CHAIN_KEYS else 1.0)
         if key in ("dL_dviewmatrix", "dL_dprojmatrix"):
             for k in range(b.shape[0]):
                 e, en = relerr(a[k], b[k]), relerr(n[k], b[k])
                 if report is not None:
                     report.append((key, k, e, en))
-                assert e <= max(tol, mult * en), f"{key}[{k}]: {e:.2e} (noise {en:.2e})"
+                assert e <= min(HARD_CAP, max(tol, m_eff * en)), f"{key}[{k}]: {e:.2e} (noise {en:.2e}, amp {amp:.1f})"
             continue
         rows = a.shape[0]
         if key == "dL_dmeans2D":
@@ -353,7 +376,8 @@ def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, mult=NOISE_MULT, floor=ROW_
         if report is not None:
             report.append((key, e, en))
         for m, t in (("col", tol), ("row", row_tol)):
-            assert e[m] <= max(t, mult * en[m]), f"{key} {m}: {e[m]:.2e} (noise {en[m]:.2e})"
+            cap = HARD_CAP if m == "col" else 10 * HARD_CAP
+            assert e[m] <= min(cap, max(t, m_eff * en[m])), f"{key} {m}: {e[m]:.2e} (noise {en[m]:.2e}, amp {amp:.1f})"
 
 
 # ------------------------------------------------------------------------- the product path exactly as bench.py runs it

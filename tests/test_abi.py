@@ -42,7 +42,7 @@ def test_struct_sizes_match_the_header_layout():
     # 6 ints + 5 floats + 5 ints + 1 float = 68 bytes (+4 padding), then 12 pointers, then 3 x (pointer + size_t)
     assert ctypes.sizeof(_lib.DgsProblem) == 72 + 12 * 8 + 3 * 16
     assert ctypes.sizeof(_lib.DgsForwardOut) == 32
-    assert ctypes.sizeof(_lib.DgsBackwardIO) == 8 + 8 * 3 + 16 + 11 * 8
+    assert ctypes.sizeof(_lib.DgsBackwardIO) == 8 + 8 * 3 + 16 + 11 * 8 + 8    # + opacity_hinge_scale (padded)
     assert ctypes.sizeof(_lib.DgsLayout) == 27 * 8 + 8
 
 
@@ -119,12 +119,12 @@ def test_argument_checks_of_the_training_side_entry_points_need_no_gpu():
     from deblurgs_amd import _lib
     L = _lib.lib()
     g = (_lib.DgsAdamGroup * 1)(_lib.DgsAdamGroup(None, 16, None, None, 8, 1e-3, 1))
-    assert L.dgs_adam_step(g, _lib.ADAM_MAX_GROUPS + 1, 0.9, 0.999, 1e-15, 0.0, None) != 0
+    assert L.dgs_adam_step(g, _lib.ADAM_MAX_GROUPS + 1, 0.9, 0.999, 1e-15, 0.0, None, None) != 0
     assert b"groups" in L.dgs_last_error()
-    assert L.dgs_adam_step(g, 1, 0.9, 0.999, 1e-15, 0.0, None) != 0          # grad given but null state pointers
+    assert L.dgs_adam_step(g, 1, 0.9, 0.999, 1e-15, 0.0, None, None) != 0          # grad given but null state pointers
     g[0].grad = None
-    assert L.dgs_adam_step(g, 1, 0.9, 0.999, 1e-15, 0.0, None) == 0          # no gradient: the group is skipped
-    assert L.dgs_adam_step(None, 0, 0.9, 0.999, 1e-15, 0.0, None) == 0
+    assert L.dgs_adam_step(g, 1, 0.9, 0.999, 1e-15, 0.0, None, None) == 0          # no gradient: the group is skipped
+    assert L.dgs_adam_step(None, 0, 0.9, 0.999, 1e-15, 0.0, None, None) == 0
     assert L.dgs_knn_mean_dist2(-1, None, None, None, None) != 0
     assert L.dgs_knn_mean_dist2(0, None, None, None, None) == 0
     assert L.dgs_knn_tmp_bytes(1000) > 1000 * 40

@@ -321,6 +321,163 @@ def test_fused_activations_equal_the_getter_path(gpu, deg, scale_lb):
         assert np.abs(a[key] - b[key]).max() <= 2e-5 * np.abs(a[key]).max(), key
 
 
+# ------------------------------------------------------------------------------------------- fused training step
+def _fused_fixture(seed=3, K=5, P=3000):
+    import torch
+    from helpers import synthetic
+    from deblurgs_amd.cloud import GaussianCloud
+    from deblurgs_amd.motion import CameraMotionModule, RefCamera
+    torch.manual_seed(seed)
+    sc = synthetic.make_scene(P, 144, 96, K=K, seed=seed, sigma_px=2.5)
+    cloud = GaussianCloud.from_scene(sc, "cuda")
+    with torch.no_grad():
+        cloud._opacity[::9] = 1.15          # outside [0, 1]: clamped in the render, pulled back by the hinge
+        cloud._opacity[4::13] = -0.05
+    ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device="cuda")
+    gt = torch.rand(3, 3, sc["H"], sc["W"], device="cuda")
+    m = CameraMotionModule(ref, gt, curve_order=4, num_subframes=K, init_se3=torch.randn(3, 6) * 0.01, device="cuda")
+    with torch.no_grad():
+        m._trans._control_points.add_(torch.randn_like(m._trans._control_points) * 0.02)
+        m._rot._control_points.add_(torch.randn_like(m._rot._control_points) * 0.004)
+        m._nu.add_(torch.randn_like(m._nu) * 0.7)
+    m.link_gaussian(cloud)
+    return sc, cloud, m
+
+
+@pytest.mark.parametrize("subframes", ["all", 3, 1])
+def test_fused_step_equals_autograd_path(gpu, subframes):
+    """deblurgs_amd.fused_step.FusedStep (the iteration's device work through the C ABI, no autograd) against the autograd
+    path it replaces -- CameraMotionModule.query + losses.blur_l1_smooth + lambda_hinge * hinge_l2, loss.backward():
+    same subframes bit for bit, same loss values, the same gradients on the cloud (rasteriser part bit-identical, the
+    hinge term within an ulp), the control points and the alignment parameters."""
+    import torch
+    from deblurgs_amd import losses
+    from deblurgs_amd.fused_step import FusedStep
+    sc, cloud, m = _fused_fixture()
+    lam_t, lam_h, cam = 2e-3, 0.1, 1
+    bg = torch.tensor([0.2, 0.5, 0.1], device="cuda")
+    params = list(cloud.hot_parameters()) + list(m.parameters())
+    for p in params:
+        p.grad = None
+    hinge = losses.hinge_l2(cloud._opacity)
+    out = m.query(cam, subframes, background=bg, compute_blurred=False)
+    total, blur, lv = losses.blur_l1_smooth(out["subframes"], out["gt"], lam_t)
+    (total + lam_h * hinge).backward()
+    ref = [None if p.grad is None else p.grad.detach().clone() for p in params]
+    ref_vs = out["viewspace_points_all"].grad.detach().clone()
+    for p in params:
+        p.grad = None
+    fs = FusedStep(cloud, m, lambda_hinge=lam_h, speculative=False)
+    fr = fs.run(cam, lam_t, m.get_gt_image(cam), bg, subframes, need_blur=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fr["subframes"], out["subframes"]) and torch.equal(fr["radii"], out["radii_all"])
+    assert torch.equal(fr["blur"], blur) and torch.equal(fr["viewspace_grad"], ref_vs)
+    assert abs(float(fr["losses"][0]) - float(lv[0])) <= 1e-7 and abs(float(fr["losses"][1]) - float(lv[1])) <= 1e-7
+    names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "rot_ctrl", "trans_ctrl", "nu"]
+    for n, p, r in zip(names, params, ref):
+        assert (p.grad is None) == (r is None), n
+        if r is None or r.numel() == 0:
+            continue
+        if n in ("xyz", "f_dc", "f_rest", "scaling", "rotation"):
+            assert torch.equal(p.grad, r), n
+        else:
+            tol = 2e-6 * float(r.abs().max()) + 1e-12
+            assert float((p.grad - r).abs().max()) <= tol, (n, float((p.grad - r).abs().max()), float(r.abs().max()))
+    assert float(cloud._opacity.grad[::9].abs().min()) > 0      # the hinge reached the clamped opacities
+    from deblurgs_amd.sharding import _shared_flat
+    assert _shared_flat([p.grad for p in cloud.hot_parameters()]) is not None
+
+
+def test_fused_step_speculative_capacity_and_overflow(gpu):
+    """Sizing the duplicate arrays ahead: the first call learns the count with the exact two-phase forward, later calls
+    run without any host synchronisation and give bit-identical results; a count above the capacity sets the device flag
+    that turns that step's optimiser update and densification statistics into no-ops (never a truncated gradient)."""
+    import torch
+    from deblurgs_amd.densify_stats import add_densification_stats_subframes
+    from deblurgs_amd.fused_step import FusedStep
+    from deblurgs_amd.training import default_optimization_params
+    sc, cloud, m = _fused_fixture(seed=4)
+    cloud.training_setup(default_optimization_params(), spatial_lr_scale=1.0)
+    bg = torch.tensor([0.3, 0.3, 0.3], device="cuda")
+    fs = FusedStep(cloud, m, lambda_hinge=0.1, speculative=True)
+    a = fs.run(0, 1e-3, m.get_gt_image(0), bg)
+    assert a["skip_flag_ptr"] is None and fs._capacity() is None      # exact path, count not polled yet
+    ga = [p.grad.clone() for p in cloud.hot_parameters()]
+    fs._poll(block=True)
+    R = fs._seen[-1]
+    assert R > 1000 and fs._capacity() > R
+    b = fs.run(0, 1e-3, m.get_gt_image(0), bg)
+    assert b["skip_flag_ptr"] is not None and fs.last_capacity == R + R // 4 + 16384
+    for x, y in zip(ga, [p.grad for p in cloud.hot_parameters()]):
+        assert torch.equal(x, y)
+    assert torch.equal(a["subframes"], b["subframes"]) and torch.equal(a["losses"], b["losses"])
+    fs._poll(block=True)
+    assert fs.dropped == 0 and fs._seen[-1] == R
+    # the step applies: parameters move
+    before = cloud._xyz.detach().clone()
+    cloud.optimizer.skip_flag_ptr = b["skip_flag_ptr"]
+    cloud.optimizer.step()
+    assert not torch.equal(before, cloud._xyz)
+    # ---- overflow: pretend the cloud used to need far fewer duplicates
+    fs._seen = [R // 3]
+    before = [p.detach().clone() for p in cloud.hot_parameters()]
+    m_before = cloud.optimizer.state[cloud._xyz]["exp_avg"].clone()
+    stats = [cloud.max_radii2D.clone(), cloud.xyz_gradient_accum.clone(), cloud.denom.clone()]
+    c = fs.run(0, 1e-3, m.get_gt_image(0), bg)
+    assert fs.last_capacity < R
+    cloud.optimizer.skip_flag_ptr = c["skip_flag_ptr"]
+    add_densification_stats_subframes(c["viewspace_grad"], c["radii"], cloud.max_radii2D, cloud.xyz_gradient_accum,
+                                      cloud.denom, skip_flag_ptr=c["skip_flag_ptr"])
+    cloud.optimizer.step()
+    torch.cuda.synchronize()
+    for x, p in zip(before, cloud.hot_parameters()):
+        assert torch.equal(x, p.detach()), "an overflowed step must not move the parameters"
+    assert torch.equal(m_before, cloud.optimizer.state[cloud._xyz]["exp_avg"])
+    for x, y in zip(stats, [cloud.max_radii2D, cloud.xyz_gradient_accum, cloud.denom]):
+        assert torch.equal(x, y)
+    fs._poll(block=True)
+    assert fs.dropped == 1 and fs._seen[-1] == R           # the true count came back: the next capacity fits
+    d = fs.run(0, 1e-3, m.get_gt_image(0), bg)
+    torch.cuda.synchronize()
+    assert torch.equal(d["subframes"], a["subframes"])
+    fs._poll(block=True)
+    assert fs.dropped == 1
+
+
+def test_training_loop_fused_and_autograd_paths_agree(gpu):
+    """TrainingLoop with the fused step (default) and with the autograd path: identical gradients at the first iteration
+    that renders all K subframes, and both reduce the loss."""
+    import torch
+    from deblurgs_amd.training import TrainingLoop, default_optimization_params
+    res = {}
+    for fused in (True, False):
+        sc, cloud, m = _fused_fixture(seed=6, K=5, P=4000)
+        opt = default_optimization_params(iterations=100, curve_start_iter=1, densify_from_iter=10 ** 9,
+                                          curve_alignment_lr=1e-3, curve_alignment_start=0)
+        loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, fused_step="auto" if fused else False)
+        assert (loop._fused is not None) == fused
+        snap = {}
+        step0 = cloud.optimizer.step
+
+        def spy(*a, _c=cloud, _m=m, _s=snap, _step=step0, **kw):
+            if "g" not in _s:
+                _s["g"] = [None if p.grad is None else p.grad.detach().clone()
+                           for p in list(_c.hot_parameters()) + list(_m.parameters())]
+            return _step(*a, **kw)
+        cloud.optimizer.step = spy
+        hist = []
+        for it in range(1, 13):
+            torch.manual_seed(it)
+            out = loop.step(it, it % 3)
+            hist.append(float(out["l1"]))
+        res[fused] = (snap["g"], hist)
+    for x, y in zip(res[True][0], res[False][0]):
+        assert (x is None) == (y is None)
+        if x is not None and x.numel():
+            assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max()) + 1e-12
+    assert abs(res[True][1][0] - res[False][1][0]) <= 1e-6
+
+
 # ------------------------------------------------------------------------------------ N-rank path on the one-GPU box
 def _run(cmd, env, timeout=900):
     import subprocess
