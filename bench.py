@@ -56,6 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-reference-lists", action="store_true",
                     help="skip the second timed region with tile_cull=0 (the reference's duplicate lists)")
     ap.add_argument("--lambda-t", type=float, default=1e-3)
+    ap.add_argument("--autograd-path", action="store_true",
+                    help="run the step through CameraMotionModule.query + torch autograd instead of the fused step")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="time query + loss + backward (+ all-reduce) only, without densification stats and Adam")
     return ap.parse_args(argv)
@@ -182,7 +184,6 @@ def run_rank(args):
     from deblurgs_amd import _lib, losses, sharding, synthetic
     from deblurgs_amd import diff_gaussian_rasterization as dgr
     from deblurgs_amd.cloud import GaussianCloud
-    from deblurgs_amd.densify_stats import add_densification_stats_subframes
     from deblurgs_amd.motion import CameraMotionModule, RefCamera
     from deblurgs_amd.training import default_optimization_params
 
@@ -220,11 +221,24 @@ def run_rank(args):
         motion._rot._control_points.copy_(torch.from_numpy(traj["ctrl_rot"])[None].to(dev))
     motion.link_gaussian(cloud)
     params = cloud.hot_parameters()
-    lambda_hinge = 0.1
-    # the iteration's tail (train.py:188-208): densification statistics + ONE fused Adam launch over the six
-    # per-Gaussian groups and the trajectory groups, reference learning rates (arguments/__init__.py:84-123)
-    cloud.training_setup(default_optimization_params(), spatial_lr_scale=1.0)
-    motion.add_training_setup(cloud, {"curve_rot": 1e-3, "curve_trans": 1e-2, "curve_alignment": 0.0})
+    # The timed step is the PRODUCT's training iteration, deblurgs_amd.training.TrainingLoop.step (train.py:104-208):
+    # scheduled hyper-parameters, the view's K subframes rendered and back-propagated (by default through
+    # deblurgs_amd.fused_step.FusedStep: no autograd graph, duplicate arrays sized ahead, no host synchronisation;
+    # --autograd-path selects CameraMotionModule.query + losses + loss.backward()), the opacity hinge, the gradient
+    # all-reduce, densification statistics and ONE fused Adam launch over the six per-Gaussian groups and the trajectory
+    # groups, reference learning rates (arguments/__init__.py:84-123).  densify_and_prune itself never fires
+    # (densify_from_iter is out of reach) and --no-optimizer drops statistics + Adam.
+    from deblurgs_amd.training import TrainingLoop
+    far = 10 ** 9
+    opt = default_optimization_params(iterations=far if not args.no_optimizer else 0, lambda_t_smooth_init=args.lambda_t,
+                                      lambda_t_smooth_final=args.lambda_t, lambda_hinge=0.1, curve_start_iter=1,
+                                      curve_end_iter=far, densify_from_iter=far,
+                                      densify_until_iter=far if not args.no_optimizer else 0,
+                                      opacity_reset_interval=far, curve_rotation_lr=1e-3, curve_controlpoints_lr=1e-2,
+                                      curve_alignment_lr=0.0)
+    mode = False if world == 1 else args.shard
+    loop = TrainingLoop(cloud, motion, opt, cameras_extent=1.0, spatial_lr_scale=1.0, distributed=mode,
+                        fused_step=False if args.autograd_path else "auto", log_losses=False)
     # The ground truth is noise, so real learning rates would pull the cloud away from the configured workload within
     # the timed region (opacities collapse and the step gets ~5 % cheaper).  The Adam kernel does the same work for
     # any learning rate; scale the rates down so that every timed step renders the workload BASELINE.json names.
@@ -233,41 +247,23 @@ def run_rank(args):
         group["lr"] *= LR_SCALE
     cloud.xyz_scheduler_args = lambda it: 0.00016 * LR_SCALE
 
-    stats = {}
+    stats = {"it": 0}
     ar_events = []
+    if world > 1:      # time the gradient all-reduce inside the product's step
+        _flat = sharding.flat_allreduce_grads
 
-    def reduce_grads(average):
-        if world == 1:
-            return
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        sharding.flat_allreduce_grads(params, average=average, extra=motion.parameters())
-        e1.record()
-        ar_events.append((e0, e1))
+        def timed_allreduce(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = _flat(*a, **kw)
+            e1.record()
+            ar_events.append((e0, e1))
+            return r
+        sharding.flat_allreduce_grads = timed_allreduce
 
     def step():
-        # hinge first: its backward then runs after the rasteriser's and adds into the flat gradient bucket in place
-        hinge = losses.hinge_l2(cloud._opacity)
-        if subframes_mode:
-            out = motion.query(0, "all", compute_blurred=False, shard=(rank, world))
-            sharding.subframe_sharded_loss_backward(out["subframes"], out["gt"], out["K_total"], out["k0"],
-                                                    args.lambda_t)
-            (lambda_hinge * hinge * (1.0 if rank == 0 else 0.0)).backward()
-            reduce_grads(average=False)
-        else:
-            out = motion.query(0, "all", compute_blurred=False)
-            loss, _blur, _ls = losses.blur_l1_smooth(out["subframes"], out["gt"], args.lambda_t)
-            loss = loss + lambda_hinge * hinge
-            loss.backward()
-            reduce_grads(average=True)
-        stats["radii"] = out["radii_all"]
-        if not args.no_optimizer:
-            with torch.no_grad():
-                if out["radii_all"].shape[0] > 0:
-                    add_densification_stats_subframes(out["viewspace_points_all"], out["radii_all"], cloud.max_radii2D,
-                                                      cloud.xyz_gradient_accum, cloud.denom, K_total=out["K_total"])
-            cloud.optimizer.step()
-        cloud.optimizer.zero_grad(set_to_none=True)
+        stats["it"] += 1
+        loop.step(stats["it"], 0)
 
     def sync():
         if world > 1:
@@ -297,7 +293,11 @@ def run_rank(args):
     for _ in range(args.warmup):
         step()
     sync()
-    Pv_tot = int((stats["radii"] > 0).sum().item())    # measured Pv of this rank's workload (output of the forward)
+    with torch.no_grad():       # measured Pv of this rank's workload (an output of the forward)
+        probe = motion.query(0, "all", compute_blurred=False,
+                             shard=(rank, world) if subframes_mode else None)
+        Pv_tot = int((probe["radii_all"] > 0).sum().item())
+        del probe
     dt = timed(args.steps, profile=True)
     prof = _lib.profile_read()
     allreduce_ms = None
@@ -309,8 +309,11 @@ def run_rank(args):
     ref_lists = None
     if world == 1 and not args.no_reference_lists and dgr.TILE_CULL:
         dgr.TILE_CULL = False
+        if loop._fused is not None:
+            loop._fused._poll(block=True)
+            loop._fused._seen = []          # the reference's lists are longer: learn their count afresh
         try:
-            for _ in range(2):
+            for _ in range(3):
                 step()
             n0 = max(10, args.steps // 4)
             dt0 = timed(n0, profile=False)
@@ -320,6 +323,8 @@ def run_rank(args):
                                  "run's (tests/test_gpu_configs.py)"}
         finally:
             dgr.TILE_CULL = True
+            if loop._fused is not None:
+                loop._fused._poll(block=True)
 
     if rank == 0:
         # R from a state-level forward (the operator keeps it in its autograd ctx)
@@ -371,6 +376,10 @@ def run_rank(args):
                        "step": ("query + fused loss + backward" + (" + grad all-reduce" if world > 1 else "") +
                                 ("" if args.no_optimizer else " + densification stats + fused Adam (all groups; learning "
                                  "rates x1e-6 so the synthetic workload stays stationary)")),
+                       "step_path": ("deblurgs_amd.training.TrainingLoop.step via " +
+                                     ("fused_step.FusedStep (C ABI, no autograd, duplicate arrays sized ahead)"
+                                      if loop._fused is not None else "CameraMotionModule.query + torch autograd")),
+                       "dropped_steps": (loop._fused.dropped if loop._fused is not None else 0),
                        "tile_cull": bool(dgr.TILE_CULL),
                        "sharding": (args.shard if world > 1 else "none"), "ranks_in_process_group": world,
                        "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),

@@ -285,10 +285,23 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    // Deterministic totals: the block sums (fixed-order fp32 trees of non-negative terms) are added as 2^-32 fixed-point
+    // integers -- integer addition is associative, so the result does not depend on the order in which the blocks
+    // arrive, unlike float atomics -- and the last block to arrive converts them.  losses is an 8-word work area:
+    // [0] L1, [1] smoothness, [2..3] / [4..5] the two 64-bit accumulators, [6] arrival counter (zeroed by the launcher).
     const float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     const float c = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    atomicAdd(&losses[0], a / (float)E);
-    if (K > 1) atomicAdd(&losses[1], c / ((float)E * (float)(K - 1)));
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(losses + 2);
+    atomicAdd(&acc[0], (unsigned long long)__double2ll_rn((double)a * 4294967296.0));
+    atomicAdd(&acc[1], (unsigned long long)__double2ll_rn((double)c * 4294967296.0));
+    __threadfence();
+    const unsigned int ticket = atomicAdd(reinterpret_cast<unsigned int*>(losses + 6), 1u);
+    if (ticket == gridDim.x - 1) {
+      __threadfence();
+      const unsigned long long t0 = atomicAdd(&acc[0], 0ull), t1 = atomicAdd(&acc[1], 0ull);
+      losses[0] = (float)(((double)t0 / 4294967296.0) / (double)E);
+      losses[1] = (K > 1) ? (float)(((double)t1 / 4294967296.0) / ((double)E * (double)(K - 1))) : 0.0f;
+    }
   }
 }
 
@@ -323,7 +336,7 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
                                 const float* scale, float* blur, float* dsub, float* losses, hipStream_t s) {
   const size_t E = (size_t)C * HW;
   if (losses != nullptr) {
-    hipError_t e = hipMemsetAsync(losses, 0, 2 * sizeof(float), s);
+    hipError_t e = hipMemsetAsync(losses, 0, 8 * sizeof(float), s);   // results + accumulators + arrival counter
     if (e != hipSuccess) return e;
   }
   const bool v4 = (E % 4 == 0) && ((reinterpret_cast<uintptr_t>(sub) | reinterpret_cast<uintptr_t>(gt) |

@@ -130,7 +130,7 @@ class FusedStep:
         ct_all, cr_all = m._trans._control_points, m._rot._control_points
         C = ct_all.shape[1] - 1
         row = cam * (C + 1) * 3
-        proj = m.ref_cam.projection_matrix
+        proj = m.ref_cam.projection_matrix.to(dev, torch.float32).contiguous()   # (stored as a transposed view)
         view = torch.empty((K, 4, 4), **f32)
         full = torch.empty((K, 4, 4), **f32)
         campos = torch.empty((K, 3), **f32)
@@ -195,9 +195,10 @@ class FusedStep:
         gtc = gt.to(dev, torch.float32).contiguous()
         blur = torch.empty((3, H, W), **f32)
         dsub = torch.empty((K, 3, H, W), **f32)
-        losses = torch.empty(2, **f32)
+        work = torch.empty(8, **f32)          # dgs_blur_loss_grad's work area: [l1, smooth | accumulators, counter]
+        losses = work[:2]
         _lib.check(L.dgs_blur_loss_grad(_ptr(color), _ptr(gtc), K, 3, H * W, float(lambda_t), None, _ptr(blur),
-                                        _ptr(dsub), _ptr(losses), stream), "dgs_blur_loss_grad")
+                                        _ptr(dsub), _ptr(work), stream), "dgs_blur_loss_grad")
 
         # ---- backward: one flat gradient bucket in optimiser-group order (as _RasterizeCloudK.backward)
         sizes = [3 * P, 3 * P, 3 * Mr * P, P, 3 * P, 4 * P]

@@ -83,10 +83,11 @@ class _BlurL1Smooth(torch.autograd.Function):
         K, C = sub.shape[0], sub.shape[1]
         HW = sub[0, 0].numel()
         blur = torch.empty_like(g)
-        losses = torch.empty(2, dtype=torch.float32, device=sub.device)
+        work = torch.empty(8, dtype=torch.float32, device=sub.device)     # [l1, smooth | accumulators, counter]
+        losses = work[:2]
         st = ctypes.c_void_p(torch.cuda.current_stream(sub.device).cuda_stream)
         _lib.check(_lib.lib().dgs_blur_loss_grad(sub.data_ptr(), g.data_ptr(), K, C, HW, float(lambda_t), None,
-                                                 blur.data_ptr(), None, losses.data_ptr(), st), "dgs_blur_loss_grad")
+                                                 blur.data_ptr(), None, work.data_ptr(), st), "dgs_blur_loss_grad")
         ctx.save_for_backward(sub, g, blur)
         ctx.lambda_t = float(lambda_t)
         total = losses[0] + float(lambda_t) * losses[1]
