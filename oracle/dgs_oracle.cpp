@@ -900,16 +900,24 @@ void dgs_oracle_unstable(int W, int H, const uint32_t* ranges, const uint32_t* p
           const float pfx = (float)px, pfy = (float)py;
           float T = 1.0f;
           bool near = false;
+          float T_relerr = 0.0f;  // accumulated relative uncertainty of T
           for (uint32_t s = r0; s < r1 && !near; s++) {
             const uint32_t g = point_list[s];
             const float dx = means2D[2 * g] - pfx, dy = means2D[2 * g + 1] - pfy;
             const float* co = conic_opacity + 4 * (size_t)g;
             const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
             const float alpha = std::min(0.99f, co[3] * std::exp(power));
-            if (std::fabs(alpha - 1.0f / 255.0f) < alpha_tol || std::fabs(power) < power_tol) near = true;
+            // fp32 evaluation uncertainty of `power`: a few ulps of its largest term (for an elongated splat far from its
+            // centre the three terms are ~1e3 and cancel to ~-5, so two correct fp32 evaluation orders differ by ~1e-4);
+            // it carries over to alpha = opacity * exp(power) as a relative error
+            const float perr = 5e-7f * (0.5f * std::fabs(co[0] * dx * dx) + 0.5f * std::fabs(co[2] * dy * dy) +
+                                        std::fabs(co[1] * dx * dy));
+            if (std::fabs(alpha - 1.0f / 255.0f) < alpha_tol + alpha * perr || std::fabs(power) < power_tol + perr)
+              near = true;
             if (power > 0.0f || alpha < 1.0f / 255.0f) continue;
             const float test_T = T * (1 - alpha);
-            if (std::fabs(test_T - 0.0001f) < T_tol) near = true;
+            if (alpha < 0.99f) T_relerr += alpha * perr / (1 - alpha);
+            if (std::fabs(test_T - 0.0001f) < T_tol + test_T * (T_relerr + 1e-6f)) near = true;
             if (test_T < 0.0001f) break;
             T = test_T;
           }

@@ -61,8 +61,12 @@ def unstable_pixels(st, alpha_tol=5e-7, power_tol=1e-4, T_tol=1e-8):
         T_incl = np.cumprod(1.0 - a, axis=1)
         stop = valid & (T_incl < 1e-4)
         reached = (np.cumsum(stop, axis=1) - stop) == 0       # pairs the pixel actually evaluates
-        near = (np.abs(alpha - 1.0 / 255.0) < alpha_tol) | (np.abs(power) < power_tol)
-        near |= valid & (np.abs(T_incl - 1e-4) < T_tol)
+        # fp32 evaluation uncertainty of `power` (a few ulps of its largest term) and what it does to alpha and T
+        perr = (5e-7 * (0.5 * np.abs(c[:, 0][None] * dx * dx) + 0.5 * np.abs(c[:, 2][None] * dy * dy)
+                        + np.abs(c[:, 1][None] * dx * dy))).astype(np.float32)
+        near = (np.abs(alpha - 1.0 / 255.0) < alpha_tol + alpha * perr) | (np.abs(power) < power_tol + perr)
+        T_rel = np.cumsum(np.where(valid & (alpha < 0.99), a * perr / np.maximum(1.0 - a, 1e-6), 0.0), axis=1)
+        near |= valid & (np.abs(T_incl - 1e-4) < T_tol + T_incl * (T_rel + 1e-6))
         near &= reached
         flag[(ys.reshape(-1) * W + xs.reshape(-1))[near.any(axis=1)]] = True
     return flag.reshape(H, W)
