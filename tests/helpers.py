@@ -387,7 +387,7 @@ def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, mult=NOISE_MULT, floor=ROW_
             report.append((key, e, en))
         for m, t in (("col", tol), ("row", row_tol)):
             cap = HARD_CAP if m == "col" else 10 * HARD_CAP
-            assert e[m] <= min(cap, max(t, m_eff * en[m])), f"{key} {m}: {e[m]:.2e} (noise {en[m]:.2e}, amp {amp:.1f})"
+            assert e[m] <= _bar(t, m_eff, en[m], cap), f"{key} {m}: {e[m]:.2e} (noise {en[m]:.2e}, amp {amp:.1f})"
 
 
 # ------------------------------------------------------------------------- the product path exactly as bench.py runs it
