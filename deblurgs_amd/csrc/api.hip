@@ -305,6 +305,82 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
   }
 }
 
+// Forward + backward at once (MODE 2's results, bit for bit) for K <= KMAX with the K subframe values of an element
+// held in registers: every subframe value is read ONCE (MODE 2 streams the subframes twice: 1.1 GB instead of 0.77 GB
+// at the metric configuration).
+template <int KMAX, int V>
+__global__ void __launch_bounds__(256)
+blur_loss_all_kernel(const float* __restrict__ sub, const float* __restrict__ gt, int K, size_t E, float lambda_t,
+                     const float* __restrict__ scale, float* __restrict__ blur, float* __restrict__ dsub,
+                     float* __restrict__ losses) {
+  __shared__ float red[2][4];
+  typedef float vec __attribute__((ext_vector_type(V)));
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
+  float l1 = 0.0f, sm = 0.0f;
+  if (e < E) {
+    vec x[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+      if (k < K) x[k] = *reinterpret_cast<const vec*>(sub + (size_t)k * E + e);
+    vec acc = x[0];
+#pragma unroll
+    for (int k = 1; k < KMAX; k++)
+      if (k < K) acc += x[k];
+    const vec b = acc / (float)K;
+    *reinterpret_cast<vec*>(blur + e) = b;
+    const vec d = b - *reinterpret_cast<const vec*>(gt + e);
+    const float up = (scale != nullptr) ? scale[0] : 1.0f;
+    const float c_l1 = up / ((float)E * (float)K);
+    const float ws = (K > 1) ? up * lambda_t / ((float)E * (float)(K - 1)) : 0.0f;
+    vec g_l1;
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+      l1 += fabsf(d[i]);
+      g_l1[i] = c_l1 * sgn(d[i]);
+    }
+    vec s_prev = (vec)(0.0f);
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+      if (k < K) {
+        vec s_next = (vec)(0.0f);
+        if (k + 1 < K) {
+          const vec dd = x[k + 1 < KMAX ? k + 1 : k] - x[k];
+#pragma unroll
+          for (int i = 0; i < V; i++) {
+            sm += fabsf(dd[i]);
+            s_next[i] = sgn(dd[i]);
+          }
+        }
+        *reinterpret_cast<vec*>(dsub + (size_t)k * E + e) = g_l1 + ws * (s_prev - s_next);
+        s_prev = s_next;
+      }
+    }
+  }
+  l1 = dgs_wave_sum63(l1);
+  sm = dgs_wave_sum63(sm);
+  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  if (lane == 63) {
+    red[0][w] = l1;
+    red[1][w] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // deterministic fixed-point totals, as in blur_loss_kernel
+    const float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const float c = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    unsigned long long* accp = reinterpret_cast<unsigned long long*>(losses + 2);
+    atomicAdd(&accp[0], (unsigned long long)__double2ll_rn((double)a * 4294967296.0));
+    atomicAdd(&accp[1], (unsigned long long)__double2ll_rn((double)c * 4294967296.0));
+    __threadfence();
+    const unsigned int ticket = atomicAdd(reinterpret_cast<unsigned int*>(losses + 6), 1u);
+    if (ticket == gridDim.x - 1) {
+      __threadfence();
+      const unsigned long long t0 = atomicAdd(&accp[0], 0ull), t1 = atomicAdd(&accp[1], 0ull);
+      losses[0] = (float)(((double)t0 / 4294967296.0) / (double)E);
+      losses[1] = (K > 1) ? (float)(((double)t1 / 4294967296.0) / ((double)E * (double)(K - 1))) : 0.0f;
+    }
+  }
+}
+
 // train.py:188-193 + scene/gaussian_model.py:456-458 for the K subframes of one step, in subframe order
 __global__ void __launch_bounds__(256)
 densify_stats_kernel(const float* __restrict__ vgrad, const int32_t* __restrict__ radii, int K, int K_total, int P,
@@ -356,6 +432,12 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
     DGS_BL(0);
   else if (losses == nullptr)
     DGS_BL(1);
+  else if (v4 && K <= 16)
+    hipLaunchKernelGGL((blur_loss_all_kernel<16, 4>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, dsub,
+                       losses);
+  else if (v4 && K <= 32)
+    hipLaunchKernelGGL((blur_loss_all_kernel<32, 2>), dim3((uint32_t)((E / 2 + 255) / 256)), dim3(256), 0, s, sub, gt, K,
+                       E, lambda_t, scale, blur, dsub, losses);
   else
     DGS_BL(2);
 #undef DGS_BL
@@ -399,7 +481,7 @@ int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, DgsLayout
 // the result (flat indices) lands in c.gsort_vals
 static hipError_t launch_depth_order(const DgsProblem* p, const DgsCarve& c, hipStream_t s) {
   return dgs_launch_depth_sort(c.gsort_keys, c.gsort_keys_alt, c.gsort_vals, c.gsort_vals_alt, p->K, (uint32_t)p->P,
-                               c.gsort_tmp, s);
+                               c.gsort_tmp, c.tiles_touched, c.tt_sorted, s);
 }
 
 int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stream_t stream) {

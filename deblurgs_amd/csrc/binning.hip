@@ -874,7 +874,8 @@ template <bool FIRST, bool LAST>
 __global__ void __launch_bounds__(DS_THREADS)
 dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t P, uint32_t nb,
-                     uint32_t nch, int shift, const uint32_t* __restrict__ table, const uint32_t* __restrict__ ctot) {
+                     uint32_t nch, int shift, const uint32_t* __restrict__ table, const uint32_t* __restrict__ ctot,
+                     const uint32_t* __restrict__ gather_src, uint32_t* __restrict__ gather_dst) {
   __shared__ uint32_t lds_k[DS_TILE];
   __shared__ uint32_t lds_v[DS_TILE];
   __shared__ uint32_t whist[DS_THREADS / 64][DS_BINS];
@@ -954,7 +955,10 @@ dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
       const uint32_t kk = lds_k[i];
       const uint32_t pos = gb[(kk >> shift) & 255u] + i;
       if (!LAST) keys_out[pos] = kk;
-      vals_out[pos] = lds_v[i];
+      const uint32_t vv = lds_v[i];
+      vals_out[pos] = vv;
+      // the last pass also lays out a per-pair word (tiles_touched) in the final order: saves a gather launch
+      if (LAST && gather_src != nullptr) gather_dst[pos] = gather_src[vv];
     }
   }
 }
@@ -1117,7 +1121,7 @@ hipError_t dgs_launch_duplicate_sorted(const DgsView& v, const DgsCarve& c, cons
                                        uint32_t* offs_sorted, uint32_t* scan_tmp, uint32_t cap, hipStream_t s) {
   const uint64_t n = (uint64_t)v.K * v.P;
   const dim3 grid((uint32_t)((n + 255) / 256));
-  hipLaunchKernelGGL(gather_u32_kernel, grid, dim3(256), 0, s, n, order, c.tiles_touched, tt_sorted);
+  // (tt_sorted was laid out by the last pass of the depth sort)
   hipError_t e = dgs_launch_scan(tt_sorted, offs_sorted, n, scan_tmp, nullptr, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(duplicate_sorted_kernel, grid, dim3(256), 0, s, v, c.rows, order, tt_sorted, offs_sorted,
@@ -1129,7 +1133,7 @@ hipError_t dgs_launch_tight_count(const DgsView& v, const DgsCarve& c, const uin
                                   uint32_t* total_tight, hipStream_t s) {
   const uint64_t n = (uint64_t)v.K * v.P;
   const dim3 grid((uint32_t)((n + 255) / 256));
-  hipLaunchKernelGGL(gather_u32_kernel, grid, dim3(256), 0, s, n, order, c.tiles_touched, c.tt_sorted);
+  // (c.tt_sorted was laid out by the last pass of the depth sort)
   hipError_t e = dgs_launch_scan(c.tt_sorted, c.offs_sorted, n, c.scan_tmp, total_full, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tight_kernel<false>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
@@ -1163,7 +1167,8 @@ size_t dgs_depth_sort_tmp_words(int K, uint32_t P) {
 // keys [K*P] u32 (destroyed), order out [K*P] u32 = flat (k, Gaussian) indices in (k, key, index) order.  Four passes:
 // the result always lands in `order` (the first of the two value buffers).
 hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
-                                 uint32_t P, uint32_t* tmp, hipStream_t s) {
+                                 uint32_t P, uint32_t* tmp, const uint32_t* gather_src, uint32_t* gather_dst,
+                                 hipStream_t s) {
   if (K <= 0 || P == 0) return hipSuccess;
   const uint32_t nb = (P + DS_TILE - 1) / DS_TILE;
   const uint32_t nch = (nb + DS_CHUNK - 1) / DS_CHUNK;
@@ -1181,13 +1186,13 @@ hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* o
     hipLaunchKernelGGL(dsort_colscan_top_kernel, dim3((uint32_t)K), dim3(DS_BINS), 0, s, ctot, nch, P);
     if (pass == 0)
       hipLaunchKernelGGL((dsort_scatter_kernel<true, false>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P, nb,
-                         nch, shift, table, ctot);
+                         nch, shift, table, ctot, gather_src, gather_dst);
     else if (pass == 3)
       hipLaunchKernelGGL((dsort_scatter_kernel<false, true>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P, nb,
-                         nch, shift, table, ctot);
+                         nch, shift, table, ctot, gather_src, gather_dst);
     else
       hipLaunchKernelGGL((dsort_scatter_kernel<false, false>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P,
-                         nb, nch, shift, table, ctot);
+                         nb, nch, shift, table, ctot, gather_src, gather_dst);
     uint32_t* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }

@@ -229,7 +229,8 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
                                 const float* scale, float* blur, float* dsub, float* losses, hipStream_t s);
 
 hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
-                                 uint32_t P, uint32_t* tmp, hipStream_t s);
+                                 uint32_t P, uint32_t* tmp, const uint32_t* gather_src, uint32_t* gather_dst,
+                                 hipStream_t s);
 size_t dgs_depth_sort_tmp_words(int K, uint32_t P);
 size_t dgs_scan_tmp_words(uint64_t n);
 size_t dgs_sort_tmp_words(uint64_t n);
