@@ -151,7 +151,9 @@ def cpu_baseline_torch_naive(scene, k, side=96):
     import numpy as np
     import torch
     from oracle import torch_naive
-    threads = os.cpu_count() or 1
+    # torch's CPU kernels on these small dense tiles get SLOWER beyond a few dozen threads (143 s with 128 threads
+    # against 9 s with 8 for the same sample, tools/naive_threads.py); the count used is stated in `cores`
+    threads = int(os.environ.get("DGS_NAIVE_THREADS", min(os.cpu_count() or 1, 16)))
     torch.set_num_threads(threads)
     W, H = scene["W"], scene["H"]
     x0, y0 = (W - side) // 2 // 16 * 16, (H - side) // 2 // 16 * 16

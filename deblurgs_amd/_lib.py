@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdgs_hip.so")
+# DGS_LIB_PATH: A/B builds of the same library for kernel experiments (tools only; the default is the in-tree build)
+LIB_PATH = os.environ.get("DGS_LIB_PATH") or os.path.join(_HERE, "libdgs_hip.so")
 
 DGS_MAX_K = 128
 STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "composite_fwd", "composite_bwd", "geometry_bwd",

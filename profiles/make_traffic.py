@@ -1,4 +1,4 @@
-"""Builds profiles/traffic_r01.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
+"""Builds profiles/traffic_r02.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
 MI355X_MICROARCH.md, "HBM" and the TCC slot table):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <fetch_dir> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d <write_dir> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
@@ -56,7 +56,7 @@ def main():
         w = write.get(k, 0.0)
         out["_detail"][k] = {"fetch_bytes": int(f), "write_bytes": int(w)}
         out[k] = int(f + w)
-    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic_r01.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic_r02.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
 
 

@@ -1,4 +1,4 @@
-"""Builds profiles/valu_r01.json from one rocprofv3 PMC pass:
+"""Builds profiles/valu_r02.json from one rocprofv3 PMC pass:
     rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE -d <dir> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
     python profiles/make_valu.py <dir>
 """
@@ -21,5 +21,5 @@ for k, c in agg.items():
     cyc = v["GRBM_GUI_ACTIVE"] / 8
     out[k] = {"valu_insts": int(v["SQ_INSTS_VALU"]), "salu_insts": int(v["SQ_INSTS_SALU"]), "lds_insts": int(v["SQ_INSTS_LDS"]),
               "waves": int(v["SQ_WAVES"]), "cycles_per_xcd": int(cyc), "ipc_per_simd": round(v["SQ_INSTS_VALU"] / (1024 * cyc), 3)}
-json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "valu_r01.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "valu_r02.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
