@@ -469,7 +469,9 @@ size_t dgs_binning_state_bytes(uint64_t R, int32_t W, int32_t H, int32_t K) {
   return L.binning_total;
 }
 size_t dgs_backward_scratch_bytes(uint64_t R, int32_t P, int32_t K) {
-  return up((size_t)R * DGS_CONTRIB_F * 4) + up((size_t)dgs_geometry_bwd_blocks(P) * (size_t)K * 24 * 4) + ALIGN;
+  // contribution rows [R] + their per-pair totals by natural index [K*P] (48 bytes each) + pose-gradient partials
+  return up((size_t)R * DGS_CONTRIB_F * 4) + up((size_t)K * (size_t)P * DGS_CONTRIB_F * 4) +
+         up((size_t)dgs_geometry_bwd_blocks(P) * (size_t)K * 24 * 4) + ALIGN;
 }
 int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, DgsLayout* out) {
   if (out == nullptr) return fail(DGS_E_ARG, "null DgsLayout");
@@ -641,10 +643,12 @@ int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stre
   carve(p, L, &c);
   const DgsView v = make_view(p);
   float* contrib = reinterpret_cast<float*>(io->scratch);
-  float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(io->scratch) + up((size_t)R * DGS_CONTRIB_F * 4));
+  float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(io->scratch) + up((size_t)R * DGS_CONTRIB_F * 4));
+  float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(sums) +
+                                             up((size_t)p->K * (size_t)p->P * DGS_CONTRIB_F * 4));
   DGS_STAGE(DGS_STAGE_COMPOSITE_BWD, "composite backward",
             dgs_launch_composite_bwd(v, c, p->bg, io->dL_dout_color, io->dL_dout_depth, contrib, s));
-  DGS_STAGE(DGS_STAGE_GEOMETRY_BWD, "geometry backward", dgs_launch_geometry_bwd(*p, v, c, *io, contrib, partials, s));
+  DGS_STAGE(DGS_STAGE_GEOMETRY_BWD, "geometry backward", dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s));
   return DGS_OK;
 }
 

@@ -250,7 +250,7 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
              const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ offs_sorted,
              uint32_t* __restrict__ tt_tight, const uint32_t* __restrict__ offs_tight,
              const uint32_t* __restrict__ total_full, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-             uint32_t* __restrict__ dup_off, uint32_t cap) {
+             uint32_t cap) {
   // the rectangle total overflowed 32 bits: the offsets are meaningless (the host raises on the overflow word)
   if (total_full[1] != 0u) {
     const uint64_t jj = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -294,10 +294,8 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
       fl = (cg.always ? 1u : 0u) | (cg.never ? 2u : 0u);
       if (EMIT) {
         otight = offs_tight[j];
-        // first contribution row of this (k, Gaussian), by natural index: a 4-byte store into a K*P-word array that stays
-        // cache-resident (stamping it into the 48-byte geometry row cost a read-modify-write of a line per pair);
-        // no surviving tile: geometry_bwd reads zeros
-        dup_off[i] = tt_tight[j] != 0 ? otight : 0xFFFFFFFFu;
+        // (the backward finds this pair's contribution rows through offs_tight[j] in this same order:
+        // contrib_reduce_kernel; nothing is stamped per pair)
       }
     } else if (EMIT) {
       otight = offs_tight[j];
@@ -1137,7 +1135,7 @@ hipError_t dgs_launch_tight_count(const DgsView& v, const DgsCarve& c, const uin
   hipError_t e = dgs_launch_scan(c.tt_sorted, c.offs_sorted, n, c.scan_tmp, total_full, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tight_kernel<false>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
-                     c.tt_tight, c.offs_tight, total_full, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+                     c.tt_tight, c.offs_tight, total_full, (uint64_t*)nullptr, (uint32_t*)nullptr, 0u);
   return dgs_launch_scan(c.tt_tight, c.offs_tight, n, c.scan_tmp, total_tight, s);
 }
 
@@ -1146,7 +1144,7 @@ hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const
   const uint64_t n = (uint64_t)v.K * v.P;
   const dim3 grid((uint32_t)((n + 255) / 256));
   hipLaunchKernelGGL(tight_kernel<true>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
-                     c.tt_tight, c.offs_tight, c.num_rendered, c.keys_unsorted, c.vals_unsorted, c.point_offsets, cap);
+                     c.tt_tight, c.offs_tight, c.num_rendered, c.keys_unsorted, c.vals_unsorted, cap);
   return hipGetLastError();
 }
 

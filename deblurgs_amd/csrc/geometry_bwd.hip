@@ -50,47 +50,51 @@ __device__ __forceinline__ M3 tr(const M3& A) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// Stage 1: one thread per (subframe, Gaussian) sums that pair's contribution rows in duplicate order and
-// leaves the total IN PLACE in the first row of its segment.  Small register footprint -> full occupancy, so
-// the dependent row loop is latency-hidden by sheer thread count (it was the bottleneck when it lived inside
-// the 180-VGPR geometry kernel).
+// Stage 1: the contribution rows of every visible (subframe, Gaussian) pair, summed in duplicate order (deterministic),
+// written as ONE 48-byte total per pair at the pair's NATURAL index k * P + g.  Pairs are walked in the order the
+// duplicates were laid out in ((k, depth, index): consecutive threads read consecutive row segments); one thread per
+// pair keeps 64 pairs x 3 x 16-byte loads in flight per wave (the walk is latency-bound), rows four at a time.
+// The geometry kernel then reads its totals with coalesced, independent loads -- no duplicate offset to chase, and the
+// emit pass of the forward no longer stores one.  A visible pair whose every tile was culled gets zeros.
 __global__ void __launch_bounds__(256)
-contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ status, const uint32_t* __restrict__ tiles_touched,
-                      const uint32_t* __restrict__ offsets, float* __restrict__ contrib) {
+contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ status, const uint32_t* __restrict__ order,
+                      const uint32_t* __restrict__ tt_visible, const uint32_t* __restrict__ tiles,
+                      const uint32_t* __restrict__ offsets, const float* __restrict__ contrib,
+                      float* __restrict__ sums) {
   if (status[5] != 0u) return;  // capacity mode, truncated lists: the offsets point past the rows that were written
-  // four lanes per (subframe, Gaussian): lane part p in {0,1,2} owns the p-th float4 of every row of the segment
-  // (part 3 idles), so a quad reads each 48-byte row with one contiguous access and no cross-lane sum is needed
-  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint64_t i = t >> 2;
-  const uint32_t part = (uint32_t)t & 3u;
-  if (i >= n || part == 3u) return;
-  const uint32_t nt = tiles_touched[i];
-  if (nt < 2) return;  // nothing to add
-  float4* cp = reinterpret_cast<float4*>(contrib + (size_t)offsets[i] * DGS_CONTRIB_F) + part;
-  float4 a = cp[0];
-  // rows are added strictly in duplicate order (deterministic); eight rows are requested before the first add so
-  // that the loop is not a chain of dependent HBM round trips
-  uint32_t r = 1;
-  for (; r + 8 <= nt; r += 8) {
-    float4 q[8];
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  if (tt_visible[j] == 0u) return;  // invisible pair: the geometry kernel never reads its slot
+  const uint32_t nt = tiles[j];
+  float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0, a2 = a0;
+  if (nt > 0) {
+    const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)offsets[j] * DGS_CONTRIB_F);
+    a0 = cp[0];
+    a1 = cp[1];
+    a2 = cp[2];
+    uint32_t r = 1;
+    for (; r + 4 <= nt; r += 4) {
+      float4 q[12];
 #pragma unroll
-    for (int j = 0; j < 8; j++) q[j] = cp[3 * (r + j)];
+      for (int t = 0; t < 12; t++) q[t] = cp[3 * r + t];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      a.x += q[j].x;
-      a.y += q[j].y;
-      a.z += q[j].z;
-      a.w += q[j].w;
+      for (int t = 0; t < 4; t++) {
+        a0.x += q[3 * t].x; a0.y += q[3 * t].y; a0.z += q[3 * t].z; a0.w += q[3 * t].w;
+        a1.x += q[3 * t + 1].x; a1.y += q[3 * t + 1].y; a1.z += q[3 * t + 1].z; a1.w += q[3 * t + 1].w;
+        a2.x += q[3 * t + 2].x; a2.y += q[3 * t + 2].y; a2.z += q[3 * t + 2].z; a2.w += q[3 * t + 2].w;
+      }
+    }
+    for (; r < nt; r++) {
+      const float4 q0 = cp[3 * r], q1 = cp[3 * r + 1], q2 = cp[3 * r + 2];
+      a0.x += q0.x; a0.y += q0.y; a0.z += q0.z; a0.w += q0.w;
+      a1.x += q1.x; a1.y += q1.y; a1.z += q1.z; a1.w += q1.w;
+      a2.x += q2.x; a2.y += q2.y; a2.z += q2.z; a2.w += q2.w;
     }
   }
-  for (; r < nt; r++) {
-    const float4 q = cp[3 * r];
-    a.x += q.x;
-    a.y += q.y;
-    a.z += q.z;
-    a.w += q.w;
-  }
-  cp[0] = a;
+  float4* dst = reinterpret_cast<float4*>(sums + (size_t)order[j] * DGS_CONTRIB_F);
+  dst[0] = a0;
+  dst[1] = a1;
+  dst[2] = a2;
 }
 
 template <int MAXC>  // MAXC = SH coefficients held in registers: 1, 4, 9 or 16
@@ -100,7 +104,7 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
                     const float* __restrict__ scales, const float* __restrict__ rotations,
                     const float* __restrict__ cov3D_precomp, const float* __restrict__ viewm,
                     const float* __restrict__ projm, const float* __restrict__ campos,
-                    const uint32_t* __restrict__ offsets, const DgsRow* __restrict__ rows,
+                    const DgsRow* __restrict__ rows,
                     const float* __restrict__ cov3Ds,
                     const float* __restrict__ pre_sigmoid, const uint32_t* __restrict__ tiles_touched,
                     const float* __restrict__ contrib, const uint32_t* __restrict__ status, float hinge_scale,
@@ -146,11 +150,11 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     }
   }
 
-  // Software pipeline over the subframes: the loads of one (subframe, Gaussian) are dependent hops
-  // (tiles_touched / duplicate offset -> contribution row at that offset) and this kernel runs at two
+  // Software pipeline over the subframes (this kernel runs at two waves per SIMD): the loads of one (subframe, Gaussian)
+  // -- tiles_touched, the geometry row, the 48-byte total at the natural index -- and this kernel runs at two
   // waves per SIMD, so they are issued ahead: row of k+2 and contribution row of k+1 are in flight while k computes.
   struct RowPf {
-    uint32_t nt, doff;
+    uint32_t nt;
     float4 ga, gb;  // x, y, cx, cy | cz, op, r, g
   };
   auto load_row = [&](int k) {
@@ -160,29 +164,24 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     r.nt = valid ? tiles_touched[o] : 0u;
     r.ga = rowp[0];   // unconditional (no dependent hop); rows of invisible pairs are never used
     r.gb = rowp[1];
-    r.doff = valid ? offsets[o] : 0u;   // first contribution row of the pair (written by the duplication pass)
     return r;
   };
   struct SumPf {
     float4 r0, r1, r2;
   };
-  auto load_sums = [&](const RowPf& r) {
-    // the (subframe, Gaussian) total left by contrib_reduce_kernel in the first row of the segment; tile_cull
-    // leaves doff = ~0 for a visible pair whose every tile was culled: all its sums are zero
+  auto load_sums = [&](int k) {
+    // the (subframe, Gaussian) total contrib_reduce_kernel left at the pair's natural index (zeros when tile culling
+    // left the pair no tile); loaded unconditionally -- the slot of an invisible pair is never used
     SumPf c;
-    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    c.r0 = c.r1 = c.r2 = z4;
-    if (r.nt > 0 && r.doff != 0xFFFFFFFFu) {
-      const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)r.doff * DGS_CONTRIB_F);
-      c.r0 = cp[0];
-      c.r1 = cp[1];
-      c.r2 = cp[2];
-    }
+    const float4* cp = reinterpret_cast<const float4*>(contrib + ((size_t)k * v.P + gi) * DGS_CONTRIB_F);
+    c.r0 = cp[0];
+    c.r1 = cp[1];
+    c.r2 = cp[2];
     return c;
   };
   RowPf row1 = load_row(0);
   RowPf row2 = load_row(v.K > 1 ? 1 : 0);
-  SumPf sum1 = load_sums(row1);
+  SumPf sum1 = load_sums(0);
 
   for (int k = 0; k < v.K; k++) {
     const float* V = viewm + 16 * k;
@@ -196,7 +195,7 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     const SumPf cs = sum1;
     row1 = row2;
     if (k + 2 < v.K) row2 = load_row(k + 2);
-    if (k + 1 < v.K) sum1 = load_sums(row1);
+    if (k + 1 < v.K) sum1 = load_sums(k + 1);
     const uint32_t ntiles = cur.nt;
     if (ntiles > 0) {
       const float4 ga = cur.ga, gb = cur.gb;
@@ -594,7 +593,7 @@ pose_grad_reduce_kernel(int K, int nblocks, const float* __restrict__ partials, 
 int dgs_geometry_bwd_blocks(int P) { return (P + GB_THREADS - 1) / GB_THREADS; }
 
 hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const DgsCarve& c, const DgsBackwardIO& io,
-                                   const float* contrib, float* partials, hipStream_t s) {
+                                   const float* contrib, float* sums, float* partials, hipStream_t s) {
   const int blocks = dgs_geometry_bwd_blocks(v.P);
   const size_t lds = (size_t)(GB_THREADS / 64) * v.K * NMAT * sizeof(float);
   const int ncoef = (p.shs != nullptr) ? (v.D + 1) * (v.D + 1) : 1;
@@ -602,16 +601,18 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
   // walk the (k, Gaussian) pairs in (k, depth, index) order: their row segments are then consecutive in memory
   // (that is the order the duplicates were laid out in), so a wave streams one contiguous span of rows
   // (tt_sorted / offs_sorted only exist when the forward produced duplicates)
-  if (io.num_rendered > 0)
-    hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((4 * kp + 255) / 256)), dim3(256), 0, s, kp,
-                       c.num_rendered, v.tile_cull ? c.tt_tight : c.tt_sorted, v.tile_cull ? c.offs_tight : c.offs_sorted,
-                       const_cast<float*>(contrib));
+  // (the depth order, tt_sorted / offs_sorted exist whenever a duplicate or -- with tile culling -- a visible pair does;
+  // otherwise no pair is visible and the geometry kernel reads no total)
+  if (io.num_rendered > 0 || v.tile_cull)
+    hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((kp + 255) / 256)), dim3(256), 0, s, kp, c.num_rendered,
+                     c.gsort_vals, c.tt_sorted, v.tile_cull ? c.tt_tight : c.tt_sorted,
+                     v.tile_cull ? c.offs_tight : c.offs_sorted, contrib, sums);
 #define DGS_GB_LAUNCH(MAXC)                                                                                          \
   hipLaunchKernelGGL(geometry_bwd_kernel<MAXC>, dim3(blocks), dim3(GB_THREADS), lds, s, v, p.means3D, p.shs,         \
                      p.shs_rest, p.opacities,                                                                        \
-                     p.scales, p.rotations, p.cov3D_precomp, p.viewmatrix, p.projmatrix, p.campos, c.point_offsets, c.rows,       \
+                     p.scales, p.rotations, p.cov3D_precomp, p.viewmatrix, p.projmatrix, p.campos, c.rows,       \
                      c.cov3D,  \
-                     c.pre_sigmoid, c.tiles_touched, contrib, c.num_rendered, io.opacity_hinge_scale, io.dL_dmeans3D,  \
+                     c.pre_sigmoid, c.tiles_touched, sums, c.num_rendered, io.opacity_hinge_scale, io.dL_dmeans3D,  \
                      io.dL_dmeans2D, io.dL_dsh,                                                                       \
                      io.dL_dsh_rest,                                                                                 \
                      io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations, io.dL_dcov3D, partials)

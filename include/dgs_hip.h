@@ -129,9 +129,10 @@ typedef struct DgsLayout {
   size_t cov3D;          /* f32 [P,6] */
   size_t pre_sigmoid;    /* f32 [K,P,3]  pre-activation colour (sigmoid) or 0/1 clamp mask (relu) */
   size_t tiles_touched;  /* u32 [K*P] */
-  size_t point_offsets;  /* u32 [K*P] by natural (k, Gaussian) index: index of the pair's first duplicate = first
-                          * contribution row of the backward (duplicates are laid out in (k, depth, index) order;
-                          * 0xFFFFFFFF = visible but every tile culled; undefined for invisible pairs) */
+  size_t point_offsets;  /* u32 [K*P] tile_cull = 0 only, by natural (k, Gaussian) index: index of the pair's first
+                          * duplicate = first contribution row of the backward (duplicates are laid out in (k, depth,
+                          * index) order; undefined for invisible pairs).  With tile culling the backward uses
+                          * offs_tight (same order as tt_tight) and the emission index in the low key word. */
   size_t scan_tmp;       /* u32 scan block sums */
   size_t num_rendered;   /* u32 [4] device copy of R (+ spare) */
   size_t gsort_keys;     /* u32 [K,P] depth bits (0xFFFFFFFF = invisible): keys of the segmented depth sort */

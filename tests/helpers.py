@@ -143,6 +143,7 @@ def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_p
         pre_sigmoid=view(geom, L.pre_sigmoid, K * P * 12, np.float32, (K, P, 3)),
         tiles_touched=view(geom, L.tiles_touched, K * P * 4, np.uint32, (K, P)),
         point_offsets=view(geom, L.point_offsets, K * P * 4, np.uint32, (K, P)),
+        order=view(geom, L.gsort_vals, K * P * 4, np.uint32, (K * P,)),
         tt_tight=view(geom, L.tt_tight, K * P * 4, np.uint32, (K * P,)),
         offs_tight=view(geom, L.offs_tight, K * P * 4, np.uint32, (K * P,)),
         final_T=view(image, L.final_T, K * N * 4, np.float32, (K, N)),

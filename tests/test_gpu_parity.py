@@ -300,13 +300,16 @@ def test_tile_cull_lists_are_the_contributing_subset(gpu, seed, sigma):
     # the low key word is the duplicate's emission index: a permutation of [0, R), segment by segment
     u = (cul["keys"] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     assert np.array_equal(np.sort(u), np.arange(cul["R"]))
-    flat_off = cul["point_offsets"].reshape(-1)
+    # first contribution row of every pair, by natural index: offs_tight is laid out in (k, depth, index) order
+    flat_off = np.zeros(K * P, np.int64)
+    flat_off[cul["order"].astype(np.int64)] = cul["offs_tight"].astype(np.int64)
     gi = (cul["keys"] >> np.uint64(32)).astype(np.int64) // cul["T"] * P + cul["point_list"]
-    doff = flat_off[gi].astype(np.int64)
+    doff = flat_off[gi]
     cnt = np.bincount(gi, minlength=K * P)
     assert np.all((u >= doff) & (u < doff + cnt[gi])), "contribution-row slot inside the pair's segment"
-    vis = cul["tiles_touched"].reshape(-1) > 0
-    assert np.all(flat_off[vis & (cnt == 0)] == 0xFFFFFFFF)
+    tight_nat = np.zeros(K * P, np.int64)
+    tight_nat[cul["order"].astype(np.int64)] = cul["tt_tight"].astype(np.int64)
+    assert np.array_equal(tight_nat, cnt), "surviving-tile counts per pair"
     rng = cul["ranges"].reshape(-1, 2).astype(np.int64)
     assert np.array_equal(rng[:, 1] - rng[:, 0], np.bincount((cul["keys"] >> np.uint64(32)).astype(np.int64),
                                                              minlength=rng.shape[0]))
