@@ -210,9 +210,9 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
                  float* __restrict__ losses) {
   __shared__ float red[2][4];
   typedef float vec __attribute__((ext_vector_type(V)));
-  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
   float l1 = 0.0f, sm = 0.0f;
-  if (e < E) {
+  // grid-stride loop: the launcher caps the grid (the loss totals cost three same-address atomics per block)
+  for (size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; e < E; e += (size_t)gridDim.x * 256 * V) {
     auto ld = [](const float* p) { return *reinterpret_cast<const vec*>(p); };
     if (MODE == 0) {
       // forward: ONE pass over the K subframes (sum for the blur and the adjacent differences together), unrolled so
@@ -315,9 +315,8 @@ blur_loss_all_kernel(const float* __restrict__ sub, const float* __restrict__ gt
                      float* __restrict__ losses) {
   __shared__ float red[2][4];
   typedef float vec __attribute__((ext_vector_type(V)));
-  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
   float l1 = 0.0f, sm = 0.0f;
-  if (e < E) {
+  for (size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; e < E; e += (size_t)gridDim.x * 256 * V) {
     vec x[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++)
@@ -418,7 +417,11 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
   const bool v4 = (E % 4 == 0) && ((reinterpret_cast<uintptr_t>(sub) | reinterpret_cast<uintptr_t>(gt) |
                                     reinterpret_cast<uintptr_t>(blur) | reinterpret_cast<uintptr_t>(dsub)) % 16 == 0);
   const size_t per = v4 ? 4 : 1;
-  const dim3 grid((uint32_t)((E / per + 255) / 256));
+  // at most 2048 blocks (8 per CU): enough to saturate HBM, few enough that the per-block atomics of the loss totals
+  // (6075 blocks at 1080p cost 0.35 ms of same-address atomics) disappear; the totals depend on the grid, which is a
+  // function of E only -- still bitwise reproducible
+  const size_t want = (E / per + 255) / 256;
+  const dim3 grid((uint32_t)(want < 2048 ? (want == 0 ? 1 : want) : 2048));
 #define DGS_BL(MODE)                                                                                              \
   do {                                                                                                            \
     if (v4)                                                                                                       \
@@ -436,8 +439,8 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
     hipLaunchKernelGGL((blur_loss_all_kernel<16, 4>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, dsub,
                        losses);
   else if (v4 && K <= 32)
-    hipLaunchKernelGGL((blur_loss_all_kernel<32, 2>), dim3((uint32_t)((E / 2 + 255) / 256)), dim3(256), 0, s, sub, gt, K,
-                       E, lambda_t, scale, blur, dsub, losses);
+    hipLaunchKernelGGL((blur_loss_all_kernel<32, 2>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, dsub,
+                       losses);
   else
     DGS_BL(2);
 #undef DGS_BL

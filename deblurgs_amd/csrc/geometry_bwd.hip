@@ -52,8 +52,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 // Stage 1: the contribution rows of every visible (subframe, Gaussian) pair, summed in duplicate order (deterministic),
 // written as ONE 48-byte total per pair at the pair's NATURAL index k * P + g.  Pairs are walked in the order the
-// duplicates were laid out in ((k, depth, index): consecutive threads read consecutive row segments); one thread per
-// pair keeps 64 pairs x 3 x 16-byte loads in flight per wave (the walk is latency-bound), rows four at a time.
+// duplicates were laid out in ((k, depth, index): consecutive quads read consecutive row segments).
 // The geometry kernel then reads its totals with coalesced, independent loads -- no duplicate offset to chase, and the
 // emit pass of the forward no longer stores one.  A visible pair whose every tile was culled gets zeros.
 __global__ void __launch_bounds__(256)
@@ -62,39 +61,42 @@ contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ status, const uin
                       const uint32_t* __restrict__ offsets, const float* __restrict__ contrib,
                       float* __restrict__ sums) {
   if (status[5] != 0u) return;  // capacity mode, truncated lists: the offsets point past the rows that were written
-  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  // four lanes per (subframe, Gaussian): lane part p in {0,1,2} owns the p-th float4 of every row of the segment
+  // (part 3 idles), so a quad reads each 48-byte row with one contiguous access and no cross-lane sum is needed
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t j = t >> 2;
+  const uint32_t part = (uint32_t)t & 3u;
+  if (j >= n || part == 3u) return;
   if (tt_visible[j] == 0u) return;  // invisible pair: the geometry kernel never reads its slot
   const uint32_t nt = tiles[j];
-  float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0, a2 = a0;
+  float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (nt > 0) {
-    const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)offsets[j] * DGS_CONTRIB_F);
-    a0 = cp[0];
-    a1 = cp[1];
-    a2 = cp[2];
+    const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)offsets[j] * DGS_CONTRIB_F) + part;
+    a = cp[0];
+    // rows are added strictly in duplicate order (deterministic); eight rows are requested before the first add so
+    // that the loop is not a chain of dependent HBM round trips
     uint32_t r = 1;
-    for (; r + 4 <= nt; r += 4) {
-      float4 q[12];
+    for (; r + 8 <= nt; r += 8) {
+      float4 q[8];
 #pragma unroll
-      for (int t = 0; t < 12; t++) q[t] = cp[3 * r + t];
+      for (int i = 0; i < 8; i++) q[i] = cp[3 * (r + i)];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        a0.x += q[3 * t].x; a0.y += q[3 * t].y; a0.z += q[3 * t].z; a0.w += q[3 * t].w;
-        a1.x += q[3 * t + 1].x; a1.y += q[3 * t + 1].y; a1.z += q[3 * t + 1].z; a1.w += q[3 * t + 1].w;
-        a2.x += q[3 * t + 2].x; a2.y += q[3 * t + 2].y; a2.z += q[3 * t + 2].z; a2.w += q[3 * t + 2].w;
+      for (int i = 0; i < 8; i++) {
+        a.x += q[i].x;
+        a.y += q[i].y;
+        a.z += q[i].z;
+        a.w += q[i].w;
       }
     }
     for (; r < nt; r++) {
-      const float4 q0 = cp[3 * r], q1 = cp[3 * r + 1], q2 = cp[3 * r + 2];
-      a0.x += q0.x; a0.y += q0.y; a0.z += q0.z; a0.w += q0.w;
-      a1.x += q1.x; a1.y += q1.y; a1.z += q1.z; a1.w += q1.w;
-      a2.x += q2.x; a2.y += q2.y; a2.z += q2.z; a2.w += q2.w;
+      const float4 q = cp[3 * r];
+      a.x += q.x;
+      a.y += q.y;
+      a.z += q.z;
+      a.w += q.w;
     }
   }
-  float4* dst = reinterpret_cast<float4*>(sums + (size_t)order[j] * DGS_CONTRIB_F);
-  dst[0] = a0;
-  dst[1] = a1;
-  dst[2] = a2;
+  reinterpret_cast<float4*>(sums + (size_t)order[j] * DGS_CONTRIB_F)[part] = a;
 }
 
 template <int MAXC>  // MAXC = SH coefficients held in registers: 1, 4, 9 or 16
@@ -604,7 +606,7 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
   // (the depth order, tt_sorted / offs_sorted exist whenever a duplicate or -- with tile culling -- a visible pair does;
   // otherwise no pair is visible and the geometry kernel reads no total)
   if (io.num_rendered > 0 || v.tile_cull)
-    hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((kp + 255) / 256)), dim3(256), 0, s, kp, c.num_rendered,
+    hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((4 * kp + 255) / 256)), dim3(256), 0, s, kp, c.num_rendered,
                      c.gsort_vals, c.tt_sorted, v.tile_cull ? c.tt_tight : c.tt_sorted,
                      v.tile_cull ? c.offs_tight : c.offs_sorted, contrib, sums);
 #define DGS_GB_LAUNCH(MAXC)                                                                                          \

@@ -273,7 +273,7 @@ def grad_errors(a, b, rows=None, floor=0.05):
 # ------------------------------------------------------------------------------- conditioning-aware gradient checker
 GRAD_TOL = 1e-4        # north_star bar, applied per gradient COMPONENT (column), each against its own scale
 ROW_TOL = 1e-3         # per GAUSSIAN: relative to the Gaussian's own gradient magnitude, floored at ROW_FLOOR x column scale
-NOISE_MULT = 4.0       # ... or within this factor of the reference algorithm's own fp32 rounding noise
+NOISE_MULT = 8.0       # ... or within this factor of the reference algorithm's own fp32 rounding noise (accumulation-noise proxy)
 ROW_FLOOR = 0.1
 
 
