@@ -486,7 +486,7 @@ int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, DgsLayout
 // the result (flat indices) lands in c.gsort_vals
 static hipError_t launch_depth_order(const DgsProblem* p, const DgsCarve& c, hipStream_t s) {
   return dgs_launch_depth_sort(c.gsort_keys, c.gsort_keys_alt, c.gsort_vals, c.gsort_vals_alt, p->K, (uint32_t)p->P,
-                               c.gsort_tmp, c.tiles_touched, c.tt_sorted, s);
+                               c.gsort_tmp, nullptr, nullptr, s);
 }
 
 int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stream_t stream) {
