@@ -141,6 +141,10 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       const float4 a = rowj[0];
       const float4 b = rowj[1];
       const float2 c = *reinterpret_cast<const float2*>(rowj + 2);
+      // 1-based list position of this entry, materialised in a VGPR once per entry: as a wave-uniform (SGPR) value the
+      // select below needs a v_mov per quadrant pass (a select cannot take an SGPR mask and an SGPR source)
+      uint32_t posv = base + (uint32_t)j + 1u;
+      asm volatile("" : "+v"(posv));
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         if ((m[q] >> j) & 1ull) {  // wave-uniform: this Gaussian can reach quadrant q
@@ -160,7 +164,7 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           C2[q] += c.x * wgt;
           Dd[q] += c.y * wgt;
           T[q] = stop ? -fabsf(T[q]) : test_T;     // alpha = 0 leaves a live T unchanged
-          last[q] = (ok && !stop) ? (base + (uint32_t)j + 1u) : last[q];
+          last[q] = (ok && !stop) ? posv : last[q];
         }
       }
     }

@@ -388,6 +388,45 @@ def test_fused_step_equals_autograd_path(gpu, subframes):
     assert _shared_flat([p.grad for p in cloud.hot_parameters()]) is not None
 
 
+@pytest.mark.parametrize("f,jitter", [(15, False), (15, True), (5, True), (2, False), (1, False), (128, True)])
+def test_alignment_kernels_match_the_torch_expression(gpu, f, jitter):
+    """dgs_alignment_forward / _backward against scene/motion.py:209-219 written with torch ops (sigmoid, optional jitter
+    u / f - 1 / (2 f), cat with the end points, clamp, sort) and its autograd: raw values far enough out that the clamp
+    is active for some, jitter that reorders neighbours."""
+    import ctypes
+    import torch
+    from deblurgs_amd import _lib
+    torch.manual_seed(f * 7 + jitter)
+    L = _lib.lib()
+    n = max(f - 2, 0)
+    raw = (torch.randn(n, device="cuda") * 2.5).requires_grad_(True)
+    if n > 3:
+        with torch.no_grad():
+            raw[0], raw[1] = 9.0, -9.0           # sigmoid ~ 1 / ~ 0: with jitter these leave [0, 1] and get clamped
+    u = torch.rand(n, device="cuda") if jitter and n > 0 else None
+    mid = torch.sigmoid(raw)
+    if u is not None:
+        mid = mid + u / f - (1 / (2 * f))
+    parts = [torch.zeros(1, device="cuda"), mid, torch.ones(1, device="cuda")] if f > 1 else [torch.zeros(1, device="cuda")]
+    ref = torch.cat(parts)[:f].clamp(0.0, 1.0).sort(stable=True).values
+    nu = torch.empty(f, device="cuda")
+    src = torch.empty(f, dtype=torch.int32, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: None if t is None or t.numel() == 0 else ctypes.c_void_p(t.data_ptr())
+    _lib.check(L.dgs_alignment_forward(p(raw), p(u), f, f, p(nu), p(src), st), "fwd")
+    torch.cuda.synchronize()
+    assert float((nu - ref).abs().max()) <= 1e-7
+    assert sorted(src.tolist()) == list(range(f)) and bool((nu[1:] >= nu[:-1]).all())
+    if n == 0:
+        return
+    g = torch.randn(f, device="cuda")
+    (ref * g).sum().backward()
+    d_raw = torch.zeros(n, device="cuda")
+    _lib.check(L.dgs_alignment_backward(p(raw), p(u), f, f, p(src), p(g), p(d_raw), st), "bwd")
+    torch.cuda.synchronize()
+    assert float((d_raw - raw.grad).abs().max()) <= 2e-6 * float(raw.grad.abs().max() + 1e-12) + 1e-9
+
+
 def test_fused_step_speculative_capacity_and_overflow(gpu):
     """Sizing the duplicate arrays ahead: the first call learns the count with the exact two-phase forward, later calls
     run without any host synchronisation and give bit-identical results; a count above the capacity sets the device flag
