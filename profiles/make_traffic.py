@@ -1,7 +1,7 @@
 """Builds profiles/traffic_r02.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
 MI355X_MICROARCH.md, "HBM" and the TCC slot table):
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <fetch_dir> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d <write_dir> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <fetch_dir> --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d <write_dir> --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists
     python profiles/make_traffic.py <fetch_dir> <write_dir> [config]
 Unit: the counters are in KiB.  gfx950 correction (same guide): FETCH_SIZE reports half the bytes of wide (16 B per
 lane) coalesced streaming reads, so it is doubled for the kernels whose reads are of that kind (STREAMING below,
@@ -47,7 +47,7 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"_config": sys.argv[3] if len(sys.argv) > 3 else "metric",
            "_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 "
-                      "bench.py --steps 2 --warmup 1 --no-cpu-baseline; see profiles/make_traffic.py",
+                      "bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists; see profiles/make_traffic.py",
            "_unit": "HBM-side bytes per launch = FETCH_SIZE*1024 (x2 for the 16-B/lane streaming kernels: "
                     + ", ".join(sorted(STREAMING)) + ") + WRITE_SIZE*1024",
            "_detail": {}}

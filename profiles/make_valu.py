@@ -1,5 +1,5 @@
 """Builds profiles/valu_r02.json from one rocprofv3 PMC pass:
-    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE -d <dir> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE -d <dir> --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists
     python profiles/make_valu.py <dir>
 """
 import collections, csv, glob, json, os, sys
@@ -10,7 +10,7 @@ for f in files[-1:]:          # the newest pass only
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"_source": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE -- python3 "
-                  "bench.py --steps 2 --warmup 1 --no-cpu-baseline (metric config)",
+                  "bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists (metric config)",
        "_unit": "per launch; GRBM_GUI_ACTIVE is summed over the 8 XCDs; ipc_per_simd = SQ_INSTS_VALU / (1024 SIMDs * "
                 "GRBM_GUI_ACTIVE / 8); tools/valu_rate.hip measures 0.32 (4 waves/SIMD) to 0.37 (8 waves/SIMD) for a "
                 "pure non-packed fp32 stream on this chip"}

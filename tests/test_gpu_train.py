@@ -415,7 +415,7 @@ def test_alignment_kernels_match_the_torch_expression(gpu, f, jitter):
     p = lambda t: None if t is None or t.numel() == 0 else ctypes.c_void_p(t.data_ptr())
     _lib.check(L.dgs_alignment_forward(p(raw), p(u), f, f, p(nu), p(src), st), "fwd")
     torch.cuda.synchronize()
-    assert float((nu - ref).abs().max()) <= 1e-7
+    assert float((nu - ref).detach().abs().max()) <= 1e-7
     assert sorted(src.tolist()) == list(range(f)) and bool((nu[1:] >= nu[:-1]).all())
     if n == 0:
         return
