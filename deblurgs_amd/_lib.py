@@ -74,7 +74,7 @@ class DgsCloudArrays(ctypes.Structure):
 
 
 ADAM_MAX_GROUPS = 16
-ABI_VERSION = 4            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
+ABI_VERSION = 5            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
 
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {
@@ -115,10 +115,10 @@ EXPORTS = {
                                    ctypes.c_void_p]),
     "dgs_densify_tmp_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dgs_densify_plan": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_float] * 4 +
-                         [ctypes.c_void_p] * 6),
+                         [ctypes.c_int32] + [ctypes.c_void_p] * 6),
     "dgs_densify_apply": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 3 +
                           [ctypes.POINTER(DgsCloudArrays), ctypes.POINTER(DgsCloudArrays), ctypes.c_void_p,
-                           ctypes.c_float, ctypes.c_void_p]),
+                           ctypes.c_float, ctypes.c_int32, ctypes.c_void_p]),
     "dgs_knn_tmp_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dgs_knn_mean_dist2": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p]),

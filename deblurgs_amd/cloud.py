@@ -27,13 +27,16 @@ class LowerBoundExponent(nn.Module):
 
 class GaussianCloud(nn.Module):
     def __init__(self, xyz, features_dc, features_rest, scaling, rotation, opacity, sh_degree=2, active_sh_degree=None,
-                 z_near=0.2, z_far=100.0, use_sigmoid=False, scale_lb=0.0, alpha_lower_bound=0.0):
+                 z_near=0.2, z_far=100.0, use_sigmoid=False, scale_lb=0.0, alpha_lower_bound=0.0, use_isotrophic=False):
         super().__init__()
         self.max_sh_degree = sh_degree
         self.active_sh_degree = sh_degree if active_sh_degree is None else active_sh_degree
         self.z_near = z_near
         self.z_far = z_far
         self.use_sigmoid = use_sigmoid
+        # one shared scale per Gaussian: column 0 of _scaling, which stays [P,3] (scene/gaussian_model.py:75,115-118;
+        # the spelling is the reference's)
+        self.use_isotrophic = bool(use_isotrophic)
         self._xyz = nn.Parameter(xyz)
         self._features_dc = nn.Parameter(features_dc)      # [P,1,3]
         self._features_rest = nn.Parameter(features_rest)  # [P,M-1,3]
@@ -66,6 +69,8 @@ class GaussianCloud(nn.Module):
 
     @property
     def get_scaling(self):
+        if self.use_isotrophic:
+            return self.scaling_activation(self._scaling[:, :1].expand(-1, 3))
         return self.scaling_activation(self._scaling)
 
     @property
@@ -93,7 +98,8 @@ class GaussianCloud(nn.Module):
         from . import _lib
         dev = self._xyz.device
         P = self._xyz.shape[0]
-        sc, rot, op = (t.detach().float().contiguous() for t in (self._scaling, self._rotation, self._opacity))
+        raw_sc = self._scaling[:, :1].expand(-1, 3) if self.use_isotrophic else self._scaling
+        sc, rot, op = (t.detach().float().contiguous() for t in (raw_sc, self._rotation, self._opacity))
         o_sc, o_rot, o_op = torch.empty_like(sc), torch.empty_like(rot), torch.empty_like(op)
         _lib.check(_lib.lib().dgs_cloud_activations(P, sc.data_ptr(), rot.data_ptr(), op.data_ptr(),
                                                     float(self.scale_lower_bound), o_sc.data_ptr(), o_rot.data_ptr(),
@@ -241,12 +247,13 @@ class GaussianCloud(nn.Module):
         min_opacity = self.alpha_lower_bound + (1 - self.alpha_lower_bound) * 0.005
         counts, flags, offs = optim.densify_plan(self.xyz_gradient_accum, self.denom, self._scaling.detach(),
                                                  self._opacity.detach(), max_grad, self.percent_dense * extent,
-                                                 min_opacity, self.scale_lower_bound)
+                                                 min_opacity, self.scale_lower_bound, isotropic=self.use_isotrophic)
         if noise is None:
             noise = torch.randn((2 * counts[3], 3), device=self._xyz.device, generator=generator)
         m, v, states = self._moments()
         params = [p.detach().contiguous() for p in self.hot_parameters()]
-        new_p, new_m, new_v = optim.densify_apply(counts, flags, offs, params, m, v, noise, self.scale_lower_bound)
+        new_p, new_m, new_v = optim.densify_apply(counts, flags, offs, params, m, v, noise, self.scale_lower_bound,
+                                                  isotropic=self.use_isotrophic)
         self._install(new_p, new_m, new_v, states)
         dev = self._xyz.device
         Pn = self._xyz.shape[0]

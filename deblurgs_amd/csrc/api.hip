@@ -82,6 +82,8 @@ int check_problem(const DgsProblem* p) {
     return fail(DGS_E_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
   (void)sr;
   if (p->shs != nullptr && p->M < (p->D + 1) * (p->D + 1)) return fail(DGS_E_ARG, "M < (D+1)^2");
+  if (p->raw_params != 0 && p->raw_params != 1 && p->raw_params != 3)
+    return fail(DGS_E_ARG, "raw_params must be 0, 1 or 3 (1 | isotropic scale)");
   if (p->raw_params) {
     if (p->shs == nullptr || p->scales == nullptr || p->rotations == nullptr)
       return fail(DGS_E_ARG, "raw_params needs shs (dc), scales and rotations");
@@ -108,7 +110,8 @@ DgsView make_view(const DgsProblem* p) {
   v.z_far = p->z_far;
   v.use_sigmoid = p->use_sigmoid; v.prefiltered = p->prefiltered;
   v.tile_cull = p->tile_cull != 0;
-  v.raw_params = p->raw_params != 0;
+  v.raw_params = (p->raw_params & 1) != 0;
+  v.iso_scale = (p->raw_params & 2) != 0;
   v.scale_lb = p->scale_lb;
   return v;
 }

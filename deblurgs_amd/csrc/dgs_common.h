@@ -142,7 +142,8 @@ struct DgsView {  // per-launch scalars shared by the kernels
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier, z_far;
   int use_sigmoid, prefiltered;
   int tile_cull;
-  int raw_params;   // kernels apply the cloud's activations (DgsProblem.raw_params)
+  int raw_params;   // kernels apply the cloud's activations (DgsProblem.raw_params bit 0)
+  int iso_scale;    // raw_params bit 1: one shared scale per Gaussian = column 0 of `scales` (use_isotrophic)
   float scale_lb;
 };
 

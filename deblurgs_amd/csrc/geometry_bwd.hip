@@ -67,15 +67,23 @@ contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ status, const uin
   const uint64_t j = t >> 2;
   const uint32_t part = (uint32_t)t & 3u;
   if (j >= n || part == 3u) return;
-  if (tt_visible[j] == 0u) return;  // invisible pair: the geometry kernel never reads its slot
-  const uint32_t nt = tiles[j];
+  // the four index words are requested together (one round trip instead of a chain of three) ...
+  const uint32_t vis = tt_visible[j], nt = tiles[j], off = offsets[j], dst = order[j];
+  if (vis == 0u) return;  // invisible pair: the geometry kernel never reads its slot
   float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (nt > 0) {
-    const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)offsets[j] * DGS_CONTRIB_F) + part;
-    a = cp[0];
-    // rows are added strictly in duplicate order (deterministic); eight rows are requested before the first add so
-    // that the loop is not a chain of dependent HBM round trips
-    uint32_t r = 1;
+    const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)off * DGS_CONTRIB_F) + part;
+    // ... and so are the first four rows of the segment (a pair has ~3 duplicates on average), then eight at a time:
+    // the loop is never a chain of dependent HBM round trips.  Rows are added strictly in duplicate order.
+    float4 q0 = cp[0], q1 = a, q2 = a, q3 = a;
+    if (nt > 1) q1 = cp[3];
+    if (nt > 2) q2 = cp[6];
+    if (nt > 3) q3 = cp[9];
+    a = q0;
+    if (nt > 1) { a.x += q1.x; a.y += q1.y; a.z += q1.z; a.w += q1.w; }
+    if (nt > 2) { a.x += q2.x; a.y += q2.y; a.z += q2.z; a.w += q2.w; }
+    if (nt > 3) { a.x += q3.x; a.y += q3.y; a.z += q3.z; a.w += q3.w; }
+    uint32_t r = 4;
     for (; r + 8 <= nt; r += 8) {
       float4 q[8];
 #pragma unroll
@@ -96,7 +104,7 @@ contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ status, const uin
       a.w += q.w;
     }
   }
-  reinterpret_cast<float4*>(sums + (size_t)order[j] * DGS_CONTRIB_F)[part] = a;
+  reinterpret_cast<float4*>(sums + (size_t)dst * DGS_CONTRIB_F)[part] = a;
 }
 
 template <int MAXC>  // MAXC = SH coefficients held in registers: 1, 4, 9 or 16
@@ -476,6 +484,7 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
       float s0 = scales[3 * idx], s1 = scales[3 * idx + 1], s2 = scales[3 * idx + 2];
       float qd = 1.0f, e0 = 1.0f, e1 = 1.0f, e2 = 1.0f;
       if (v.raw_params) {
+        if (v.iso_scale) s1 = s2 = s0;
         e0 = expf(s0); e1 = expf(s1); e2 = expf(s2);   // d(exp(x) + lb)/dx
         s0 = dgs_act_scale(s0, v.scale_lb);
         s1 = dgs_act_scale(s1, v.scale_lb);
@@ -500,9 +509,17 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
       M3 dL_dM = mul(M2, dSig);
       M3 Rt = tr(R);
       M3 dMt = tr(dL_dM);
-      dL_dscales[3 * idx + 0] = (Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2]) * e0;
-      dL_dscales[3 * idx + 1] = (Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2]) * e1;
-      dL_dscales[3 * idx + 2] = (Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2]) * e2;
+      float ds0 = (Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2]) * e0;
+      float ds1 = (Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2]) * e1;
+      float ds2 = (Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2]) * e2;
+      if (v.iso_scale) {  // expand(-1, 3) backward: the three columns' gradients land on column 0
+        ds0 = (ds0 + ds1) + ds2;
+        ds1 = 0.0f;
+        ds2 = 0.0f;
+      }
+      dL_dscales[3 * idx + 0] = ds0;
+      dL_dscales[3 * idx + 1] = ds1;
+      dL_dscales[3 * idx + 2] = ds2;
 #pragma unroll
       for (int rr = 0; rr < 3; rr++) {
         dMt.m[0][rr] *= sx;

@@ -82,13 +82,13 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(AdamArgs a) {
 __global__ void __launch_bounds__(256)
 densify_flags_kernel(int P, const float* __restrict__ accum, const float* __restrict__ denom,
                      const float* __restrict__ scaling, const float* __restrict__ opacity, float grad_thr,
-                     float size_thr, float min_opacity, float scale_lb, uint32_t* __restrict__ flags) {
+                     float size_thr, float min_opacity, float scale_lb, int iso, uint32_t* __restrict__ flags) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   float g = accum[i] / denom[i];            // gaussian_model.py:437-438
   if (g != g) g = 0.0f;
-  const float s0 = expf(scaling[3 * i]) + scale_lb, s1 = expf(scaling[3 * i + 1]) + scale_lb,
-              s2 = expf(scaling[3 * i + 2]) + scale_lb;
+  const float s0 = expf(scaling[3 * i]) + scale_lb, s1 = iso ? s0 : expf(scaling[3 * i + 1]) + scale_lb,
+              s2 = iso ? s0 : expf(scaling[3 * i + 2]) + scale_lb;
   const float smax = fmaxf(s0, fmaxf(s1, s2));
   const bool clone_sel = (fabsf(g) >= grad_thr) && (smax <= size_thr);   // :421-424
   const bool split_sel = (g >= grad_thr) && (smax > size_thr);           // :394-399
@@ -127,7 +127,7 @@ __device__ __forceinline__ void field_of(int e, int n_rest, int& f, int& off, in
 __global__ void __launch_bounds__(256)
 densify_apply_kernel(int P, int n_rest, uint32_t n_keep, uint32_t n_clone, uint32_t n_split, uint32_t m_all,
                      const uint32_t* __restrict__ flags, const uint32_t* __restrict__ offs, CloudPtrs src,
-                     CloudPtrs dst, const float* __restrict__ noise, float scale_lb) {
+                     CloudPtrs dst, const float* __restrict__ noise, float scale_lb, int iso) {
   const int E = 14 + n_rest;
   const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (tid >= (uint64_t)P * E) return;
@@ -155,7 +155,8 @@ densify_apply_kernel(int P, int n_rest, uint32_t n_keep, uint32_t n_clone, uint3
       float out = val;
       if (f == 0 || f == 4) {
         const float* sc = src.t[4] + 3 * (size_t)i;
-        const float s0 = expf(sc[0]) + scale_lb, s1 = expf(sc[1]) + scale_lb, s2 = expf(sc[2]) + scale_lb;
+        const float s0 = expf(sc[0]) + scale_lb, s1 = iso ? s0 : expf(sc[1]) + scale_lb,
+                    s2 = iso ? s0 : expf(sc[2]) + scale_lb;   // get_scaling: column 0 for all three when isotropic
         if (f == 4) {
           // scaling_inverse_activation(get_scaling / (0.8 N)), N = 2 (:405; LowerBoundLog clamps at eps = 0.001)
           const float s = (off == 0 ? s0 : off == 1 ? s1 : s2) / 1.6f;
@@ -237,8 +238,8 @@ size_t dgs_densify_tmp_bytes(int32_t P) { return dgs_scan_tmp_words((uint64_t)(P
 
 int dgs_densify_plan(int32_t P, const float* xyz_gradient_accum, const float* denom, const float* scaling,
                      const float* opacity, float grad_threshold, float size_threshold, float min_opacity,
-                     float scale_lb, uint32_t* flags, uint32_t* offsets, uint32_t* counts_dev, uint32_t* counts_host,
-                     void* tmp, dgs_stream_t stream) {
+                     float scale_lb, int32_t isotropic, uint32_t* flags, uint32_t* offsets, uint32_t* counts_dev,
+                     uint32_t* counts_host, void* tmp, dgs_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (P < 0 || counts_host == nullptr) return dgs_fail_arg("densify_plan: bad argument");
   if (P == 0) {
@@ -249,7 +250,7 @@ int dgs_densify_plan(int32_t P, const float* xyz_gradient_accum, const float* de
       flags == nullptr || offsets == nullptr || counts_dev == nullptr || tmp == nullptr)
     return dgs_fail_arg("densify_plan: null pointer");
   hipLaunchKernelGGL(densify_flags_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, xyz_gradient_accum, denom, scaling,
-                     opacity, grad_threshold, size_threshold, min_opacity, scale_lb, flags);
+                     opacity, grad_threshold, size_threshold, min_opacity, scale_lb, isotropic != 0 ? 1 : 0, flags);
   hipError_t e = hipGetLastError();
   for (int a = 0; a < 4 && e == hipSuccess; a++) {
     // counts_dev[2a], [2a+1] = the 64-bit total of flag array a
@@ -263,7 +264,7 @@ int dgs_densify_plan(int32_t P, const float* xyz_gradient_accum, const float* de
 
 int dgs_densify_apply(int32_t P, int32_t n_rest, const uint32_t* counts, const uint32_t* flags, const uint32_t* offsets,
                       const DgsCloudArrays* src, const DgsCloudArrays* dst, const float* noise, float scale_lb,
-                      dgs_stream_t stream) {
+                      int32_t isotropic, dgs_stream_t stream) {
   if (P < 0 || n_rest < 0 || counts == nullptr || src == nullptr || dst == nullptr)
     return dgs_fail_arg("densify_apply: bad argument");
   if (P == 0) return DGS_OK;
@@ -284,7 +285,7 @@ int dgs_densify_apply(int32_t P, int32_t n_rest, const uint32_t* counts, const u
   const uint64_t threads = (uint64_t)P * (14 + n_rest);
   hipLaunchKernelGGL(densify_apply_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), P, n_rest, counts[0], counts[1], counts[2], counts[3], flags,
-                     offsets, sp, dp, noise, scale_lb);
+                     offsets, sp, dp, noise, scale_lb, isotropic != 0 ? 1 : 0);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? DGS_OK : dgs_fail_hip(e, "densify_apply");
 }

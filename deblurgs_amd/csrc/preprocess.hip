@@ -78,6 +78,7 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
     float s0 = scales[3 * idx], s1 = scales[3 * idx + 1], s2 = scales[3 * idx + 2];
     float r = rotations[4 * idx], x = rotations[4 * idx + 1], y = rotations[4 * idx + 2], z = rotations[4 * idx + 3];
     if (v.raw_params) {
+      if (v.iso_scale) s1 = s2 = s0;   // get_scaling of an isotropic cloud (scene/gaussian_model.py:115-118)
       s0 = dgs_act_scale(s0, v.scale_lb);
       s1 = dgs_act_scale(s1, v.scale_lb);
       s2 = dgs_act_scale(s2, v.scale_lb);

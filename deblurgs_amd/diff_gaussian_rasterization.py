@@ -92,7 +92,7 @@ def _make_problem(K, means3D, sh, colors_precomp, opacities, scales, rotations, 
                   rs, geom, image, binning, tile_cull, raw=None):
     p = _lib.DgsProblem()
     p.tile_cull = int(bool(tile_cull))
-    p.raw_params = 0 if raw is None else 1
+    p.raw_params = 0 if raw is None else (3 if raw.get("isotropic") else 1)
     p.scale_lb = 0.0 if raw is None else float(raw["scale_lb"])
     p.shs_rest = None if raw is None else _ptr(raw["sh_rest"])
     p.P = means3D.shape[0]
@@ -139,7 +139,7 @@ class _RS:
 
 def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm, campos,
                   raster_settings, raw=None):
-    """raw = {"scale_lb": float, "sh_rest": [P,M-1,3] or None}: the inputs are the cloud's raw parameters
+    """raw = {"scale_lb": float, "sh_rest": [P,M-1,3] or None, "isotropic": bool}: the inputs are the cloud's raw parameters
     (DgsProblem.raw_params) and sh is the dc part [P,1,3]."""
     L = _lib.lib()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
@@ -396,7 +396,7 @@ class _RasterizeCloudK(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, viewmatrices, projmatrices,
-                raster_settings, scale_lb):
+                raster_settings, scale_lb, isotropic=False):
         m3, dc, opc, scc, rotc = (_f32c(t) for t in (xyz, f_dc, opacity, scaling, rotation))
         rest = _f32c(f_rest) if f_rest is not None and f_rest.shape[1] > 0 else None
         viewm, projm = _f32c(viewmatrices), _f32c(projmatrices)
@@ -404,7 +404,8 @@ class _RasterizeCloudK(torch.autograd.Function):
         campos = _f32c(raster_settings.campos.to(m3.device)).reshape(-1, 3)
         if viewm.shape != (K, 4, 4) or projm.shape != (K, 4, 4) or campos.shape[0] != K:
             raise RuntimeError("viewmatrices / projmatrices must be [K,4,4] and raster_settings.campos [K,3]")
-        raw = {"scale_lb": float(scale_lb), "sh_rest": rest}
+        raw = {"scale_lb": float(scale_lb), "sh_rest": rest, "isotropic": bool(isotropic)}
+        ctx.isotropic = bool(isotropic)
         num_rendered, color, depth, radii, geom, binning, img = _forward_impl(
             K, m3, dc.reshape(-1, 1, 3), None, opc.reshape(-1), scc, rotc, None, viewm, projm, campos, raster_settings,
             raw=raw)
@@ -423,7 +424,7 @@ class _RasterizeCloudK(torch.autograd.Function):
         m3, dc, rest, opc, scc, rotc, radii, geom, binning, img, viewm, projm, campos = ctx.saved_tensors
         rest = None if rest.numel() == 0 else rest
         if grad_out_color is None and grad_out_depth is None:
-            return (None,) * 11
+            return (None,) * 12
         H, W = int(rs.image_height), int(rs.image_width)
         device = m3.device
         if grad_out_color is None:
@@ -457,7 +458,7 @@ class _RasterizeCloudK(torch.autograd.Function):
         io.dL_dcov3D, io.dL_dviewmatrix, io.dL_dprojmatrix = _ptr(g_cov3D), _ptr(g_view), _ptr(g_proj)
         prob = _make_problem(K, m3, dc, None, opc.reshape(-1), scc, rotc, None, viewm, projm, campos, _RS(rs, device),
                              geom, img, binning, getattr(R, "tile_cull", False),
-                             raw={"scale_lb": ctx.scale_lb, "sh_rest": rest})
+                             raw={"scale_lb": ctx.scale_lb, "sh_rest": rest, "isotropic": ctx.isotropic})
         prob.M = 1 + Mr
         _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), _stream(device)), "dgs_backward")
         if P == 0:
@@ -467,13 +468,15 @@ class _RasterizeCloudK(torch.autograd.Function):
         g_rest_out = g_rest.view(rest_shape) if g_rest is not None else (
             None if rest_shape is None else flat.new_empty(rest_shape))
         return (g_xyz, g_means2D, g_dc.view(dc_shape), g_rest_out,
-                g_op.view(op_shape), g_sc, g_rot, g_view, g_proj, None, None)
+                g_op.view(op_shape), g_sc, g_rot, g_view, g_proj, None, None, None)
 
 
 def rasterize_cloud_subframes(xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, viewmatrices, projmatrices,
-                              raster_settings, scale_lb=0.0):
+                              raster_settings, scale_lb=0.0, isotropic=False):
+    """isotropic: the cloud has one shared scale per Gaussian, column 0 of `scaling` (use_isotrophic,
+    scene/gaussian_model.py:115-118); the gradient of `scaling` then has zeros in columns 1 and 2."""
     return _RasterizeCloudK.apply(xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, viewmatrices, projmatrices,
-                                  raster_settings, scale_lb)
+                                  raster_settings, scale_lb, bool(isotropic))
 
 
 class GaussianRasterizer(nn.Module):

@@ -154,7 +154,8 @@ class FusedStep:
         prob.tanfovx, prob.tanfovy = math.tan(m.ref_cam.FoVx * 0.5), math.tan(m.ref_cam.FoVy * 0.5)
         prob.scale_modifier, prob.z_near, prob.z_far = 1.0, float(cloud.z_near), float(cloud.z_far)
         prob.use_sigmoid, prob.prefiltered, prob.debug = int(bool(cloud.use_sigmoid)), 0, 0
-        prob.tile_cull, prob.raw_params, prob.scale_lb = int(cull), 1, float(cloud.scale_lower_bound)
+        prob.tile_cull, prob.scale_lb = int(cull), float(cloud.scale_lower_bound)
+        prob.raw_params = 3 if getattr(cloud, "use_isotrophic", False) else 1
         prob.means3D, prob.shs, prob.shs_rest = _ptr(cloud._xyz), _ptr(cloud._features_dc), _ptr(rest)
         prob.opacities, prob.scales, prob.rotations = _ptr(cloud._opacity), _ptr(cloud._scaling), _ptr(cloud._rotation)
         prob.viewmatrix, prob.projmatrix, prob.campos, prob.bg = _ptr(view), _ptr(full), _ptr(campos), _ptr(bg)

@@ -103,7 +103,8 @@ def render_subframes(world_views, full_projs, camera_centers, ref_camera, pc, bg
         # the kernels, forward and backward: no getter launches, gradients land on the raw parameters directly
         images, depths, radii = rasterize_cloud_subframes(
             pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation,
-            world_views, full_projs, raster_settings, pc.scale_lower_bound)
+            world_views, full_projs, raster_settings, pc.scale_lower_bound,
+            isotropic=getattr(pc, "use_isotrophic", False))
         return {"render": images, "depth": depths, "viewspace_points": screenspace_points,
                 "visibility_filter": radii > 0, "radii": radii}
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)

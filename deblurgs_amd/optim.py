@@ -95,8 +95,10 @@ def _counts_buffer(device):
 
 
 @torch.no_grad()
-def densify_plan(xyz_gradient_accum, denom, scaling, opacity, grad_threshold, size_threshold, min_opacity, scale_lb):
-    """Returns (counts [n_keep, n_clone, n_split, m_all], flags u32 [4,P], offsets u32 [4,P])."""
+def densify_plan(xyz_gradient_accum, denom, scaling, opacity, grad_threshold, size_threshold, min_opacity, scale_lb,
+                 isotropic=False):
+    """Returns (counts [n_keep, n_clone, n_split, m_all], flags u32 [4,P], offsets u32 [4,P]).
+    isotropic: get_scaling = activation of column 0 for all three axes (use_isotrophic clouds)."""
     device = scaling.device
     P = scaling.shape[0]
     L = _lib.lib()
@@ -109,14 +111,14 @@ def densify_plan(xyz_gradient_accum, denom, scaling, opacity, grad_threshold, si
     acc, den, sc, op = c(xyz_gradient_accum), c(denom), c(scaling), c(opacity)
     _lib.check(L.dgs_densify_plan(P, acc.data_ptr(), den.data_ptr(), sc.data_ptr(), op.data_ptr(),
                                   float(grad_threshold), float(size_threshold), float(min_opacity), float(scale_lb),
-                                  flags.data_ptr(), offs.data_ptr(), counts_dev.data_ptr(), host.data_ptr(),
+                                  int(bool(isotropic)), flags.data_ptr(), offs.data_ptr(), counts_dev.data_ptr(), host.data_ptr(),
                                   tmp.data_ptr(), _stream(device)), "dgs_densify_plan")
     torch.cuda.current_stream(device).synchronize()
     return [int(x) & 0xFFFFFFFF for x in host.tolist()], flags, offs
 
 
 @torch.no_grad()
-def densify_apply(counts, flags, offs, params, exp_avgs, exp_avg_sqs, noise, scale_lb):
+def densify_apply(counts, flags, offs, params, exp_avgs, exp_avg_sqs, noise, scale_lb, isotropic=False):
     """params: the six raw tensors in FIELDS order; exp_avgs / exp_avg_sqs: their moments (None = no state).
     Returns (new_params, new_exp_avgs, new_exp_avg_sqs) with n_keep + n_clone + 2 n_split rows."""
     device = params[0].device
@@ -145,5 +147,5 @@ def densify_apply(counts, flags, offs, params, exp_avgs, exp_avg_sqs, noise, sca
     _lib.check(_lib.lib().dgs_densify_apply(P, n_rest, ctypes.cast(carr, ctypes.c_void_p), flags.data_ptr(),
                                             offs.data_ptr(), ctypes.byref(src), ctypes.byref(dst),
                                             None if noise is None else noise.data_ptr(), float(scale_lb),
-                                            _stream(device)), "dgs_densify_apply")
+                                            int(bool(isotropic)), _stream(device)), "dgs_densify_apply")
     return new_p, new_m, new_v

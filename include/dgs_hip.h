@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 4
+#define DGS_ABI_VERSION 5
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -65,7 +65,10 @@ typedef struct DgsProblem {
                         *    kernels apply the reference's activations themselves (scene/gaussian_model.py:36-50,
                         *    scene/gaussian_activation.py): opacity clamp(x, 0, 1), scale exp(x) + scale_lb, rotation
                         *    x / max(|x|, 1e-12), SH = [shs (dc, [P,1,3]) | shs_rest ([P,M-1,3])]; the backward then
-                        *    returns gradients with respect to the raw parameters. */
+                        *    returns gradients with respect to the raw parameters.  3 (= 1 | 2): the same with ONE shared
+                        *    scale per Gaussian, column 0 of `scales` used for all three axes (use_isotrophic,
+                        *    scene/gaussian_model.py:115-118); dL_dscales then carries the summed gradient in column 0
+                        *    and zeros in columns 1, 2. */
   float scale_lb;
   /* inputs, device pointers, fp32 contiguous */
   const float* means3D;        /* [P,3] */
@@ -266,16 +269,18 @@ size_t dgs_densify_tmp_bytes(int32_t P);
  * async copy: {n_keep, n_clone, n_split, m_all}.  The new cloud has n_keep + n_clone + 2 n_split Gaussians. */
 int dgs_densify_plan(int32_t P, const float* xyz_gradient_accum, const float* denom, const float* scaling,
                      const float* opacity, float grad_threshold, float size_threshold, float min_opacity,
-                     float scale_lb, uint32_t* flags, uint32_t* offsets, uint32_t* counts_dev, uint32_t* counts_host,
-                     void* tmp, dgs_stream_t stream);
+                     float scale_lb, int32_t isotropic, uint32_t* flags, uint32_t* offsets, uint32_t* counts_dev,
+                     uint32_t* counts_host, void* tmp, dgs_stream_t stream);
 /* apply: writes the new cloud in the reference's order [surviving originals | clones | children copy 0 | children
  * copy 1]; clones and children get zero Adam moments; a child is xyz + R(rotation) (std * z), scaling
  * log(max(std / 1.6 - scale_lb, 0.001)) with std = exp(scaling) + scale_lb, and z = noise[c * m_all + rank] the
  * caller's standard-normal samples [2 m_all, 3] (the reference draws torch.normal(0, stds) for every selected
- * Gaussian and copy before the opacity prune).  counts = the host copy {n_keep, n_clone, n_split, m_all}. */
+ * Gaussian and copy before the opacity prune).  isotropic != 0 (both calls): std = exp(scaling[:, 0]) + scale_lb for all
+ * three axes (use_isotrophic clouds): size test, child offsets and all three child scaling columns use it; survivors
+ * and clones copy the raw rows unchanged.  counts = the host copy {n_keep, n_clone, n_split, m_all}. */
 int dgs_densify_apply(int32_t P, int32_t n_rest, const uint32_t* counts, const uint32_t* flags, const uint32_t* offsets,
                       const DgsCloudArrays* src, const DgsCloudArrays* dst, const float* noise, float scale_lb,
-                      dgs_stream_t stream);
+                      int32_t isotropic, dgs_stream_t stream);
 
 /* ---- initialisation: mean squared distance to the 3 nearest neighbours -------------------------
  * Replaces simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26, simple_knn.cu:138-221), which

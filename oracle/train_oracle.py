@@ -37,14 +37,17 @@ def build_rotation(r):
     return R
 
 
-def densify_and_prune(params, m, v, accum, denom, max_grad, extent, percent_dense, noise, scale_lb=0.0, alpha_lb=0.0):
+def densify_and_prune(params, m, v, accum, denom, max_grad, extent, percent_dense, noise, scale_lb=0.0, alpha_lb=0.0,
+                      isotropic=False):
     """params / m / v: dicts over FIELDS (m / v may be None = no optimiser state).  noise: [2 m_sel, 3] unit normals in
     the reference's draw order (copy-major).  Returns (params, m, v) of the new cloud."""
     params = {k: np.asarray(a, f32) for k, a in params.items()}
     has = m is not None
     m = {k: np.asarray(a, f32) for k, a in m.items()} if has else {k: np.zeros_like(a) for k, a in params.items()}
     v = {k: np.asarray(a, f32) for k, a in v.items()} if has else {k: np.zeros_like(a) for k, a in params.items()}
-    get_scaling = lambda: np.exp(params["scaling"]) + f32(scale_lb)
+    # get_scaling (scene/gaussian_model.py:114-119): column 0 expanded to three when use_isotrophic
+    raw_scaling = lambda: np.repeat(params["scaling"][:, :1], 3, 1) if isotropic else params["scaling"]
+    get_scaling = lambda: np.exp(raw_scaling()) + f32(scale_lb)
     with np.errstate(all="ignore"):
         grads = (np.asarray(accum, f32) / np.asarray(denom, f32)).reshape(-1)
     grads[np.isnan(grads)] = 0.0

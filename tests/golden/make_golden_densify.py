@@ -80,12 +80,14 @@ def main():
     spec.loader.exec_module(gm)
 
     out = {}
-    for case, (scale_lb, alpha_lb, seed) in {"a": (0.0, 0.0, 0), "b": (0.002, 0.01, 1)}.items():
+    # case c: use_isotrophic (one shared scale per Gaussian = column 0 of _scaling, scene/gaussian_model.py:115-118)
+    for case, (scale_lb, alpha_lb, seed, iso) in {"a": (0.0, 0.0, 0, False), "b": (0.002, 0.01, 1, False),
+                                                  "c": (0.001, 0.0, 2, True)}.items():
         rng = np.random.default_rng(seed)
         torch.manual_seed(seed)
         P, M = 400, 9
         margs = types.SimpleNamespace(sh_degree=2, z_near=0.2, z_far=100.0, alpha_lower_bound=alpha_lb, scale_lb=scale_lb,
-                                      scale_ub=-1.0, use_isotrophic=False, activation="relu")
+                                      scale_ub=-1.0, use_isotrophic=iso, activation="relu")
         targs = types.SimpleNamespace(iterations=150_000, position_lr_init=0.00016, position_lr_final=0.0000016,
                                       feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001,
                                       percent_dense=0.01)
@@ -120,6 +122,13 @@ def main():
                 g.optimizer.step()
                 g.optimizer.zero_grad(set_to_none=True)
             after_adam = {n: p.detach().numpy().copy() for n, p in params0.items()}
+            # what the rasteriser is fed, and how a gradient on it reaches the raw parameter (autograd of the getter)
+            act = g.get_scaling
+            up = f32(np.random.default_rng(seed + 100).normal(0, 1, tuple(act.shape)).astype(np.float32))
+            (act * up).sum().backward()
+            get_scaling, get_scaling_up, get_scaling_grad = (act.detach().numpy().copy(), up.numpy().copy(),
+                                                              g._scaling.grad.numpy().copy())
+            g._scaling.grad = None
             m_adam = {n: g.optimizer.state[p]["exp_avg"].numpy().copy() for n, p in params0.items()}
             v_adam = {n: g.optimizer.state[p]["exp_avg_sq"].numpy().copy() for n, p in params0.items()}
             # densification statistics: accum / denom with zeros (NaN), large and small ratios
@@ -154,6 +163,9 @@ def main():
             out[pre + "out_v_" + n] = v_after[n]
         out[pre + "accum"], out[pre + "denom"], out[pre + "noise"] = accum, denom, z.astype(np.float32)
         out[pre + "step_after"] = np.array(step_after)
+        out[pre + "iso"] = np.array(int(iso))
+        out[pre + "get_scaling"], out[pre + "get_scaling_up"], out[pre + "get_scaling_grad"] = (
+            get_scaling, get_scaling_up, get_scaling_grad)
         out[pre + "opacity_reset"], out[pre + "opacity_reset_m"] = op_reset, m_op_reset
         print(case, "P", P, "->", after["xyz"].shape[0], "split draws", z.shape[0])
     np.savez_compressed(os.path.join(HERE, "densify_golden.npz"), **out)

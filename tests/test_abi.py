@@ -129,8 +129,8 @@ def test_argument_checks_of_the_training_side_entry_points_need_no_gpu():
     assert L.dgs_knn_mean_dist2(0, None, None, None, None) == 0
     assert L.dgs_knn_tmp_bytes(1000) > 1000 * 40
     assert L.dgs_densify_tmp_bytes(1000) >= 256
-    assert L.dgs_densify_plan(5, None, None, None, None, 0.0, 0.0, 0.0, 0.0, None, None, None, None, None, None) != 0
-    assert L.dgs_densify_apply(-1, 0, None, None, None, None, None, None, 0.0, None) != 0
+    assert L.dgs_densify_plan(5, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0, None, None, None, None, None, None) != 0
+    assert L.dgs_densify_apply(-1, 0, None, None, None, None, None, None, 0.0, 0, None) != 0
     p = _lib.DgsProblem()
     p.P, p.W, p.H, p.K, p.D, p.M = 10, 32, 32, 1, 0, 1
     for name in ("means3D", "opacities", "shs", "viewmatrix", "projmatrix", "campos", "bg"):

@@ -21,12 +21,13 @@ def _targs(**kw):
     return types.SimpleNamespace(**d)
 
 
-def _cloud_from(arrs, scale_lb=0.0, alpha_lb=0.0):
+def _cloud_from(arrs, scale_lb=0.0, alpha_lb=0.0, iso=False):
     import torch
     from deblurgs_amd.cloud import GaussianCloud
     t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
     return GaussianCloud(t(arrs["xyz"]), t(arrs["f_dc"]), t(arrs["f_rest"]), t(arrs["scaling"]), t(arrs["rotation"]),
-                         t(arrs["opacity"]), sh_degree=2, scale_lb=scale_lb, alpha_lower_bound=alpha_lb)
+                         t(arrs["opacity"]), sh_degree=2, scale_lb=scale_lb, alpha_lower_bound=alpha_lb,
+                         use_isotrophic=iso)
 
 
 @pytest.mark.parametrize("clip", [0.0, 0.004])
@@ -68,13 +69,13 @@ def test_fused_adam_matches_torch_adam(gpu, clip):
         assert np.allclose(sa["exp_avg_sq"].cpu().numpy(), sb["exp_avg_sq"].cpu().numpy(), rtol=ADAM_RTOL, atol=1e-12), n
 
 
-@pytest.mark.parametrize("case", ["a", "b"])
+@pytest.mark.parametrize("case", ["a", "b", "c"])
 def test_training_side_against_reference_model_vectors(gpu, case):
     """training_setup -> 3 fused Adam steps -> densify_and_prune -> reset_opacity, every stage against what the
-    reference's GaussianModel produced from the same inputs, gradients and normal draws."""
+    reference's GaussianModel produced from the same inputs, gradients and normal draws (case c: use_isotrophic)."""
     import torch
     scale_lb, alpha_lb, max_grad, extent, pd, lr_scale = G[f"{case}_cfg"]
-    cloud = _cloud_from({n: G[f"{case}_in_{n}"] for n in to.FIELDS}, scale_lb, alpha_lb)
+    cloud = _cloud_from({n: G[f"{case}_in_{n}"] for n in to.FIELDS}, scale_lb, alpha_lb, iso=bool(G[f"{case}_iso"]))
     cloud.training_setup(_targs(percent_dense=pd), spatial_lr_scale=lr_scale)
     for it in range(3):
         for n, p in cloud._named().items():
@@ -85,6 +86,14 @@ def test_training_side_against_reference_model_vectors(gpu, case):
         assert np.allclose(p.detach().cpu().numpy(), G[f"{case}_adam_{n}"], rtol=ADAM_RTOL, atol=1e-7), n
         st = cloud.optimizer.state[p]
         assert np.allclose(st["exp_avg"].cpu().numpy(), G[f"{case}_adam_m_{n}"], rtol=ADAM_RTOL, atol=3e-9), n
+    # the reference's getter and its autograd on the post-Adam parameters: torch getter, and the kernels' activation
+    up = torch.tensor(G[f"{case}_get_scaling_up"], device="cuda")
+    act = cloud.get_scaling
+    assert np.allclose(act.detach().cpu().numpy(), G[f"{case}_get_scaling"], rtol=ADAM_RTOL * 4, atol=1e-7)
+    (act * up).sum().backward()
+    assert np.allclose(cloud._scaling.grad.cpu().numpy(), G[f"{case}_get_scaling_grad"], rtol=1e-5, atol=1e-7)
+    cloud._scaling.grad = None
+    assert np.allclose(cloud.device_activations()[0].cpu().numpy(), G[f"{case}_get_scaling"], rtol=ADAM_RTOL * 4, atol=1e-7)
     # continue from the reference's own post-Adam state so that the densification comparison can be exact
     for n, p in cloud._named().items():
         p.data.copy_(torch.tensor(G[f"{case}_adam_{n}"]))
@@ -265,8 +274,9 @@ def test_training_loop_with_densification_and_fused_adam(gpu):
     assert min(hist[-5:]) < 0.6 * max(hist[4:9]), (hist[4:9], hist[-5:])
 
 
-@pytest.mark.parametrize("deg,scale_lb", [(2, 0.0), (2, 0.003), (0, 0.0), (3, 0.0)])
-def test_fused_activations_equal_the_getter_path(gpu, deg, scale_lb):
+@pytest.mark.parametrize("deg,scale_lb,iso", [(2, 0.0, False), (2, 0.003, False), (0, 0.0, False), (3, 0.0, False),
+                                              (2, 0.003, True)])
+def test_fused_activations_equal_the_getter_path(gpu, deg, scale_lb, iso):
     """render_subframes() with the cloud's activations folded into the kernels (DgsProblem.raw_params) against the
     reference's arrangement (get_opacity / get_scaling / get_rotation / get_features evaluated by torch, their
     backward by autograd): same images, same gradients on the RAW parameters, including clamped opacities (zero
@@ -289,6 +299,7 @@ def test_fused_activations_equal_the_getter_path(gpu, deg, scale_lb):
         cloud = GaussianCloud.from_scene(sc, "cuda")
         cloud.scaling_activation.lower_bound = scale_lb
         cloud.scale_lower_bound = scale_lb
+        cloud.use_isotrophic = iso       # column 0 of _scaling for all three axes; columns 1, 2 get no gradient
         with torch.no_grad():
             cloud._rotation.mul_(t(rng.uniform(0.3, 3.0, (sc["P"], 1)).astype(np.float32)) if fused is False else 1.0)
             cloud._opacity[::7] = 1.2          # clamped from above
@@ -314,9 +325,16 @@ def test_fused_activations_equal_the_getter_path(gpu, deg, scale_lb):
     names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
     for n, ga, gb in zip(names, a["g"], b["g"]):
         assert ga.shape == gb.shape, n
+        if iso and n == "rotation":
+            # an isotropic covariance does not depend on the rotation: both gradients are rounding residue
+            ref_mag = np.abs(a["g"][4]).max()
+            assert np.abs(ga).max() <= 1e-4 * ref_mag and np.abs(gb).max() <= 1e-4 * ref_mag, (np.abs(ga).max(), ref_mag)
+            continue
         if ga.size:
             assert np.abs(ga - gb).max() <= 2e-5 * (np.abs(ga).max() + 1e-30), (n, np.abs(ga - gb).max(), np.abs(ga).max())
     assert not b["g"][3][::7].any() and not b["g"][3][3::11].any()      # clamp: no gradient outside [0, 1]
+    if iso:
+        assert not b["g"][4][:, 1:].any() and b["g"][4][:, 0].any()
     for key in ("view", "proj", "m2d"):
         assert np.abs(a[key] - b[key]).max() <= 2e-5 * np.abs(a[key]).max(), key
 
@@ -344,8 +362,8 @@ def _fused_fixture(seed=3, K=5, P=3000):
     return sc, cloud, m
 
 
-@pytest.mark.parametrize("subframes", ["all", 3, 1])
-def test_fused_step_equals_autograd_path(gpu, subframes):
+@pytest.mark.parametrize("subframes,iso", [("all", False), (3, False), (1, False), ("all", True)])
+def test_fused_step_equals_autograd_path(gpu, subframes, iso):
     """deblurgs_amd.fused_step.FusedStep (the iteration's device work through the C ABI, no autograd) against the autograd
     path it replaces -- CameraMotionModule.query + losses.blur_l1_smooth + lambda_hinge * hinge_l2, loss.backward():
     same subframes bit for bit, same loss values, the same gradients on the cloud (rasteriser part bit-identical, the
@@ -354,6 +372,7 @@ def test_fused_step_equals_autograd_path(gpu, subframes):
     from deblurgs_amd import losses
     from deblurgs_amd.fused_step import FusedStep
     sc, cloud, m = _fused_fixture()
+    cloud.use_isotrophic = iso
     lam_t, lam_h, cam = 2e-3, 0.1, 1
     bg = torch.tensor([0.2, 0.5, 0.1], device="cuda")
     params = list(cloud.hot_parameters()) + list(m.parameters())
