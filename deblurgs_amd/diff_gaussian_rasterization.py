@@ -138,9 +138,12 @@ class _RS:
 
 
 def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm, campos,
-                  raster_settings, raw=None):
+                  raster_settings, raw=None, capacity=None):
     """raw = {"scale_lb": float, "sh_rest": [P,M-1,3] or None, "isotropic": bool}: the inputs are the cloud's raw parameters
-    (DgsProblem.raw_params) and sh is the dc part [P,1,3]."""
+    (DgsProblem.raw_params) and sh is the dc part [P,1,3].
+    capacity: size the duplicate arrays for that many duplicates up front and run the one-call dgs_forward (no host
+    read between the phases; what fused_step.FusedStep does every iteration).  The returned count then carries
+    `.capacity` (the binning blob is laid out for it) and `.overflow`."""
     L = _lib.lib()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:60-62
@@ -166,6 +169,16 @@ def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, 
                          campos, rs, geom, image, None, tile_cull, raw)
     if raw is not None:
         prob.M = 1 + (0 if raw["sh_rest"] is None else raw["sh_rest"].shape[1])
+    if capacity is not None:
+        binning = torch.empty(L.dgs_binning_state_bytes(int(capacity), W, H, K), dtype=torch.uint8, device=device)
+        prob.binning_state = _ptr(binning)
+        prob.binning_bytes = binning.numel()
+        _lib.check(L.dgs_forward(ctypes.byref(prob), ctypes.byref(out), int(capacity), stream), "dgs_forward")
+        torch.cuda.current_stream(device).synchronize()
+        R = _NumRendered(int(host_R[3].item()) & 0xFFFFFFFF)
+        R.tile_cull, R.capacity, R.overflow = tile_cull, int(capacity), bool(int(host_R[2].item()))
+        R.counted = int(host_R[0].item()) & 0xFFFFFFFF
+        return R, color, depth, radii, geom, binning, image
     _lib.check(L.dgs_forward_geometry(ctypes.byref(prob), ctypes.byref(out), stream), "dgs_forward_geometry")
     torch.cuda.current_stream(device).synchronize()   # the one host read of num_rendered (rasterizer_impl.cu:287)
     if int(host_R[1].item()) != 0:

@@ -104,15 +104,16 @@ def tile_cull(flag):
 
 
 def hip_forward_state(scene, K, sh_degree=None, use_sigmoid=False, colors_precomp=None, cov3D_precomp=None,
-                      scale_modifier=1.0, cull=False):
+                      scale_modifier=1.0, cull=False, capacity=None):
     """Runs the fused forward through the C ABI and returns outputs + every saved sub-array as numpy.  cull=False
     (default) keeps the reference's duplicate lists so that keys / point_list / ranges compare bit for bit; with
     cull=True the low key word is the duplicate's emission index instead of the depth bits."""
     with tile_cull(cull):
-        return _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_precomp, scale_modifier)
+        return _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_precomp, scale_modifier,
+                                  capacity)
 
 
-def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_precomp, scale_modifier):
+def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_precomp, scale_modifier, capacity=None):
     import torch
     from deblurgs_amd import _lib
     from deblurgs_amd import diff_gaussian_rasterization as dgr
@@ -125,12 +126,14 @@ def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_p
     cov = None if cov3D_precomp is None else _t(cov3D_precomp)
     R, color, depth, radii, geom, binning, image = dgr._forward_impl(
         K, _t(scene["means3D"]), sh, col, _t(scene["opacities"]).reshape(-1), sc, rot, cov,
-        _t(scene["viewmatrix"][:K]), _t(scene["projmatrix"][:K]), _t(scene["campos"][:K]), rs)
+        _t(scene["viewmatrix"][:K]), _t(scene["projmatrix"][:K]), _t(scene["campos"][:K]), rs, capacity=capacity)
     torch.cuda.synchronize()
     P, W, H = scene["P"], scene["W"], scene["H"]
     N = W * H
     T = ((W + 15) // 16) * ((H + 15) // 16)
-    L = _lib.layout(P, W, H, K, R)
+    L = _lib.layout(P, W, H, K, R if capacity is None else capacity)   # the blob is laid out for the capacity
+    R_obj = R
+    R = int(R)
 
     def view(blob, off, nbytes, dtype, shape):
         return blob[off:off + nbytes].cpu().numpy().view(dtype).reshape(shape)
@@ -153,6 +156,8 @@ def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_p
         point_list=view(binning, L.point_list, R * 4, np.uint32, (R,)),
         sort_bits=L.sort_bits, T=T,
     )
+    if capacity is not None:
+        st.update(overflow=R_obj.overflow, counted=R_obj.counted)
     return st
 
 

@@ -378,6 +378,32 @@ def test_tile_cull_edge_cases_equal_reference_lists_results(gpu, case):
             assert relerr(b[key].reshape(ora[key].shape), ora[key]) <= GRAD_TOL, key
 
 
+@pytest.mark.parametrize("P,W,H,K,sigma", [(3000, 144, 96, 3, 2.5), (2000, 320, 240, 2, 14.0), (5, 64, 48, 1, 3.0),
+                                           (200_000, 800, 800, 4, 1.5), (70_001, 333, 217, 7, 4.0)])
+def test_capacity_mode_builds_the_same_lists(gpu, P, W, H, K, sigma):
+    """dgs_forward (duplicate arrays sized ahead, kernels take the count from device memory) against the two-phase
+    exact path: counts, per-pair offsets, keys (tile | emission index), point lists, ranges and images bit for bit --
+    at a capacity with slack, at exactly the count, and one short (overflow flag set, nothing consumed).  Cases: small;
+    splats of ~25 tiles; fewer pairs than one wave; 200k Gaussians; sizes that are multiples of nothing."""
+    sc = synthetic.make_scene(P, W, H, K=K, seed=11, sigma_px=sigma)
+    a = hip_forward_state(sc, K, cull=True)
+    R = a["R"]
+    for cap in (R + 1000, max(R, 1)):
+        b = hip_forward_state(sc, K, cull=True, capacity=cap)
+        assert b["R"] == R and b["counted"] == R and not b["overflow"]
+        for key in ("tt_tight", "offs_tight", "order", "radii", "ranges", "color", "depth", "n_contrib", "final_T"):
+            assert np.array_equal(a[key], b[key]), (key, cap)
+        assert np.array_equal(a["keys"], b["keys"][:R]) and np.array_equal(a["point_list"], b["point_list"][:R])
+    if R > 1:
+        c = hip_forward_state(sc, K, cull=True, capacity=R - 1)
+        assert c["overflow"] and c["R"] == 0 and c["counted"] == R
+    # the reference's lists (no tile culling) through the same entry point
+    a0 = hip_forward_state(sc, K, cull=False)
+    b0 = hip_forward_state(sc, K, cull=False, capacity=a0["R"] + 77)
+    assert b0["R"] == a0["R"] and np.array_equal(a0["keys"], b0["keys"][:a0["R"]])
+    assert np.array_equal(a0["point_list"], b0["point_list"][:a0["R"]]) and np.array_equal(a0["color"], b0["color"])
+
+
 def test_ragged_image_and_empty_tiles(gpu):
     """W, H not multiples of 16 (partial tiles, partial quadrants) and many empty tiles."""
     sc = small_scene(P=300, W=75, H=41, K=2, seed=7)
