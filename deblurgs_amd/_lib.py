@@ -60,7 +60,8 @@ class DgsLayout(ctypes.Structure):
         "gsort_keys", "gsort_keys_alt", "gsort_vals", "gsort_vals_alt", "tt_sorted", "offs_sorted", "tt_tight", "offs_tight", "gsort_tmp",
         "geom_total", "final_T", "n_contrib", "ranges", "image_total", "keys_sorted", "point_list",
         "keys_unsorted", "vals_unsorted", "sort_tmp", "binning_total")] + [
-        ("sort_bits", ctypes.c_int32), ("sort_passes", ctypes.c_int32)]
+        ("sort_bits", ctypes.c_int32), ("sort_passes", ctypes.c_int32), ("pack_g_shift", ctypes.c_int32),
+        ("pack_tile_shift", ctypes.c_int32)]
 
 
 class DgsAdamGroup(ctypes.Structure):

@@ -65,6 +65,16 @@ void make_layout(int P, int W, int H, int K, uint64_t R, DgsLayout* L) {
   L->binning_total = o;
   L->sort_bits = sort_bits_for(W, H, K);
   L->sort_passes = dgs_sort_num_passes(32, L->sort_bits);
+  // compact keys (tile_cull only): tile | Gaussian | emission index in one 64-bit word when the three fit
+  const char* ck = getenv("DGS_COMPACT_KEYS");   // "0": keep key + value arrays (A/B switch, tests of that path)
+  const bool compact = ck == nullptr || ck[0] != '0';
+  const int u_bits = (int)dgs_higher_msb64(R), g_bits = (int)dgs_higher_msb((uint32_t)(P > 0 ? P : 1));
+  L->pack_g_shift = 0;
+  L->pack_tile_shift = 0;
+  if (compact && R > 0 && u_bits + g_bits + (L->sort_bits - 32) <= 64) {
+    L->pack_g_shift = u_bits;
+    L->pack_tile_shift = u_bits + g_bits;
+  }
 }
 
 int check_problem(const DgsProblem* p) {
@@ -112,6 +122,8 @@ DgsView make_view(const DgsProblem* p) {
   v.tile_cull = p->tile_cull != 0;
   v.raw_params = (p->raw_params & 1) != 0;
   v.iso_scale = (p->raw_params & 2) != 0;
+  v.pack_g_shift = 0;      // set from the layout by the callers that know R (tile_cull only)
+  v.pack_tile_shift = 0;
   v.scale_lb = p->scale_lb;
   return v;
 }
@@ -555,7 +567,12 @@ static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, ui
     return fail(DGS_E_CAPACITY, "binning_state too small");
   DgsCarve c;
   carve(p, L, &c);
-  const DgsView v = make_view(p);
+  DgsView v = make_view(p);
+  if (v.tile_cull) {
+    v.pack_g_shift = L.pack_g_shift;
+    v.pack_tile_shift = L.pack_tile_shift;
+  }
+  const int key_lo = v.pack_tile_shift > 0 ? v.pack_tile_shift : 32;   // first tile bit of the key
   const uint32_t* n_dev = speculative ? c.num_rendered + 4 : nullptr;
   if (R > 0 || v.tile_cull) {  // tile_cull with R == 0 still marks the visible pairs as "no surviving tile"
     // choose the sort's input pair so that the result always lands in keys_sorted / point_list
@@ -580,11 +597,12 @@ static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, ui
     int in_alt = 0;
     uint64_t* kalt = even ? c.keys_unsorted : c.keys_sorted;
     uint32_t* valt = even ? c.vals_unsorted : c.point_list;
+    const bool packed = v.pack_tile_shift > 0;
     DGS_STAGE(DGS_STAGE_SORT, "radix sort",
-              dgs_launch_sort(cd.keys_unsorted, cd.vals_unsorted, kalt, valt, R, 32, L.sort_bits, c.sort_tmp, &in_alt,
-                              s, n_dev));
+              dgs_launch_sort(cd.keys_unsorted, packed ? nullptr : cd.vals_unsorted, kalt, packed ? nullptr : valt, R,
+                              key_lo, key_lo + (L.sort_bits - 32), c.sort_tmp, &in_alt, s, n_dev));
   }
-  DGS_STAGE(DGS_STAGE_RANGES, "identifyTileRanges", dgs_launch_ranges(v, c, R, s, n_dev));
+  DGS_STAGE(DGS_STAGE_RANGES, "identifyTileRanges", dgs_launch_ranges(v, c, R, s, n_dev, key_lo));
   DGS_STAGE(DGS_STAGE_COMPOSITE_FWD, "composite forward",
             dgs_launch_composite_fwd(v, c, p->bg, out->out_color, out->out_depth, s));
   return DGS_OK;
@@ -647,7 +665,11 @@ int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stre
     return fail(DGS_E_CAPACITY, "backward scratch too small");
   DgsCarve c;
   carve(p, L, &c);
-  const DgsView v = make_view(p);
+  DgsView v = make_view(p);
+  if (v.tile_cull) {
+    v.pack_g_shift = L.pack_g_shift;
+    v.pack_tile_shift = L.pack_tile_shift;
+  }
   float* contrib = reinterpret_cast<float*>(io->scratch);
   float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(io->scratch) + up((size_t)R * DGS_CONTRIB_F * 4));
   float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(sums) +

@@ -353,8 +353,12 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
       if (hit) {
         const uint32_t pos = obase + run + (uint32_t)__builtin_popcountll(hm & lt);
         if (pos < cap) {
-          keys[pos] = ((uint64_t)tile << 32) | pos;
-          vals[pos] = s_g[w][lo];
+          if (v.pack_tile_shift > 0) {   // compact keys: the whole record in the key, no value array
+            keys[pos] = ((uint64_t)tile << v.pack_tile_shift) | ((uint64_t)s_g[w][lo] << v.pack_g_shift) | pos;
+          } else {
+            keys[pos] = ((uint64_t)tile << 32) | pos;
+            vals[pos] = s_g[w][lo];
+          }
         }
       }
       run += (uint32_t)__builtin_popcountll(hm);
@@ -393,15 +397,15 @@ __global__ void finalize_count_kernel(uint32_t* __restrict__ nr, int cull, uint3
 // ---------------------------------------------------------------------------------------------- ranges
 __global__ void __launch_bounds__(256)
 ranges_kernel(uint32_t L, const uint32_t* __restrict__ n_dev, const uint64_t* __restrict__ keys,
-              uint2* __restrict__ ranges) {
+              uint2* __restrict__ ranges, int tile_shift) {
   if (n_dev != nullptr) L = min(L, n_dev[0]);
   const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= L) return;
-  const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+  const uint32_t currtile = (uint32_t)(keys[idx] >> tile_shift);
   if (idx == 0)
     ranges[currtile].x = 0;
   else {
-    const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+    const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> tile_shift);
     if (currtile != prevtile) {
       ranges[prevtile].y = idx;
       ranges[currtile].x = idx;
@@ -693,7 +697,7 @@ onesweep_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __
     const uint64_t i = wbase + (uint64_t)r * 64 + lane;
     const bool valid = i < n;
     key[r] = valid ? keys_in[i] : ~0ull;
-    val[r] = valid ? vals_in[i] : 0u;
+    val[r] = (valid && vals_in != nullptr) ? vals_in[i] : 0u;   // vals_in == nullptr: keys only (compact keys)
   }
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS; r++) {
@@ -788,6 +792,7 @@ onesweep_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __
       keys_out[gpos[r]] = k;
     }
   }
+  if (vals_in == nullptr) return;   // block-uniform
   __syncthreads();
   uint32_t* lds_v = reinterpret_cast<uint32_t*>(lds_k);
 #pragma unroll
@@ -1036,6 +1041,7 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
   *result_in_alt = plan.n & 1;
   if (n == 0) return hipSuccess;
   if (n_dev != nullptr && sort_mode() != 1) return hipErrorInvalidValue;  // device-side counts: default path only
+  if (vals == nullptr && sort_mode() == 0) return hipErrorInvalidValue;   // keys-only: not in the classic A/B variant
   const uint32_t nblocks = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
   if (sort_mode() == 2 && n < (1ull << 30) && plan.n <= OS_MAX_PASSES) {
     // tmp layout: [status: nblocks*512][ghist: passes*512][tickets: passes]
@@ -1150,11 +1156,13 @@ hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const
   return hipGetLastError();
 }
 
-hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s, const uint32_t* n_dev) {
+hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s, const uint32_t* n_dev,
+                             int tile_shift) {
   hipError_t e = hipMemsetAsync(c.ranges, 0, (size_t)v.K * v.T * sizeof(uint2), s);
   if (e != hipSuccess) return e;
   if (R > 0)
-    hipLaunchKernelGGL(ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, n_dev, c.keys_sorted, c.ranges);
+    hipLaunchKernelGGL(ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, n_dev, c.keys_sorted, c.ranges,
+                       tile_shift);
   return hipGetLastError();
 }
 

@@ -72,7 +72,8 @@ using CullGauss = DgsCull;
 // ------------------------------------------------------------------------------------------------ forward
 __global__ void __launch_bounds__(64 * CW)
 composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
-                     const uint32_t* __restrict__ point_list, const DgsRow* __restrict__ rows,
+                     const uint32_t* __restrict__ point_list, const uint64_t* __restrict__ keys,
+                     const DgsRow* __restrict__ rows,
                      const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                      float* __restrict__ out_color, float* __restrict__ out_depth) {
   // one 48-byte LDS row per list entry: (x, y, A, B | C, op, r, g | b, depth, -, -): one address per read
@@ -108,7 +109,11 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     const bool has = base + lane < n;
     float4 A = make_float4(0, 0, 0, 0), B = A, Cc = A;
     if (has) {
-      const uint32_t g = point_list[t.r0 + base + lane];
+      // compact keys: the Gaussian sits between the emission index and the tile in the key itself
+      const uint32_t g = v.pack_tile_shift > 0
+                             ? (uint32_t)(keys[t.r0 + base + lane] >> v.pack_g_shift) &
+                                   ((1u << (v.pack_tile_shift - v.pack_g_shift)) - 1u)
+                             : point_list[t.r0 + base + lane];
       const float4* rp = reinterpret_cast<const float4*>(krows + g);
       A = rp[0];
       B = rp[1];
@@ -278,14 +283,20 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     float4 A = make_float4(0, 0, 0, 0), B = A, Cc = A;
     uint32_t u = 0;
     if (has) {
-      const uint32_t g = point_list[t.r0 + base + lane];
+      uint32_t g;
+      if (TIGHT && v.pack_tile_shift > 0) {   // compact keys: tile | Gaussian | emission index in one word
+        const uint64_t key = keys[t.r0 + base + lane];
+        g = (uint32_t)(key >> v.pack_g_shift) & ((1u << (v.pack_tile_shift - v.pack_g_shift)) - 1u);
+        u = (uint32_t)(key & ((1ull << v.pack_g_shift) - 1ull));
+      } else {
+        g = point_list[t.r0 + base + lane];
+        if (TIGHT) u = reinterpret_cast<const uint32_t*>(keys)[2 * (size_t)(t.r0 + base + lane)];
+      }
       const float4* rp = reinterpret_cast<const float4*>(krows + g);
       A = rp[0];
       B = rp[1];
       Cc = rp[2];
-      if (TIGHT) {
-        u = reinterpret_cast<const uint32_t*>(keys)[2 * (size_t)(t.r0 + base + lane)];
-      } else {
+      if (!TIGHT) {
         // index of this (tile, Gaussian) duplicate in duplicate order: row-major inside the Gaussian's tile rect
         int minx, miny, maxx, maxy;
         dgs_get_rect(A.x, A.y, __float_as_int(Cc.w), v.gx, v.gy, minx, miny, maxx, maxy);
@@ -421,7 +432,7 @@ hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const f
   const uint32_t per = per_xcd_blocks(v);
   if (per == 0) return hipSuccess;
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
-                     c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth);
+                     c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth);
   return hipGetLastError();
 }
 

@@ -49,6 +49,11 @@ struct DgsCarve {  // resolved device pointers of the three blobs
   uint32_t* sort_tmp;
 };
 
+static inline uint32_t dgs_higher_msb64(uint64_t n) {   // bits needed for values 0 .. n
+  uint32_t b = 0;
+  while (b < 64 && (n >> b) != 0) b++;
+  return b;
+}
 // rasterizer_impl.cu:35-50
 static inline uint32_t dgs_higher_msb(uint32_t n) {
   uint32_t msb = sizeof(n) * 4;
@@ -144,6 +149,9 @@ struct DgsView {  // per-launch scalars shared by the kernels
   int tile_cull;
   int raw_params;   // kernels apply the cloud's activations (DgsProblem.raw_params bit 0)
   int iso_scale;    // raw_params bit 1: one shared scale per Gaussian = column 0 of `scales` (use_isotrophic)
+  // tile_cull with compact keys (DgsLayout.pack_*): key = tile << pack_tile_shift | Gaussian << pack_g_shift | emission
+  // index, no value array; pack_tile_shift == 0: key = tile << 32 | emission index, Gaussian in point_list
+  int pack_g_shift, pack_tile_shift;
   float scale_lb;
 };
 
@@ -208,7 +216,7 @@ hipError_t dgs_launch_cloud_activations(int P, const float* scales, const float*
                                         hipStream_t s);
 hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, hipStream_t s);
 hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s,
-                             const uint32_t* n_dev = nullptr);
+                             const uint32_t* n_dev = nullptr, int tile_shift = 32);
 hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, uint32_t* total,
                            hipStream_t s);
 hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,

@@ -161,7 +161,12 @@ typedef struct DgsLayout {
   size_t sort_tmp;       /* u32 radix histogram table */
   size_t binning_total;
   int32_t sort_bits;     /* 32 + bits(K*T): width of the reference-compatible key */
-  int32_t sort_passes;   /* digit passes of the duplicate sort (over the tile bits [32, sort_bits) only) */
+  int32_t sort_passes;   /* digit passes of the duplicate sort (over the tile bits only) */
+  /* tile_cull = 1 only, when bits(K*T) + bits(P) + bits(R) <= 64 (else both are 0 and keys / point_list are as above):
+   * the key is the whole record, (tile << pack_tile_shift) | (Gaussian << pack_g_shift) | emission index, point_list /
+   * vals_unsorted stay unused and the sort moves 8 instead of 12 bytes per duplicate and pass. */
+  int32_t pack_g_shift;
+  int32_t pack_tile_shift;
 } DgsLayout;
 
 int dgs_abi_version(void);

@@ -156,6 +156,15 @@ def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_p
         point_list=view(binning, L.point_list, R * 4, np.uint32, (R,)),
         sort_bits=L.sort_bits, T=T,
     )
+    st["compact_keys"] = False
+    if R_obj.tile_cull and L.pack_tile_shift > 0:
+        # compact keys (DgsLayout.pack_*): tile | Gaussian | emission index in one word and no value array; the tests
+        # read the canonical form, key = tile << 32 | emission index and the Gaussian in point_list
+        raw = st["keys"]
+        gs, ts = np.uint64(L.pack_g_shift), np.uint64(L.pack_tile_shift)
+        st["point_list"] = ((raw >> gs) & ((np.uint64(1) << (ts - gs)) - np.uint64(1))).astype(np.uint32)
+        st["keys"] = ((raw >> ts) << np.uint64(32)) | (raw & ((np.uint64(1) << gs) - np.uint64(1)))
+        st["compact_keys"] = True
     if capacity is not None:
         st.update(overflow=R_obj.overflow, counted=R_obj.counted)
     return st
@@ -476,7 +485,13 @@ def hip_state_on_device(scene, K, cull=True, raw=True):
     T = ((W + 15) // 16) * ((H + 15) // 16)
     L = _lib.layout(P, W, H, K, R)
     v = lambda blob, off, nbytes, dtype, shape: blob[off:off + nbytes].view(dtype).reshape(shape)
-    return dict(R=int(R), K=K, T=T, sort_bits=L.sort_bits, sort_passes=L.sort_passes, color=color, depth=depth,
+    keys = v(binning, L.keys_sorted, R * 8, torch.int64, (R,))
+    point_list = v(binning, L.point_list, R * 4, torch.int32, (R,))
+    if cull and L.pack_tile_shift > 0:   # compact keys -> the canonical (tile << 32 | emission index, Gaussian) form
+        gs, ts = L.pack_g_shift, L.pack_tile_shift
+        point_list = ((keys >> gs) & ((1 << (ts - gs)) - 1)).int()
+        keys = ((keys >> ts) << 32) | (keys & ((1 << gs) - 1))
+    return dict(R=int(R), K=K, T=T, compact_keys=bool(cull and L.pack_tile_shift > 0), sort_bits=L.sort_bits, sort_passes=L.sort_passes, color=color, depth=depth,
                 radii=radii, _blobs=(geom, binning, image),
                 tiles_touched=v(geom, L.tiles_touched, K * P * 4, torch.int32, (K, P)),
                 tt_tight=v(geom, L.tt_tight, K * P * 4, torch.int32, (K * P,)),
@@ -484,5 +499,4 @@ def hip_state_on_device(scene, K, cull=True, raw=True):
                 final_T=v(image, L.final_T, K * W * H * 4, torch.float32, (K, H * W)),
                 n_contrib=v(image, L.n_contrib, K * W * H * 4, torch.int32, (K, H * W)),
                 ranges=v(image, L.ranges, K * T * 8, torch.int32, (K * T, 2)),
-                keys=v(binning, L.keys_sorted, R * 8, torch.int64, (R,)),
-                point_list=v(binning, L.point_list, R * 4, torch.int32, (R,)))
+                keys=keys, point_list=point_list)

@@ -43,7 +43,7 @@ def test_struct_sizes_match_the_header_layout():
     assert ctypes.sizeof(_lib.DgsProblem) == 72 + 12 * 8 + 3 * 16
     assert ctypes.sizeof(_lib.DgsForwardOut) == 32
     assert ctypes.sizeof(_lib.DgsBackwardIO) == 8 + 8 * 3 + 16 + 11 * 8 + 8    # + opacity_hinge_scale (padded)
-    assert ctypes.sizeof(_lib.DgsLayout) == 27 * 8 + 8
+    assert ctypes.sizeof(_lib.DgsLayout) == 27 * 8 + 16     # + sort_bits, sort_passes, pack_g_shift, pack_tile_shift
 
 
 def test_size_queries_and_layout():
@@ -57,6 +57,10 @@ def test_size_queries_and_layout():
     T = 120 * 68
     assert lay.sort_bits == 32 + 17 and lay.sort_passes == 2          # bits(15*8160) = 17 tile bits, 2 digit passes
     assert _lib.layout(P, W, H, 1, R).sort_bits == 45                  # the reference's key width at 1080p
+    # compact keys: 22 bits of emission index (R = 4e6), 10 bits of Gaussian (P = 1000), tile above
+    assert lay.pack_g_shift == 22 and lay.pack_tile_shift == 32
+    big = _lib.layout(5_000_000, 3840, 2160, 31, 400_000_000)          # 29 + 23 + 20 bits do not fit one word
+    assert big.pack_g_shift == 0 and big.pack_tile_shift == 0
     assert lay.geom_rows == 0 and lay.cov3D >= K * P * 48
     assert lay.final_T == 0 and lay.n_contrib >= K * W * H * 4 and lay.ranges >= 2 * K * W * H * 4
     assert lay.image_total >= lay.ranges + K * T * 8

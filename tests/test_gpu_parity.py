@@ -327,6 +327,26 @@ def test_tile_cull_gradients_bitwise_equal(gpu, depth):
         assert np.array_equal(a[key], b[key]), key
 
 
+def test_compact_keys_and_key_value_lists_agree(gpu, monkeypatch):
+    """With tile culling the sorted record is ONE 64-bit word, tile | Gaussian | emission index, whenever the three
+    fit (DgsLayout.pack_*; every config but the 5M / 4K / K=31 stress one); otherwise key (tile | emission index) +
+    value (Gaussian) arrays.  Both storages must give the same lists, images and gradients."""
+    sc = small_scene()
+    gC, gD = _grads(sc, sc["K"], depth=True)
+    out = {}
+    for compact in ("1", "0"):
+        monkeypatch.setenv("DGS_COMPACT_KEYS", compact)
+        st = hip_forward_state(sc, sc["K"], cull=True)
+        assert st["compact_keys"] == (compact == "1")
+        with tile_cull(True):
+            out[compact] = (st, hip_forward_backward(sc, sc["K"], gC, gD))
+    (a, ga), (b, gb) = out["1"], out["0"]
+    for key in ("keys", "point_list", "ranges", "color", "depth", "n_contrib"):
+        assert np.array_equal(a[key], b[key]), key
+    for key in GRAD_KEYS:
+        assert np.array_equal(ga[key], gb[key]), key
+
+
 @pytest.mark.parametrize("case", ["faint", "indefinite_cov", "huge", "mixed_opacity"])
 def test_tile_cull_edge_cases_equal_reference_lists_results(gpu, case):
     """Corner cases of the tile test: every pair below 1/255 (all duplicates culled while the pairs stay visible:
