@@ -128,9 +128,8 @@ EXPORTS = {
     "dgs_alignment_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dgs_pose_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
-    "dgs_pose_forward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 4),
-    "dgs_pose_backward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32]
-                          + [ctypes.c_void_p] * 7),
+    "dgs_pose_forward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 3 + [ctypes.c_void_p] * 4),
+    "dgs_pose_backward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 3 + [ctypes.c_void_p] * 7),
     "dgs_profile_enable": (ctypes.c_int, [ctypes.c_int32]),
     "dgs_profile_reset": (ctypes.c_int, []),
     "dgs_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32),

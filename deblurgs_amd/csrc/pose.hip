@@ -1,6 +1,8 @@
 // pose.hip -- the pose path of the blur-integration loop as ONE kernel per direction:
 //   Bezier(control points, nu) -> se(3) -> se3_exp_map -> world_view, full_proj, camera_center for all K
-//   subframes, and its backward from dL/d{world_view, full_proj} to the control points and nu.
+//   subframes, and its backward from dL/d{world_view, full_proj} to the control points and nu; curve_type
+//   "quarternion_cartesian" (scene/motion.py:191-194,242-246) takes the other branch: a 4-component quaternion curve,
+//   normalised, to a rotation matrix (x, y, z, w convention of roma.unitquat_to_rotmat) + a cartesian translation curve.
 // Replaces ~250 micro-kernels per training step in the reference (scene/bezier.py:54-83,
 // utils/pytorch3d_functions.py:218-247,373-457,546-573, scene/motion.py:248-294, scene/cameras.py:63-74).
 //
@@ -14,15 +16,16 @@ namespace {
 
 constexpr int MAX_ORDER = 32;
 
-struct D6 {  // value + gradient w.r.t. the 6 se(3) coordinates (trans xyz, rot xyz)
+constexpr int ND = 7;  // dual-number directions: 6 se(3) coordinates, or 3 translation + 4 quaternion components
+struct D6 {  // value + gradient w.r.t. the curve outputs (trans xyz, rot xyz [, w])
   double v;
-  double d[6];
+  double d[ND];
 };
 __device__ __forceinline__ D6 cst(double x) {
   D6 r;
   r.v = x;
 #pragma unroll
-  for (int i = 0; i < 6; i++) r.d[i] = 0.0;
+  for (int i = 0; i < ND; i++) r.d[i] = 0.0;
   return r;
 }
 __device__ __forceinline__ D6 var(double x, int i) {
@@ -34,28 +37,28 @@ __device__ __forceinline__ D6 operator+(const D6& a, const D6& b) {
   D6 r;
   r.v = a.v + b.v;
 #pragma unroll
-  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] + b.d[i];
+  for (int i = 0; i < ND; i++) r.d[i] = a.d[i] + b.d[i];
   return r;
 }
 __device__ __forceinline__ D6 operator-(const D6& a, const D6& b) {
   D6 r;
   r.v = a.v - b.v;
 #pragma unroll
-  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] - b.d[i];
+  for (int i = 0; i < ND; i++) r.d[i] = a.d[i] - b.d[i];
   return r;
 }
 __device__ __forceinline__ D6 operator-(const D6& a) {
   D6 r;
   r.v = -a.v;
 #pragma unroll
-  for (int i = 0; i < 6; i++) r.d[i] = -a.d[i];
+  for (int i = 0; i < ND; i++) r.d[i] = -a.d[i];
   return r;
 }
 __device__ __forceinline__ D6 operator*(const D6& a, const D6& b) {
   D6 r;
   r.v = a.v * b.v;
 #pragma unroll
-  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  for (int i = 0; i < ND; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
   return r;
 }
 __device__ __forceinline__ D6 operator/(const D6& a, const D6& b) {
@@ -63,7 +66,7 @@ __device__ __forceinline__ D6 operator/(const D6& a, const D6& b) {
   const double inv = 1.0 / b.v;
   r.v = a.v * inv;
 #pragma unroll
-  for (int i = 0; i < 6; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+  for (int i = 0; i < ND; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
   return r;
 }
 __device__ __forceinline__ D6 dsqrt(const D6& a) {
@@ -71,7 +74,7 @@ __device__ __forceinline__ D6 dsqrt(const D6& a) {
   r.v = sqrt(a.v);
   const double k = 0.5 / r.v;
 #pragma unroll
-  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * k;
+  for (int i = 0; i < ND; i++) r.d[i] = a.d[i] * k;
   return r;
 }
 __device__ __forceinline__ D6 dsin(const D6& a) {
@@ -79,7 +82,7 @@ __device__ __forceinline__ D6 dsin(const D6& a) {
   r.v = sin(a.v);
   const double c = cos(a.v);
 #pragma unroll
-  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * c;
+  for (int i = 0; i < ND; i++) r.d[i] = a.d[i] * c;
   return r;
 }
 __device__ __forceinline__ D6 dcos(const D6& a) {
@@ -87,7 +90,7 @@ __device__ __forceinline__ D6 dcos(const D6& a) {
   r.v = cos(a.v);
   const double s = -sin(a.v);
 #pragma unroll
-  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * s;
+  for (int i = 0; i < ND; i++) r.d[i] = a.d[i] * s;
   return r;
 }
 __device__ __forceinline__ D6 dclamp_min(const D6& a, double lo) { return a.v < lo ? cst(lo) : a; }
@@ -137,7 +140,20 @@ __device__ void se3_exp(const D6 se3[6], D6 R[9], D6 T[3]) {
 }
 
 // One thread per subframe.  MODE 0: forward outputs.  MODE 1: dL_dse3[k][6] and dL_dnu[k].
-template <int MODE>
+// roma.unitquat_to_rotmat on dual numbers, after q / |q| (scene/motion.py:243-245); R row-major 3x3
+__device__ void quat_rot(const D6 q[4], D6 R[9]) {
+  const D6 n = dsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const D6 x = q[0] / n, y = q[1] / n, z = q[2] / n, w = q[3] / n;
+  const D6 x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+  const D6 xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+  const D6 two = cst(2.0);
+  R[0] = x2 - y2 - z2 + w2;  R[1] = two * (xy - zw);     R[2] = two * (xz + yw);
+  R[3] = two * (xy + zw);    R[4] = y2 - x2 - z2 + w2;   R[5] = two * (yz - xw);
+  R[6] = two * (xz - yw);    R[7] = two * (yz + xw);     R[8] = z2 - x2 - y2 + w2;
+}
+
+// QUAT = 0: se(3) curves (rotation control points [C+1,3]); 1: quaternion + cartesian curves ([C+1,4])
+template <int MODE, int QUAT>
 __global__ void pose_kernel(int C, int K, const float* __restrict__ ctrl_trans, const float* __restrict__ ctrl_rot,
                             const float* __restrict__ nu, const float* __restrict__ proj, float* __restrict__ view,
                             float* __restrict__ full, float* __restrict__ campos, const float* __restrict__ dL_dview,
@@ -147,20 +163,27 @@ __global__ void pose_kernel(int C, int K, const float* __restrict__ ctrl_trans, 
   if (k >= K) return;
   double coeff[MAX_ORDER + 1], dcoeff[MAX_ORDER + 1];
   bernstein(C, nu[k], coeff, MODE == 1 ? dcoeff : nullptr);
-  double s[6] = {0, 0, 0, 0, 0, 0}, ds[6] = {0, 0, 0, 0, 0, 0};
-  for (int c = 0; c <= C; c++)
+  constexpr int NR = QUAT ? 4 : 3, NP = 3 + NR;   // rotation components, curve outputs per subframe
+  double s[ND] = {0, 0, 0, 0, 0, 0, 0}, ds[ND] = {0, 0, 0, 0, 0, 0, 0};
+  for (int c = 0; c <= C; c++) {
     for (int d = 0; d < 3; d++) {
       s[d] += coeff[c] * (double)ctrl_trans[3 * c + d];
-      s[3 + d] += coeff[c] * (double)ctrl_rot[3 * c + d];
-      if (MODE == 1) {
-        ds[d] += dcoeff[c] * (double)ctrl_trans[3 * c + d];
-        ds[3 + d] += dcoeff[c] * (double)ctrl_rot[3 * c + d];
-      }
+      if (MODE == 1) ds[d] += dcoeff[c] * (double)ctrl_trans[3 * c + d];
     }
-  D6 se3[6];
-  for (int i = 0; i < 6; i++) se3[i] = var(s[i], i);
+    for (int d = 0; d < NR; d++) {
+      s[3 + d] += coeff[c] * (double)ctrl_rot[NR * c + d];
+      if (MODE == 1) ds[3 + d] += dcoeff[c] * (double)ctrl_rot[NR * c + d];
+    }
+  }
+  D6 se3[ND];
+  for (int i = 0; i < ND; i++) se3[i] = var(s[i], i);
   D6 R[9], T[3];
-  se3_exp(se3, R, T);
+  if (QUAT) {
+    quat_rot(se3 + 3, R);
+    for (int d = 0; d < 3; d++) T[d] = se3[d];
+  } else {
+    se3_exp(se3, R, T);
+  }
   // scene/motion.py:277-279 (c2w rotation = R, translation = T in the row-vector convention):
   //   world_view[:3,:3] = R, world_view[3,:3] = -T @ R, rounded to float32
   if (MODE == 0) {
@@ -191,16 +214,16 @@ __global__ void pose_kernel(int C, int K, const float* __restrict__ ctrl_trans, 
         for (int j = 0; j < 4; j++) acc += (double)dL_dfull[16 * k + 4 * r + j] * (double)proj[4 * c + j];
         G[4 * r + c] = acc;
       }
-    double g[6] = {0, 0, 0, 0, 0, 0};
+    double g[ND] = {0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 3; c++) {
         const double gR = G[4 * r + c] - G[12 + c] * T[r].v;  // through world_view[r][c] and world_view[3][c]
         const double gT = -G[12 + c] * R[3 * r + c].v;        // dL/dT[r] contribution
-        for (int i = 0; i < 6; i++) g[i] += gR * R[3 * r + c].d[i] + gT * T[r].d[i];
+        for (int i = 0; i < NP; i++) g[i] += gR * R[3 * r + c].d[i] + gT * T[r].d[i];
       }
     double gn = 0.0;
-    for (int i = 0; i < 6; i++) {
-      dL_dse3[6 * k + i] = g[i];
+    for (int i = 0; i < NP; i++) {
+      dL_dse3[NP * k + i] = g[i];
       gn += g[i] * ds[i];
     }
     dL_dnu[k] = (float)gn;
@@ -209,17 +232,18 @@ __global__ void pose_kernel(int C, int K, const float* __restrict__ ctrl_trans, 
 }
 
 // dL/dctrl[c][d] = sum_k coeff[k][c] * dL_dse3[k][d], summed in k order (deterministic)
-__global__ void pose_ctrl_grad_kernel(int C, int K, const double* __restrict__ coeff, const double* __restrict__ dL_dse3,
-                                      float* __restrict__ dL_dctrl_trans, float* __restrict__ dL_dctrl_rot) {
-  const int i = threadIdx.x;  // (c, d) pair, d in 0..5
-  if (i >= (C + 1) * 6) return;
-  const int c = i / 6, d = i % 6;
+__global__ void pose_ctrl_grad_kernel(int C, int K, int NP, const double* __restrict__ coeff,
+                                      const double* __restrict__ dL_dse3, float* __restrict__ dL_dctrl_trans,
+                                      float* __restrict__ dL_dctrl_rot) {
+  const int i = threadIdx.x;  // (c, d) pair, d in 0..NP-1 (NP = 6 curve outputs, 7 with a quaternion curve)
+  if (i >= (C + 1) * NP) return;
+  const int c = i / NP, d = i % NP;
   double acc = 0.0;
-  for (int k = 0; k < K; k++) acc += coeff[(size_t)k * (MAX_ORDER + 1) + c] * dL_dse3[6 * k + d];
+  for (int k = 0; k < K; k++) acc += coeff[(size_t)k * (MAX_ORDER + 1) + c] * dL_dse3[NP * k + d];
   if (d < 3)
     dL_dctrl_trans[3 * c + d] = (float)acc;
   else
-    dL_dctrl_rot[3 * c + d - 3] = (float)acc;
+    dL_dctrl_rot[(NP - 3) * c + d - 3] = (float)acc;
 }
 
 // Subframe times of one view from its alignment parameters (scene/motion.py:209-219):
@@ -289,32 +313,41 @@ int dgs_alignment_backward(const float* raw, const float* uniform, int32_t f, in
   return hipGetLastError() == hipSuccess ? DGS_OK : DGS_E_HIP;
 }
 
-size_t dgs_pose_scratch_bytes(int32_t K) { return (size_t)K * (6 + MAX_ORDER + 1) * sizeof(double) + 256; }
+size_t dgs_pose_scratch_bytes(int32_t K) { return (size_t)K * (ND + MAX_ORDER + 1) * sizeof(double) + 256; }
 
 int dgs_pose_forward(const float* ctrl_trans, const float* ctrl_rot, const float* nu, const float* proj, int32_t C,
-                     int32_t K, float* view, float* full, float* campos, dgs_stream_t stream) {
+                     int32_t K, int32_t quaternion, float* view, float* full, float* campos, dgs_stream_t stream) {
   if (C < 0 || C > MAX_ORDER || K < 1 || ctrl_trans == nullptr || ctrl_rot == nullptr || nu == nullptr ||
       proj == nullptr || view == nullptr || full == nullptr || campos == nullptr)
     return DGS_E_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(pose_kernel<0>, dim3((K + 63) / 64), dim3(64), 0, s, C, K, ctrl_trans, ctrl_rot, nu, proj, view,
-                     full, campos, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (quaternion)
+    hipLaunchKernelGGL((pose_kernel<0, 1>), dim3((K + 63) / 64), dim3(64), 0, s, C, K, ctrl_trans, ctrl_rot, nu, proj,
+                       view, full, campos, nullptr, nullptr, nullptr, nullptr, nullptr);
+  else
+    hipLaunchKernelGGL((pose_kernel<0, 0>), dim3((K + 63) / 64), dim3(64), 0, s, C, K, ctrl_trans, ctrl_rot, nu, proj,
+                       view, full, campos, nullptr, nullptr, nullptr, nullptr, nullptr);
   return hipGetLastError() == hipSuccess ? DGS_OK : DGS_E_HIP;
 }
 
 int dgs_pose_backward(const float* ctrl_trans, const float* ctrl_rot, const float* nu, const float* proj, int32_t C,
-                      int32_t K, const float* dL_dview, const float* dL_dfull, void* scratch, float* dL_dctrl_trans,
-                      float* dL_dctrl_rot, float* dL_dnu, dgs_stream_t stream) {
-  if (C < 0 || C > MAX_ORDER || K < 1 || (C + 1) * 6 > 1024 || ctrl_trans == nullptr || ctrl_rot == nullptr ||
+                      int32_t K, int32_t quaternion, const float* dL_dview, const float* dL_dfull, void* scratch,
+                      float* dL_dctrl_trans, float* dL_dctrl_rot, float* dL_dnu, dgs_stream_t stream) {
+  if (C < 0 || C > MAX_ORDER || K < 1 || (C + 1) * ND > 256 || ctrl_trans == nullptr || ctrl_rot == nullptr ||
       nu == nullptr || proj == nullptr || dL_dview == nullptr || dL_dfull == nullptr || scratch == nullptr ||
       dL_dctrl_trans == nullptr || dL_dctrl_rot == nullptr || dL_dnu == nullptr)
     return DGS_E_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   double* dse3 = reinterpret_cast<double*>(scratch);
-  double* coeff = dse3 + (size_t)6 * K;
-  hipLaunchKernelGGL(pose_kernel<1>, dim3((K + 63) / 64), dim3(64), 0, s, C, K, ctrl_trans, ctrl_rot, nu, proj, nullptr,
-                     nullptr, nullptr, dL_dview, dL_dfull, dse3, dL_dnu, coeff);
-  hipLaunchKernelGGL(pose_ctrl_grad_kernel, dim3(1), dim3(256), 0, s, C, K, coeff, dse3, dL_dctrl_trans, dL_dctrl_rot);
+  double* coeff = dse3 + (size_t)ND * K;
+  if (quaternion)
+    hipLaunchKernelGGL((pose_kernel<1, 1>), dim3((K + 63) / 64), dim3(64), 0, s, C, K, ctrl_trans, ctrl_rot, nu, proj,
+                       nullptr, nullptr, nullptr, dL_dview, dL_dfull, dse3, dL_dnu, coeff);
+  else
+    hipLaunchKernelGGL((pose_kernel<1, 0>), dim3((K + 63) / 64), dim3(64), 0, s, C, K, ctrl_trans, ctrl_rot, nu, proj,
+                       nullptr, nullptr, nullptr, dL_dview, dL_dfull, dse3, dL_dnu, coeff);
+  hipLaunchKernelGGL(pose_ctrl_grad_kernel, dim3(1), dim3(256), 0, s, C, K, quaternion ? 7 : 6, coeff, dse3,
+                     dL_dctrl_trans, dL_dctrl_rot);
   return hipGetLastError() == hipSuccess ? DGS_OK : DGS_E_HIP;
 }
 

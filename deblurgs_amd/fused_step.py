@@ -44,8 +44,6 @@ class _Pending:
 
 class FusedStep:
     def __init__(self, cloud, motion, lambda_hinge=0.0, speculative=True, tile_cull=None):
-        if motion.curve_type != "se3":
-            raise NotImplementedError("FusedStep covers curve_type='se3' (use CameraMotionModule.query otherwise)")
         if not getattr(cloud, "fused_activations", False):
             raise NotImplementedError("FusedStep needs a cloud with fused_activations")
         self.cloud, self.motion = cloud, motion
@@ -129,12 +127,14 @@ class FusedStep:
         # ---- cameras
         ct_all, cr_all = m._trans._control_points, m._rot._control_points
         C = ct_all.shape[1] - 1
-        row = cam * (C + 1) * 3
+        row = cam * (C + 1) * 3                       # this view's curve in the translation control points ...
+        quat = int(cr_all.shape[-1] == 4)             # ... and in the rotation ones ([C+1,4]: quaternion curve)
+        rrow = cam * (C + 1) * cr_all.shape[-1]
         proj = m.ref_cam.projection_matrix.to(dev, torch.float32).contiguous()   # (stored as a transposed view)
         view = torch.empty((K, 4, 4), **f32)
         full = torch.empty((K, 4, 4), **f32)
         campos = torch.empty((K, 3), **f32)
-        _lib.check(L.dgs_pose_forward(_ptr(ct_all, row), _ptr(cr_all, row), _ptr(nu), _ptr(proj), C, K, _ptr(view),
+        _lib.check(L.dgs_pose_forward(_ptr(ct_all, row), _ptr(cr_all, rrow), _ptr(nu), _ptr(proj), C, K, quat, _ptr(view),
                                       _ptr(full), _ptr(campos), stream), "dgs_pose_forward")
 
         # ---- forward
@@ -237,9 +237,10 @@ class FusedStep:
             d_ct_all, d_cr_all = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
             d_nu = torch.empty(K, **f32)
             pscratch = torch.empty(L.dgs_pose_scratch_bytes(K), dtype=torch.uint8, device=dev)
-            _lib.check(L.dgs_pose_backward(_ptr(ct_all, row), _ptr(cr_all, row), _ptr(nu), _ptr(proj), C, K, _ptr(g_view),
+            _lib.check(L.dgs_pose_backward(_ptr(ct_all, row), _ptr(cr_all, rrow), _ptr(nu), _ptr(proj), C, K, quat,
+                                           _ptr(g_view),
                                            _ptr(g_proj), ctypes.c_void_p(pscratch.data_ptr()), _ptr(d_ct_all, row),
-                                           _ptr(d_cr_all, row), _ptr(d_nu), stream), "dgs_pose_backward")
+                                           _ptr(d_cr_all, rrow), _ptr(d_nu), stream), "dgs_pose_backward")
             m._trans._control_points.grad, m._rot._control_points.grad = d_ct_all, d_cr_all
             if nrow > 0:
                 d_raw_all = torch.zeros_like(nu_raw)

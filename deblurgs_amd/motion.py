@@ -8,8 +8,8 @@ curve types ("se3", the default, and "quarternion_cartesian").  Differences, all
   * dataset loading, PLY/COLMAP I/O, optimiser wiring and cm.pth checkpoints are out of scope (SURVEY 2, rows
     12-21): the module is constructed from initial c2w poses and ground-truth images held in memory;
   * curve_type="quarternion_cartesian" calls the third-party `roma` in the reference (unpinned, absent here); its two
-    conversions are restated in pose.py (rotmat_to_unitquat / unitquat_to_rotmat) and pinned against scipy.  That
-    curve type evaluates its poses with torch ops (the fused pose kernel covers the default se3 type).
+    conversions are restated in pose.py (rotmat_to_unitquat / unitquat_to_rotmat) and pinned against scipy; on the
+    device both curve types go through the fused pose kernel (csrc/pose.hip), the torch ops are its test reference.
 """
 import torch
 import torch.nn as nn
@@ -149,10 +149,8 @@ class CameraMotionModule:
         """Batched _c2w_to_minicam: (world_view [K,4,4], full_proj [K,4,4], camera_center [K,3]).
         On device tensors the whole chain nu -> Bezier -> se3_exp_map -> cameras runs as one HIP kernel
         (pose.fused_trajectory); `fused=False` forces the torch-op reference implementation."""
-        use_fused = (self.device.type == "cuda" and self.curve_type == "se3") if fused is None else fused
-        if use_fused:
-            if self.curve_type != "se3":
-                raise NotImplementedError("the fused pose kernel covers curve_type='se3'")
+        use_fused = (self.device.type == "cuda") if fused is None else fused
+        if use_fused:   # both curve types (the rotation control points are [C+1,3] or [C+1,4])
             nu = self._sample_nu_from_alignment(idx) if t is None else t.to(self.device)
             if isinstance(idx, int):
                 ct, cr = self._trans._control_points[idx], self._rot._control_points[idx]

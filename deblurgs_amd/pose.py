@@ -243,7 +243,8 @@ class MiniCam:
 class _FusedTrajectory(torch.autograd.Function):
     """(ctrl_trans [C+1,3], ctrl_rot [C+1,3], nu [K], proj_T [4,4]) -> (world_view, full_proj, camera_center) through
     the single-kernel pose path of libdgs_hip.so (csrc/pose.hip); same math as BezierModel + se3_exp_map +
-    c2w_to_view_proj, which stay as the torch reference implementation (and the CPU path of the tests)."""
+    c2w_to_view_proj, which stay as the torch reference implementation (and the CPU path of the tests).
+    ctrl_rot [C+1,4] selects the quaternion + cartesian curves of curve_type="quarternion_cartesian"."""
 
     @staticmethod
     def forward(ctx, ctrl_trans, ctrl_rot, nu, proj_T):
@@ -256,11 +257,12 @@ class _FusedTrajectory(torch.autograd.Function):
         t = nu.detach().float().contiguous()
         pj = proj_T.detach().float().contiguous()
         C, K = ct.shape[0] - 1, t.shape[0]
+        quat = int(cr.shape[-1] == 4)
         view = torch.empty((K, 4, 4), dtype=torch.float32, device=dev)
         full = torch.empty((K, 4, 4), dtype=torch.float32, device=dev)
         cam = torch.empty((K, 3), dtype=torch.float32, device=dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(L.dgs_pose_forward(ct.data_ptr(), cr.data_ptr(), t.data_ptr(), pj.data_ptr(), C, K,
+        _lib.check(L.dgs_pose_forward(ct.data_ptr(), cr.data_ptr(), t.data_ptr(), pj.data_ptr(), C, K, quat,
                                       view.data_ptr(), full.data_ptr(), cam.data_ptr(), st), "dgs_pose_forward")
         ctx.save_for_backward(ct, cr, t, pj)
         ctx.mark_non_differentiable(cam)
@@ -280,7 +282,8 @@ class _FusedTrajectory(torch.autograd.Function):
         d_nu = torch.empty_like(t)
         scratch = torch.empty(L.dgs_pose_scratch_bytes(K), dtype=torch.uint8, device=dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(L.dgs_pose_backward(ct.data_ptr(), cr.data_ptr(), t.data_ptr(), pj.data_ptr(), C, K, gv.data_ptr(),
+        _lib.check(L.dgs_pose_backward(ct.data_ptr(), cr.data_ptr(), t.data_ptr(), pj.data_ptr(), C, K,
+                                       int(cr.shape[-1] == 4), gv.data_ptr(),
                                        gf.data_ptr(), scratch.data_ptr(), d_ct.data_ptr(), d_cr.data_ptr(),
                                        d_nu.data_ptr(), st), "dgs_pose_backward")
         return d_ct, d_cr, d_nu, None

@@ -42,7 +42,7 @@ class TrainingLoop:
         the ground-truth images are already linear.
         fused_step: "auto" (default) enqueues the iteration's device work through deblurgs_amd.fused_step.FusedStep (no
         autograd graph, no host synchronisation; `speculative` sizes the duplicate arrays ahead, see that module) whenever
-        the configuration allows it (se3 curves, fused activations, no depth-TV term, not "subframes" sharding), and falls
+        the configuration allows it (fused activations, no depth-TV term, not "subframes" sharding), and falls
         back to the autograd path (CameraMotionModule.query + losses) otherwise; False forces the autograd path.
         log_losses=False skips forming the scalar "loss" entry of step()'s result (two tiny launches).
         Not carried over from train.py: logging / visualiser / checkpoint-saving calls and `args.flag`."""

@@ -299,7 +299,9 @@ int dgs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* 
  * subframe times nu, se3_exp_map, and the three camera tensors render() reads -- scene/bezier.py:54-83,
  * utils/pytorch3d_functions.py:373-457, scene/motion.py:248-294, scene/cameras.py:63-74 -- as one kernel, and its
  * backward from dL/d{world_view, full_proj} to the control points and nu.  ctrl_* are [C+1,3] (one curve),
- * proj is the transposed projection matrix [4,4] (row-vector convention), outputs are [K,4,4], [K,4,4], [K,3]. */
+ * proj is the transposed projection matrix [4,4] (row-vector convention), outputs are [K,4,4], [K,4,4], [K,3].
+ * quaternion != 0: curve_type "quarternion_cartesian" (scene/motion.py:191-194,242-246): ctrl_rot is [C+1,4], a
+ * quaternion curve (x, y, z, w) that is normalised and turned into the c2w rotation, ctrl_trans the camera origin. */
 /* Subframe times of one view from its alignment parameters (scene/motion.py:209-219):
  * nu = sort(clamp(cat(0, sigmoid(raw) [+ uniform / n_subframes - 1 / (2 n_subframes)], 1), 0, 1)), f values from the
  * f - 2 raw ones (uniform: optional [f-2] samples of U(0,1), the reference's curve_random_sample); src[r] = index of
@@ -311,10 +313,10 @@ int dgs_alignment_backward(const float* raw, const float* uniform, int32_t f, in
                            const float* dL_dnu, float* dL_draw, dgs_stream_t stream);
 size_t dgs_pose_scratch_bytes(int32_t K);
 int dgs_pose_forward(const float* ctrl_trans, const float* ctrl_rot, const float* nu, const float* proj, int32_t C,
-                     int32_t K, float* view, float* full, float* campos, dgs_stream_t stream);
+                     int32_t K, int32_t quaternion, float* view, float* full, float* campos, dgs_stream_t stream);
 int dgs_pose_backward(const float* ctrl_trans, const float* ctrl_rot, const float* nu, const float* proj, int32_t C,
-                      int32_t K, const float* dL_dview, const float* dL_dfull, void* scratch, float* dL_dctrl_trans,
-                      float* dL_dctrl_rot, float* dL_dnu, dgs_stream_t stream);
+                      int32_t K, int32_t quaternion, const float* dL_dview, const float* dL_dfull, void* scratch,
+                      float* dL_dctrl_trans, float* dL_dctrl_rot, float* dL_dnu, dgs_stream_t stream);
 
 /* The cloud's activations as the raw_params kernels evaluate them -- clamp(opacity, 0, 1), exp(scaling) + scale_lb,
  * rotation / max(|rotation|, 1e-12): the reference's get_opacity / get_scaling / get_rotation getters

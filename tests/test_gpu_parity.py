@@ -558,19 +558,21 @@ def test_metric_size_properties(gpu):
 # product path exactly as bench.py runs it, by tests/test_gpu_configs.py.
 
 
-@pytest.mark.parametrize("K,C", [(15, 3), (21, 9), (1, 3), (31, 5)])
-def test_fused_pose_kernel_matches_torch_path(gpu, K, C):
+@pytest.mark.parametrize("K,C,curve", [(15, 3, "se3"), (21, 9, "se3"), (1, 3, "se3"), (31, 5, "se3"),
+                                       (15, 3, "quarternion_cartesian"), (21, 9, "quarternion_cartesian")])
+def test_fused_pose_kernel_matches_torch_path(gpu, K, C, curve):
     """csrc/pose.hip (one kernel) against the torch-op pose path, which tests/test_oracle_golden.py pins to the
-    reference's se3_exp_map / Bezier / MiniCam recipe."""
+    reference's se3_exp_map / Bezier / MiniCam recipe (quaternion curves: to the SciPy-pinned conversions)."""
     import torch
     from deblurgs_amd.motion import CameraMotionModule, RefCamera
     torch.manual_seed(K * 100 + C)
     ref = RefCamera(320, 200, 1.0, 0.7, device="cuda")
     m = CameraMotionModule(ref, torch.rand(2, 3, 8, 8, device="cuda"), curve_order=C, num_subframes=max(K, 1),
-                           init_se3=torch.randn(2, 6) * 0.2, device="cuda")
+                           init_se3=torch.randn(2, 6) * 0.2, device="cuda", curve_type=curve)
+    assert m._rot._control_points.shape[-1] == (4 if curve != "se3" else 3)
     with torch.no_grad():
         m._trans._control_points.add_(torch.randn_like(m._trans._control_points) * 0.05)
-        m._rot._control_points.add_(torch.randn_like(m._rot._control_points) * 0.05)
+        m._rot._control_points.add_(torch.randn_like(m._rot._control_points) * 0.05)   # (no longer unit quaternions)
         if m._nu.numel():
             m._nu.add_(torch.randn_like(m._nu) * 0.3)
     gW = torch.randn(max(K, 1) if K > 1 else 2, 4, 4, device="cuda")

@@ -340,7 +340,7 @@ def test_fused_activations_equal_the_getter_path(gpu, deg, scale_lb, iso):
 
 
 # ------------------------------------------------------------------------------------------- fused training step
-def _fused_fixture(seed=3, K=5, P=3000):
+def _fused_fixture(seed=3, K=5, P=3000, curve_type="se3"):
     import torch
     from helpers import synthetic
     from deblurgs_amd.cloud import GaussianCloud
@@ -353,7 +353,8 @@ def _fused_fixture(seed=3, K=5, P=3000):
         cloud._opacity[4::13] = -0.05
     ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device="cuda")
     gt = torch.rand(3, 3, sc["H"], sc["W"], device="cuda")
-    m = CameraMotionModule(ref, gt, curve_order=4, num_subframes=K, init_se3=torch.randn(3, 6) * 0.01, device="cuda")
+    m = CameraMotionModule(ref, gt, curve_order=4, num_subframes=K, init_se3=torch.randn(3, 6) * 0.01, device="cuda",
+                           curve_type=curve_type)
     with torch.no_grad():
         m._trans._control_points.add_(torch.randn_like(m._trans._control_points) * 0.02)
         m._rot._control_points.add_(torch.randn_like(m._rot._control_points) * 0.004)
@@ -362,8 +363,9 @@ def _fused_fixture(seed=3, K=5, P=3000):
     return sc, cloud, m
 
 
-@pytest.mark.parametrize("subframes,iso", [("all", False), (3, False), (1, False), ("all", True)])
-def test_fused_step_equals_autograd_path(gpu, subframes, iso):
+@pytest.mark.parametrize("subframes,iso,curve", [("all", False, "se3"), (3, False, "se3"), (1, False, "se3"),
+                                                 ("all", True, "se3"), ("all", False, "quarternion_cartesian")])
+def test_fused_step_equals_autograd_path(gpu, subframes, iso, curve):
     """deblurgs_amd.fused_step.FusedStep (the iteration's device work through the C ABI, no autograd) against the autograd
     path it replaces -- CameraMotionModule.query + losses.blur_l1_smooth + lambda_hinge * hinge_l2, loss.backward():
     same subframes bit for bit, same loss values, the same gradients on the cloud (rasteriser part bit-identical, the
@@ -371,7 +373,7 @@ def test_fused_step_equals_autograd_path(gpu, subframes, iso):
     import torch
     from deblurgs_amd import losses
     from deblurgs_amd.fused_step import FusedStep
-    sc, cloud, m = _fused_fixture()
+    sc, cloud, m = _fused_fixture(curve_type=curve)
     cloud.use_isotrophic = iso
     lam_t, lam_h, cam = 2e-3, 0.1, 1
     bg = torch.tensor([0.2, 0.5, 0.1], device="cuda")
