@@ -90,8 +90,12 @@ class FusedStep:
 
     # ------------------------------------------------------------------------------------------------- the step
     @torch.no_grad()
-    def run(self, cam_idx, lambda_t, gt, background, subframe_indice="all", need_blur=False, uniform=None):
+    def run(self, cam_idx, lambda_t, gt, background, subframe_indice="all", need_blur=False, uniform=None,
+            lambda_depth_tv=0.0):
         """gt: [3,H,W] ground truth of view cam_idx (already tone-mapped / noised by the caller); background: [3].
+        lambda_depth_tv > 0 adds the reference's optional depth-smoothness term (train.py:150-153,
+        utils/loss_utils.py:66-78): its gradient on the K depth images is formed with a few torch ops and handed to the
+        rasteriser's backward as dL/ddepth; 'depth_tv' is its value.
         Returns a dict: 'losses' (device float32 [2]: L1(blur, gt), smoothness -- no host read), 'blur' ([3,H,W] if
         need_blur), 'radii' [K,P] int32, 'viewspace_grad' [K,P,3], 'K', 'skip_flag_ptr' (int or None)."""
         L = _lib.lib()
@@ -218,7 +222,15 @@ class FusedStep:
         scratch = torch.empty(L.dgs_backward_scratch_bytes(R, P, K), dtype=torch.uint8, device=dev)
         io = _lib.DgsBackwardIO()
         io.num_rendered = R
-        io.radii, io.dL_dout_color, io.dL_dout_depth = ctypes.c_void_p(radii.data_ptr()), _ptr(dsub), None
+        depth_tv, g_depth = None, None
+        if lambda_depth_tv > 0.0:
+            from . import losses as _losses
+            with torch.enable_grad():
+                dleaf = depth.detach().requires_grad_(True)
+                depth_tv = _losses.tv_loss(dleaf)
+                g_depth, = torch.autograd.grad(float(lambda_depth_tv) * depth_tv, dleaf)
+            g_depth, depth_tv = g_depth.contiguous(), depth_tv.detach()
+        io.radii, io.dL_dout_color, io.dL_dout_depth = ctypes.c_void_p(radii.data_ptr()), _ptr(dsub), _ptr(g_depth)
         io.scratch, io.scratch_bytes = ctypes.c_void_p(scratch.data_ptr()), scratch.numel()
         io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh = _ptr(g_xyz), _ptr(g_means2D), _ptr(g_dc)
         io.dL_dsh_rest = _ptr(g_rest) if Mr > 0 else None
@@ -251,6 +263,6 @@ class FusedStep:
                 _lib.check(L.dgs_alignment_backward(raw_ptr, _ptr(uniform), f, f, _ptr(src), _ptr(d_nu),
                                                     _ptr(d_raw_all, cam * nrow), stream), "dgs_alignment_backward")
                 m._nu.grad = d_raw_all
-        self._keep = (geom, image, binning, scratch, color, depth, dsub, view, full, campos, nu, gtc, bg, flat)
+        self._keep = (geom, image, binning, scratch, color, depth, dsub, view, full, campos, nu, gtc, bg, flat, g_depth)
         return {"losses": losses, "blur": blur if need_blur else None, "radii": radii, "viewspace_grad": g_means2D,
-                "K": K, "subframes": color, "depths": depth, "skip_flag_ptr": skip_ptr}
+                "K": K, "subframes": color, "depths": depth, "skip_flag_ptr": skip_ptr, "depth_tv": depth_tv}

@@ -363,9 +363,11 @@ def _fused_fixture(seed=3, K=5, P=3000, curve_type="se3"):
     return sc, cloud, m
 
 
-@pytest.mark.parametrize("subframes,iso,curve", [("all", False, "se3"), (3, False, "se3"), (1, False, "se3"),
-                                                 ("all", True, "se3"), ("all", False, "quarternion_cartesian")])
-def test_fused_step_equals_autograd_path(gpu, subframes, iso, curve):
+@pytest.mark.parametrize("subframes,iso,curve,tv", [("all", False, "se3", 0.0), (3, False, "se3", 0.0),
+                                                    (1, False, "se3", 0.0), ("all", True, "se3", 0.0),
+                                                    ("all", False, "quarternion_cartesian", 0.0),
+                                                    ("all", False, "se3", 0.05)])
+def test_fused_step_equals_autograd_path(gpu, subframes, iso, curve, tv):
     """deblurgs_amd.fused_step.FusedStep (the iteration's device work through the C ABI, no autograd) against the autograd
     path it replaces -- CameraMotionModule.query + losses.blur_l1_smooth + lambda_hinge * hinge_l2, loss.backward():
     same subframes bit for bit, same loss values, the same gradients on the cloud (rasteriser part bit-identical, the
@@ -383,13 +385,18 @@ def test_fused_step_equals_autograd_path(gpu, subframes, iso, curve):
     hinge = losses.hinge_l2(cloud._opacity)
     out = m.query(cam, subframes, background=bg, compute_blurred=False)
     total, blur, lv = losses.blur_l1_smooth(out["subframes"], out["gt"], lam_t)
-    (total + lam_h * hinge).backward()
+    loss = total + lam_h * hinge
+    if tv > 0.0:       # the optional depth-smoothness term (train.py:150-153)
+        loss = loss + tv * losses.tv_loss(out["depths"])
+    loss.backward()
     ref = [None if p.grad is None else p.grad.detach().clone() for p in params]
     ref_vs = out["viewspace_points_all"].grad.detach().clone()
     for p in params:
         p.grad = None
     fs = FusedStep(cloud, m, lambda_hinge=lam_h, speculative=False)
-    fr = fs.run(cam, lam_t, m.get_gt_image(cam), bg, subframes, need_blur=True)
+    fr = fs.run(cam, lam_t, m.get_gt_image(cam), bg, subframes, need_blur=True, lambda_depth_tv=tv)
+    if tv > 0.0:
+        assert torch.equal(fr["depth_tv"], losses.tv_loss(out["depths"]).detach())
     torch.cuda.synchronize()
     assert torch.equal(fr["subframes"], out["subframes"]) and torch.equal(fr["radii"], out["radii_all"])
     assert torch.equal(fr["blur"], blur) and torch.equal(fr["viewspace_grad"], ref_vs)
