@@ -88,14 +88,40 @@ class FusedStep:
             return h
         return torch.zeros(4, dtype=torch.int32).pin_memory()
 
+    def _empty_slice(self, gt, lambda_t, K_total, P, H, W, ct_all, cr_all, nu_raw, need_blur):
+        """"subframes" sharding with more ranks than subframes: this rank rasterises nothing but takes part in the loss
+        block's exchanges; all its gradients are zero."""
+        from . import sharding
+        cloud, m = self.cloud, self.motion
+        dev = cloud._xyz.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        color = torch.zeros((0, 3, H, W), **f32)
+        _, l1, sm = sharding.subframe_sharded_loss_grad(color, gt.to(dev, torch.float32).contiguous(), K_total,
+                                                        float(lambda_t))
+        for p in cloud.hot_parameters():
+            p.grad = torch.zeros_like(p)
+        if m.is_optimizing():
+            m._trans._control_points.grad, m._rot._control_points.grad = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
+            if nu_raw.numel() > 0:
+                m._nu.grad = torch.zeros_like(nu_raw)
+        return {"losses": torch.stack([l1.reshape(()), sm.reshape(())]).float(), "blur": None,
+                "radii": torch.zeros((0, P), dtype=torch.int32, device=dev), "viewspace_grad": torch.zeros((0, P, 3), **f32),
+                "K": K_total, "subframes": color, "depths": torch.zeros((0, 1, H, W), **f32), "skip_flag_ptr": None,
+                "depth_tv": None}
+
     # ------------------------------------------------------------------------------------------------- the step
     @torch.no_grad()
     def run(self, cam_idx, lambda_t, gt, background, subframe_indice="all", need_blur=False, uniform=None,
-            lambda_depth_tv=0.0):
+            lambda_depth_tv=0.0, shard=None):
         """gt: [3,H,W] ground truth of view cam_idx (already tone-mapped / noised by the caller); background: [3].
         lambda_depth_tv > 0 adds the reference's optional depth-smoothness term (train.py:150-153,
         utils/loss_utils.py:66-78): its gradient on the K depth images is formed with a few torch ops and handed to the
         rasteriser's backward as dL/ddepth; 'depth_tv' is its value.
+        shard=(rank, world): "subframes" sharding (deblurgs_amd.sharding): this rank rasterises subframes
+        [floor(rank K / world), floor((rank+1) K / world)) of the view; the loss block runs across the ranks
+        (sharding.subframe_sharded_loss_grad: one all-reduce of the partial blur sum, one boundary frame each way), the
+        gradients are this rank's PARTIAL sums (the caller adds them over the ranks; the opacity hinge is added on rank 0
+        only); 'radii' / 'viewspace_grad' / 'subframes' hold the local slice, 'K' the view's subframe count.
         Returns a dict: 'losses' (device float32 [2]: L1(blur, gt), smoothness -- no host read), 'blur' ([3,H,W] if
         need_blur), 'radii' [K,P] int32, 'viewspace_grad' [K,P,3], 'K', 'skip_flag_ptr' (int or None)."""
         L = _lib.lib()
@@ -141,9 +167,18 @@ class FusedStep:
         _lib.check(L.dgs_pose_forward(_ptr(ct_all, row), _ptr(cr_all, rrow), _ptr(nu), _ptr(proj), C, K, quat, _ptr(view),
                                       _ptr(full), _ptr(campos), stream), "dgs_pose_forward")
 
+        K_total, k0 = K, 0
+        nu_loc = nu
+        if shard is not None:
+            from .sharding import shard_range
+            k0, k1 = shard_range(K_total, int(shard[0]), int(shard[1]))
+            view, full, campos, nu_loc = view[k0:k1], full[k0:k1], campos[k0:k1], nu[k0:k1]   # (contiguous row slices)
+            K = k1 - k0
         # ---- forward
         P = cloud._xyz.shape[0]
         H, W = int(m.ref_cam.image_height), int(m.ref_cam.image_width)
+        if K == 0:
+            return self._empty_slice(gt, lambda_t, K_total, P, H, W, ct_all, cr_all, nu_raw, need_blur)
         rest = cloud._features_rest if cloud._features_rest.shape[1] > 0 else None
         Mr = 0 if rest is None else rest.shape[1]
         color = torch.empty((K, 3, H, W), **f32)
@@ -202,8 +237,15 @@ class FusedStep:
         dsub = torch.empty((K, 3, H, W), **f32)
         work = torch.empty(8, **f32)          # dgs_blur_loss_grad's work area: [l1, smooth | accumulators, counter]
         losses = work[:2]
-        _lib.check(L.dgs_blur_loss_grad(_ptr(color), _ptr(gtc), K, 3, H * W, float(lambda_t), None, _ptr(blur),
-                                        _ptr(dsub), _ptr(work), stream), "dgs_blur_loss_grad")
+        if shard is None:
+            _lib.check(L.dgs_blur_loss_grad(_ptr(color), _ptr(gtc), K, 3, H * W, float(lambda_t), None, _ptr(blur),
+                                            _ptr(dsub), _ptr(work), stream), "dgs_blur_loss_grad")
+        else:   # the loss block across the ranks holding the view's other subframes
+            from . import sharding
+            dsub, l1, sm = sharding.subframe_sharded_loss_grad(color, gtc, K_total, float(lambda_t))
+            dsub = dsub.contiguous()
+            losses = torch.stack([l1.reshape(()), sm.reshape(())]).float()
+            blur = None
 
         # ---- backward: one flat gradient bucket in optimiser-group order (as _RasterizeCloudK.backward)
         sizes = [3 * P, 3 * P, 3 * Mr * P, P, 3 * P, 4 * P]
@@ -236,7 +278,8 @@ class FusedStep:
         io.dL_dsh_rest = _ptr(g_rest) if Mr > 0 else None
         io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations = _ptr(g_colors), _ptr(g_op), _ptr(g_sc), _ptr(g_rot)
         io.dL_dcov3D, io.dL_dviewmatrix, io.dL_dprojmatrix = _ptr(g_cov3D), _ptr(g_view), _ptr(g_proj)
-        io.opacity_hinge_scale = self.lambda_hinge / max(P, 1)
+        # sharded: the ranks' gradients are summed, so the hinge term is added by one of them only
+        io.opacity_hinge_scale = self.lambda_hinge / max(P, 1) if (shard is None or int(shard[0]) == 0) else 0.0
         _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward")
         if P == 0:
             flat.zero_()
@@ -249,13 +292,17 @@ class FusedStep:
             d_ct_all, d_cr_all = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
             d_nu = torch.empty(K, **f32)
             pscratch = torch.empty(L.dgs_pose_scratch_bytes(K), dtype=torch.uint8, device=dev)
-            _lib.check(L.dgs_pose_backward(_ptr(ct_all, row), _ptr(cr_all, rrow), _ptr(nu), _ptr(proj), C, K, quat,
+            _lib.check(L.dgs_pose_backward(_ptr(ct_all, row), _ptr(cr_all, rrow), _ptr(nu_loc), _ptr(proj), C, K, quat,
                                            _ptr(g_view),
                                            _ptr(g_proj), ctypes.c_void_p(pscratch.data_ptr()), _ptr(d_ct_all, row),
                                            _ptr(d_cr_all, rrow), _ptr(d_nu), stream), "dgs_pose_backward")
             m._trans._control_points.grad, m._rot._control_points.grad = d_ct_all, d_cr_all
             if nrow > 0:
                 d_raw_all = torch.zeros_like(nu_raw)
+                if shard is not None:                    # this rank's slice of the view's subframe times
+                    d_all = torch.zeros(K_total, **f32)
+                    d_all[k0:k0 + K] = d_nu
+                    d_nu = d_all
                 if sel is not None:                      # gradients of the selected subframes back to all f slots
                     d_full = torch.zeros(f, **f32)
                     d_full.index_add_(0, sel, d_nu)
@@ -265,4 +312,4 @@ class FusedStep:
                 m._nu.grad = d_raw_all
         self._keep = (geom, image, binning, scratch, color, depth, dsub, view, full, campos, nu, gtc, bg, flat, g_depth)
         return {"losses": losses, "blur": blur if need_blur else None, "radii": radii, "viewspace_grad": g_means2D,
-                "K": K, "subframes": color, "depths": depth, "skip_flag_ptr": skip_ptr, "depth_tv": depth_tv}
+                "K": K_total, "subframes": color, "depths": depth, "skip_flag_ptr": skip_ptr, "depth_tv": depth_tv}

@@ -188,6 +188,16 @@ def subframe_sharded_loss_backward(local_subframes, gt, K, k0, lambda_t, group=N
     autograd graph of the rasteriser.  Computes the reference loss block (train.py:147-163 image terms:
     L1(mean_k, gt) + lambda_t * L1(sub[k+1]-sub[k])) across ranks and back-propagates dL/dsubframes through the
     local graph.  Returns (l1, smooth) as python floats (identical on every rank)."""
+    dS, l1, sm = subframe_sharded_loss_grad(local_subframes, gt, K, lambda_t, group)
+    if local_subframes.shape[0] > 0:
+        local_subframes.backward(gradient=dS)
+    return float(l1), float(sm)
+
+
+def subframe_sharded_loss_grad(local_subframes, gt, K, lambda_t, group=None):
+    """The loss block of subframe_sharded_loss_backward without autograd: returns (dL/dlocal_subframes, l1, smooth),
+    the two values as device scalars (identical on every rank).  fused_step.FusedStep hands the gradient straight to the
+    rasteriser's backward."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     S = local_subframes.detach()
@@ -249,6 +259,4 @@ def subframe_sharded_loss_backward(local_subframes, gt, K, k0, lambda_t, group=N
         sm_local = own.abs().sum() / (E * (K - 1))
     if world > 1:
         dist.all_reduce(sm_local, op=dist.ReduceOp.SUM, group=group)
-    if k_loc > 0:
-        local_subframes.backward(gradient=dS)
-    return float(d.abs().mean()), float(sm_local)
+    return dS, d.abs().mean(), sm_local

@@ -42,7 +42,7 @@ class TrainingLoop:
         the ground-truth images are already linear.
         fused_step: "auto" (default) enqueues the iteration's device work through deblurgs_amd.fused_step.FusedStep (no
         autograd graph, no host synchronisation; `speculative` sizes the duplicate arrays ahead, see that module) whenever
-        the configuration allows it (fused activations, not "subframes" sharding), and falls
+        the cloud allows it (fused activations), and falls
         back to the autograd path (CameraMotionModule.query + losses) otherwise; False forces the autograd path.
         log_losses=False skips forming the scalar "loss" entry of step()'s result (two tiny launches).
         Not carried over from train.py: logging / visualiser / checkpoint-saving calls and `args.flag`."""
@@ -72,7 +72,7 @@ class TrainingLoop:
         cam_motion_module.alternate_optimization()      # train.py:102, unconditional: curve gradients off at the start
         self.log_losses = log_losses
         self._fused = None
-        if fused_step and self.mode != "subframes":
+        if fused_step:
             try:
                 from .fused_step import FusedStep
                 if gaussians._xyz.device.type == "cuda":
@@ -139,18 +139,32 @@ class TrainingLoop:
         dev = g._xyz.device
         gt = self._ground_truth(cam_idx, self.motion.get_gt_image(cam_idx), iteration)
         bg = torch.rand(3, device=dev)                                   # scene/motion.py:112-113
+        shard = None
+        if self.mode == "subframes":
+            import torch.distributed as dist
+            if self.opt.lambda_depth_tv > 0.0:
+                raise NotImplementedError("lambda_depth_tv with 'subframes' sharding")
+            shard = (dist.get_rank(), dist.get_world_size())
+            dist.broadcast(bg, src=0)          # one view, one background: every rank composites over rank 0's draw
         fr = self._fused.run(cam_idx, lambda_t_smooth, gt, bg, subframe_indice,
-                             lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0))
+                             lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0), shard=shard)
         skip = fr["skip_flag_ptr"]
         if self.distributed:
             from . import sharding
             import torch.distributed as dist
-            if skip is not None:
-                # a rank whose duplicate capacity overflowed holds a meaningless gradient: every rank must drop the step
-                off = skip - self._fused._keep[0].data_ptr()
-                flag = self._fused._keep[0][off:off + 4].view(torch.int32)
+            if self._fused.speculative:
+                # a rank whose duplicate capacity overflowed holds a meaningless gradient: every rank must drop the
+                # step (a rank that took the exact path this iteration, or rasterised nothing, brings a zero)
+                if skip is not None:
+                    off = skip - self._fused._keep[0].data_ptr()
+                    flag = self._fused._keep[0][off:off + 4].view(torch.int32)
+                else:
+                    flag = torch.zeros(1, dtype=torch.int32, device=dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            sharding.flat_allreduce_grads(g.hot_parameters(), average=True,
+                self._flag_keep = flag
+                skip = flag.data_ptr()
+            # "views": a mini-batch of views, gradients averaged; "subframes": partial sums of one view's gradient
+            sharding.flat_allreduce_grads(g.hot_parameters(), average=self.mode != "subframes",
                                           extra=[p for p in self.motion.parameters() if p.requires_grad])
         g.optimizer.skip_flag_ptr = skip
         r = {"viewspace_points_all": fr["viewspace_grad"], "radii_all": fr["radii"], "K_total": fr["K"],
