@@ -80,6 +80,8 @@ void make_layout(int P, int W, int H, int K, uint64_t R, DgsLayout* L) {
 int check_problem(const DgsProblem* p) {
   if (p == nullptr) return fail(DGS_E_ARG, "null DgsProblem");
   if (p->P < 0 || p->W <= 0 || p->H <= 0) return fail(DGS_E_ARG, "bad P/W/H");
+  // tile coordinates are packed into 12 bits each by the duplication kernels (and tile counts stay below 2^24)
+  if (p->W > 4095 * DGS_TILE || p->H > 4095 * DGS_TILE) return fail(DGS_E_ARG, "W / H above 65520 pixels");
   if (p->K < 1 || p->K > DGS_MAX_K) return fail(DGS_E_ARG, "K must be in [1, DGS_MAX_K]");
   if (p->D < 0 || p->D > 3) return fail(DGS_E_ARG, "SH degree must be 0..3");
   if (p->P == 0) return DGS_OK;

@@ -9,6 +9,24 @@
 
 #include "dgs_common.h"
 
+// n / d and n % d for n < 2^24, 1 <= d < 2^12 (slots of a tile rectangle by its width) from a float reciprocal:
+// 3 conversions / multiplies, one 24-bit multiply and a fix-up, instead of the ~22 instructions (six of them quarter-rate
+// 32-bit multiplies) of a u32 division.  float(n) is exact and the quotient is below 2^12, so the estimate is off by at
+// most one; the fix-up makes the result exact.
+__device__ __forceinline__ void dgs_divmod_u24(uint32_t n, uint32_t d, float inv_d, uint32_t& q, uint32_t& r) {
+  uint32_t qe = (uint32_t)((float)n * inv_d);
+  int rr = (int)n - (int)__umul24(qe, d);
+  if (rr < 0) {
+    qe -= 1u;
+    rr += (int)d;
+  } else if (rr >= (int)d) {
+    qe += 1u;
+    rr -= (int)d;
+  }
+  q = qe;
+  r = (uint32_t)rr;
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ scan
@@ -172,6 +190,7 @@ duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __
   __shared__ uint32_t s_off[4][64];    // segment start relative to the wave's first duplicate
   __shared__ uint32_t s_rect[4][64];   // minx | miny << 12 | width << 24  (grid <= 4095 tiles per side, width <= 255)
   __shared__ uint32_t s_wide[4][64];   // full width for rectangles wider than 255 tiles
+  __shared__ float s_invw[4][64];      // 1 / width (dgs_divmod_u24)
   __shared__ uint32_t s_tb[4][64];     // k * T
   __shared__ uint32_t s_db[4][64];     // depth bits
   __shared__ uint32_t s_g[4][64];      // Gaussian index
@@ -199,6 +218,7 @@ duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __
     }
     s_rect[w][lane] = rect;
     s_wide[w][lane] = wide;
+    s_invw[w][lane] = __builtin_amdgcn_rcpf((float)wide);
     s_tb[w][lane] = tb;
     s_db[w][lane] = db;
     s_g[w][lane] = g;
@@ -225,8 +245,9 @@ duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __
     const uint32_t local = d - s_off[w][lo];
     const uint32_t width = s_wide[w][lo];
     const uint32_t rect = s_rect[w][lo];
-    const uint32_t ry = local / width, rx = local - ry * width;
-    const uint32_t tile = s_tb[w][lo] + ((rect >> 12) + ry) * (uint32_t)v.gx + (rect & 0xFFFu) + rx;
+    uint32_t ry, rx;
+    dgs_divmod_u24(local, width, s_invw[w][lo], ry, rx);
+    const uint32_t tile = s_tb[w][lo] + __umul24((rect >> 12) + ry, (uint32_t)v.gx) + (rect & 0xFFFu) + rx;
     if (base + d < cap) {   // cap = capacity of the duplicate arrays (the exact count unless the caller sized them ahead)
       keys[base + d] = ((uint64_t)tile << 32) | s_db[w][lo];
       vals[base + d] = s_g[w][lo];
@@ -260,6 +281,7 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
   __shared__ uint32_t s_off[4][64];
   __shared__ uint32_t s_rect[4][64];
   __shared__ uint32_t s_wide[4][64];
+  __shared__ float s_invw[4][64];   // 1 / width (dgs_divmod_u24)
   __shared__ uint32_t s_tb[4][64];
   __shared__ uint32_t s_g[4][64];
   __shared__ uint32_t s_cnt[4][64];
@@ -302,6 +324,7 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
     }
     s_rect[w][lane] = rect;
     s_wide[w][lane] = wide;
+    s_invw[w][lane] = __builtin_amdgcn_rcpf((float)wide);
     s_tb[w][lane] = tb;
     s_g[w][lane] = g;
     s_q[w][lane] = q;
@@ -336,9 +359,10 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
       const uint32_t local = d - s_off[w][lo];
       const uint32_t width = s_wide[w][lo];
       const uint32_t rect = s_rect[w][lo];
-      const uint32_t ry = local / width, rx = local - ry * width;
+      uint32_t ry, rx;
+      dgs_divmod_u24(local, width, s_invw[w][lo], ry, rx);
       const uint32_t tx = (rect & 0xFFFu) + rx, ty = (rect >> 12) + ry;
-      tile = s_tb[w][lo] + ty * (uint32_t)v.gx + tx;
+      tile = s_tb[w][lo] + __umul24(ty, (uint32_t)v.gx) + tx;
       const float4 q = s_q[w][lo], r = s_r[w][lo];
       const uint32_t fl = s_fl[w][lo];
       DgsCull cg;
