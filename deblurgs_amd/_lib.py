@@ -26,6 +26,7 @@ class DgsProblem(ctypes.Structure):
         ("z_near", ctypes.c_float), ("z_far", ctypes.c_float),
         ("use_sigmoid", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
         ("tile_cull", ctypes.c_int32), ("raw_params", ctypes.c_int32), ("scale_lb", ctypes.c_float),
+        ("wide_records", ctypes.c_int32),
         ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p), ("shs_rest", ctypes.c_void_p),
         ("colors_precomp", ctypes.c_void_p),
         ("opacities", ctypes.c_void_p), ("scales", ctypes.c_void_p), ("rotations", ctypes.c_void_p),
@@ -75,7 +76,7 @@ class DgsCloudArrays(ctypes.Structure):
 
 
 ADAM_MAX_GROUPS = 16
-ABI_VERSION = 5            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
+ABI_VERSION = 6            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
 
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {
@@ -86,7 +87,9 @@ EXPORTS = {
     "dgs_binning_state_bytes": (ctypes.c_size_t, [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "dgs_backward_scratch_bytes": (ctypes.c_size_t, [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32]),
     "dgs_layout": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64,
-                                  ctypes.POINTER(DgsLayout)]),
+                                  ctypes.c_int32, ctypes.POINTER(DgsLayout)]),
+    "dgs_backward_scratch_layout": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32,
+                                                   ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "dgs_forward_geometry": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsForwardOut),
                                             ctypes.c_void_p]),
     "dgs_forward_render": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsForwardOut),
@@ -164,10 +167,21 @@ def check(rc, what):
         raise RuntimeError(f"libdgs_hip {what} failed (code {rc}): {msg}")
 
 
-def layout(P, W, H, K, R):
+def layout(P, W, H, K, R, wide_records=None):
+    """wide_records=None: the package-wide default (diff_gaussian_rasterization.WIDE_RECORDS)."""
+    if wide_records is None:
+        from . import diff_gaussian_rasterization as dgr
+        wide_records = dgr.WIDE_RECORDS
     L = DgsLayout()
-    check(lib().dgs_layout(P, W, H, K, R, ctypes.byref(L)), "dgs_layout")
+    check(lib().dgs_layout(P, W, H, K, R, int(bool(wide_records)), ctypes.byref(L)), "dgs_layout")
     return L
+
+
+def backward_scratch_layout(R, P, K):
+    """(sums_offset, partials_offset) of DgsBackwardIO.scratch, in bytes."""
+    so, po = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib().dgs_backward_scratch_layout(int(R), P, K, ctypes.byref(so), ctypes.byref(po)), "scratch_layout")
+    return so.value, po.value
 
 
 def profile_enable(on=True):

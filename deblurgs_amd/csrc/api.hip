@@ -29,7 +29,7 @@ int sort_bits_for(int W, int H, int K) {
   return 32 + (int)dgs_higher_msb(T * (uint32_t)K);  // rasterizer_impl.cu:306, with K*T tiles
 }
 
-void make_layout(int P, int W, int H, int K, uint64_t R, DgsLayout* L) {
+void make_layout(int P, int W, int H, int K, uint64_t R, bool wide_records, DgsLayout* L) {
   const size_t KP = (size_t)K * (size_t)P;
   const size_t N = (size_t)W * (size_t)H;
   const size_t T = (size_t)((W + DGS_TILE - 1) / DGS_TILE) * (size_t)((H + DGS_TILE - 1) / DGS_TILE);
@@ -66,8 +66,7 @@ void make_layout(int P, int W, int H, int K, uint64_t R, DgsLayout* L) {
   L->sort_bits = sort_bits_for(W, H, K);
   L->sort_passes = dgs_sort_num_passes(32, L->sort_bits);
   // compact keys (tile_cull only): tile | Gaussian | emission index in one 64-bit word when the three fit
-  const char* ck = getenv("DGS_COMPACT_KEYS");   // "0": keep key + value arrays (A/B switch, tests of that path)
-  const bool compact = ck == nullptr || ck[0] != '0';
+  const bool compact = !wide_records;   // DgsProblem.wide_records: keep key + value arrays
   const int u_bits = (int)dgs_higher_msb64(R), g_bits = (int)dgs_higher_msb((uint32_t)(P > 0 ? P : 1));
   L->pack_g_shift = 0;
   L->pack_tile_shift = 0;
@@ -475,17 +474,17 @@ const char* dgs_last_error(void) { return g_err; }
 
 size_t dgs_geom_state_bytes(int32_t P, int32_t K) {
   DgsLayout L;
-  make_layout(P, 16, 16, K, 0, &L);
+  make_layout(P, 16, 16, K, 0, false, &L);
   return L.geom_total;
 }
 size_t dgs_image_state_bytes(int32_t W, int32_t H, int32_t K) {
   DgsLayout L;
-  make_layout(0, W, H, K, 0, &L);
+  make_layout(0, W, H, K, 0, false, &L);
   return L.image_total;
 }
 size_t dgs_binning_state_bytes(uint64_t R, int32_t W, int32_t H, int32_t K) {
   DgsLayout L;
-  make_layout(0, W, H, K, R, &L);
+  make_layout(0, W, H, K, R, false, &L);
   return L.binning_total;
 }
 size_t dgs_backward_scratch_bytes(uint64_t R, int32_t P, int32_t K) {
@@ -493,9 +492,15 @@ size_t dgs_backward_scratch_bytes(uint64_t R, int32_t P, int32_t K) {
   return up((size_t)R * DGS_CONTRIB_F * 4) + up((size_t)K * (size_t)P * DGS_CONTRIB_F * 4) +
          up((size_t)dgs_geometry_bwd_blocks(P) * (size_t)K * 24 * 4) + ALIGN;
 }
-int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, DgsLayout* out) {
+int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, int32_t wide_records, DgsLayout* out) {
   if (out == nullptr) return fail(DGS_E_ARG, "null DgsLayout");
-  make_layout(P, W, H, K, R, out);
+  make_layout(P, W, H, K, R, wide_records != 0, out);
+  return DGS_OK;
+}
+int dgs_backward_scratch_layout(uint64_t R, int32_t P, int32_t K, size_t* sums_offset, size_t* partials_offset) {
+  const size_t so = up((size_t)R * DGS_CONTRIB_F * 4);
+  if (sums_offset) *sums_offset = so;
+  if (partials_offset) *partials_offset = so + up((size_t)K * (size_t)P * DGS_CONTRIB_F * 4);
   return DGS_OK;
 }
 
@@ -519,7 +524,7 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
   }
   if (out->radii == nullptr) return fail(DGS_E_ARG, "DgsForwardOut: radii is null");
   DgsLayout L;
-  make_layout(p->P, p->W, p->H, p->K, 0, &L);
+  make_layout(p->P, p->W, p->H, p->K, 0, p->wide_records != 0, &L);
   if (p->geom_state == nullptr || p->geom_bytes < L.geom_total) return fail(DGS_E_CAPACITY, "geom_state too small");
   DgsCarve c;
   carve(p, L, &c);
@@ -562,7 +567,7 @@ static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, ui
     return e == hipSuccess ? DGS_OK : fail_hip(e, "memset outputs");
   }
   DgsLayout L;
-  make_layout(p->P, p->W, p->H, p->K, R, &L);
+  make_layout(p->P, p->W, p->H, p->K, R, p->wide_records != 0, &L);
   if (p->geom_state == nullptr || p->geom_bytes < L.geom_total) return fail(DGS_E_CAPACITY, "geom_state too small");
   if (p->image_state == nullptr || p->image_bytes < L.image_total) return fail(DGS_E_CAPACITY, "image_state too small");
   if (R > 0 && (p->binning_state == nullptr || p->binning_bytes < L.binning_total))
@@ -620,7 +625,7 @@ int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity
   if (rc != DGS_OK) return rc;
   if (p->P > 0) {
     DgsLayout L;
-    make_layout(p->P, p->W, p->H, p->K, 0, &L);
+    make_layout(p->P, p->W, p->H, p->K, 0, p->wide_records != 0, &L);
     DgsCarve c;
     carve(p, L, &c);
     hipError_t e = dgs_launch_finalize_count(c, p->tile_cull != 0, capacity, s);
@@ -658,7 +663,7 @@ int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stre
     return fail(DGS_E_ARG, "dL_dscales / dL_drotations are null");
   const uint64_t R = io->num_rendered;
   DgsLayout L;
-  make_layout(p->P, p->W, p->H, p->K, R, &L);
+  make_layout(p->P, p->W, p->H, p->K, R, p->wide_records != 0, &L);
   if (p->geom_state == nullptr || p->geom_bytes < L.geom_total) return fail(DGS_E_CAPACITY, "geom_state too small");
   if (p->image_state == nullptr || p->image_bytes < L.image_total) return fail(DGS_E_CAPACITY, "image_state too small");
   if (R > 0 && (p->binning_state == nullptr || p->binning_bytes < L.binning_total))

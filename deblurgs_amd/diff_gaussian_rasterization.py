@@ -42,6 +42,13 @@ class GaussianRasterizationSettings(NamedTuple):
 # reference would skip at every pixel of the tile.  Outputs are unchanged; TILE_CULL = False (or DGS_TILE_CULL=0)
 # reproduces the reference's rectangle lists bit for bit.
 TILE_CULL = os.environ.get("DGS_TILE_CULL", "1") != "0"
+# DgsProblem.wide_records: True keeps key + value arrays for the duplicates even when the one-word record fits (the tests
+# of that storage); carried by every problem this module builds, forward and backward alike.
+WIDE_RECORDS = False
+# Test hook: a dict placed here receives the backward's scratch blob and internal gradients ("scratch", "R", "K", "P",
+# "dL_dcov3D", "dL_dcolors") so that the parity tests can read the compositing backward's per-(subframe, Gaussian) totals
+# (dgs_backward_scratch_layout) -- dL_dconic / dL_dopacity / dL_dcov3D before the ill-conditioned scale / rotation chain.
+BACKWARD_DEBUG = None
 
 
 class _NumRendered(int):
@@ -92,6 +99,7 @@ def _make_problem(K, means3D, sh, colors_precomp, opacities, scales, rotations, 
                   rs, geom, image, binning, tile_cull, raw=None):
     p = _lib.DgsProblem()
     p.tile_cull = int(bool(tile_cull))
+    p.wide_records = int(bool(WIDE_RECORDS))
     p.raw_params = 0 if raw is None else (3 if raw.get("isotropic") else 1)
     p.scale_lb = 0.0 if raw is None else float(raw["scale_lb"])
     p.shs_rest = None if raw is None else _ptr(raw["sh_rest"])
@@ -233,6 +241,8 @@ def _backward_impl(K, R, means3D, sh, colors_precomp, opacities_shape, scales, r
                          rs, geom, image, binning, getattr(R, "tile_cull", False))
     prob.opacities = _ptr(means3D)   # not read by the backward; must be non-null for the argument check
     _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), _stream(device)), "dgs_backward")
+    if BACKWARD_DEBUG is not None:
+        BACKWARD_DEBUG.update(scratch=scratch, R=int(R), K=K, P=P, dL_dcov3D=g_cov3D, dL_dcolors=g_colors)
     if P == 0:
         for t in (g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rots, g_cov3D):
             if t is not None:
@@ -474,6 +484,8 @@ class _RasterizeCloudK(torch.autograd.Function):
                              raw={"scale_lb": ctx.scale_lb, "sh_rest": rest, "isotropic": ctx.isotropic})
         prob.M = 1 + Mr
         _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), _stream(device)), "dgs_backward")
+        if BACKWARD_DEBUG is not None:
+            BACKWARD_DEBUG.update(scratch=scratch, R=int(R), K=K, P=P, dL_dcov3D=g_cov3D, dL_dcolors=g_colors)
         if P == 0:
             flat.zero_()
             g_means2D.zero_()

@@ -7,7 +7,8 @@
  *   - plain C: raw device pointers, sizes and a HIP stream handle; no torch types.  The caller owns every
  *     byte (inputs, outputs, gradients, the three state blobs and the backward scratch); the library never
  *     allocates device memory.  Blob sizes come from the dgs_*_bytes() queries, and the carving of a blob
- *     into sub-arrays is a pure function of (P, W, H, K, R), replayed identically by forward and backward
+ *     into sub-arrays is a pure function of (P, W, H, K, R, wide_records) -- no environment variable, no process
+ *     state --, replayed identically by forward and backward
  *     (the reference does the same with GeometryState/ImageState/BinningState::fromChunk,
  *     rasterizer_impl.cu:155-194,389-391).
  *   - the duplicates are generated in (k, depth, index) order (a 15 M-pair sort of the Gaussians) so that the
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 5
+#define DGS_ABI_VERSION 6
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -70,6 +71,10 @@ typedef struct DgsProblem {
                         *    scene/gaussian_model.py:115-118); dL_dscales then carries the summed gradient in column 0
                         *    and zeros in columns 1, 2. */
   float scale_lb;
+  int32_t wide_records; /* tile_cull only.  0 (default): a duplicate is ONE 64-bit word, tile | Gaussian | emission index,
+                         *    whenever the three fit (DgsLayout.pack_*), and the value arrays stay unused; 1: always keep
+                         *    the key (tile << 32 | emission index) and the Gaussian index in separate arrays.  Part of
+                         *    the blob carving: must be the same in the forward and backward calls of one problem. */
   /* inputs, device pointers, fp32 contiguous */
   const float* means3D;        /* [P,3] */
   const float* shs;            /* [P,M,3] or NULL */
@@ -162,7 +167,8 @@ typedef struct DgsLayout {
   size_t binning_total;
   int32_t sort_bits;     /* 32 + bits(K*T): width of the reference-compatible key */
   int32_t sort_passes;   /* digit passes of the duplicate sort (over the tile bits only) */
-  /* tile_cull = 1 only, when bits(K*T) + bits(P) + bits(R) <= 64 (else both are 0 and keys / point_list are as above):
+  /* tile_cull = 1 with wide_records = 0 only, when bits(K*T) + bits(P) + bits(R) <= 64 (else both are 0 and keys /
+   * point_list are as above):
    * the key is the whole record, (tile << pack_tile_shift) | (Gaussian << pack_g_shift) | emission index, point_list /
    * vals_unsorted stay unused and the sort moves 8 instead of 12 bytes per duplicate and pass. */
   int32_t pack_g_shift;
@@ -176,7 +182,15 @@ size_t dgs_geom_state_bytes(int32_t P, int32_t K);
 size_t dgs_image_state_bytes(int32_t W, int32_t H, int32_t K);
 size_t dgs_binning_state_bytes(uint64_t R, int32_t W, int32_t H, int32_t K);
 size_t dgs_backward_scratch_bytes(uint64_t R, int32_t P, int32_t K);
-int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, DgsLayout* out);
+/* wide_records: DgsProblem.wide_records of the problem the layout is for (it only decides pack_g_shift / pack_tile_shift;
+ * the offsets and totals do not depend on it). */
+int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, int32_t wide_records, DgsLayout* out);
+/* Byte offsets inside DgsBackwardIO.scratch (for debuggers and the parity tests): contribution rows f32 [R,12] at 0
+ * ([S_wx, S_wy, S_xx, S_xy, S_yy, S_w, dL_dr, dL_dg, dL_db, dL_ddepth, -, -] per duplicate, in emission order), their
+ * per-(subframe, Gaussian) totals f32 [K*P,12] at *sums_offset (natural index k*P + g; defined for visible pairs only; the
+ * reference's per-Gaussian sinks follow from them as dL_dconic = -0.5 (S_xx, S_xy, S_yy), dL_dopacity = S_w / opacity,
+ * backward.cu:620-637), the per-block pose-gradient partials at *partials_offset. */
+int dgs_backward_scratch_layout(uint64_t R, int32_t P, int32_t K, size_t* sums_offset, size_t* partials_offset);
 
 /* Replaces Rasterizer::forward up to the host read of num_rendered (rasterizer_impl.cu:198-287):
  * preprocess for all K subframes + prefix sum, then an async copy of R to out->num_rendered_host. */

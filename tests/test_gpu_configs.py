@@ -197,7 +197,7 @@ def test_cfg5_stress_as_benchmarked(gpu):
     g_mid[0][:, run.unstable[1]] = 0.0
     gC = np.zeros((K, 3, H, W), np.float32)
     gC[K // 2] = g_mid[0]
-    hip = hip_cloud_forward_backward(sc, K, gC, cull=True)
+    hip = hip_cloud_forward_backward(sc, K, gC, cull=True, conic_ks=[K // 2])
     ora = cloud_grads_from_activated(act, run.subset([1]).backward(g_mid))
     for key in ("dL_dmeans2D", "dL_dviewmatrix", "dL_dprojmatrix"):
         rest = np.delete(hip[key], K // 2, axis=0)

@@ -6,7 +6,7 @@ scale is arbitrary)."""
 import numpy as np
 import pytest
 
-from helpers import (OracleRun, assert_grads_close, tile_cull, hip_forward_backward, hip_forward_state, oracle_forward,
+from helpers import (OracleRun, assert_grads_close, tile_cull, wide_records, hip_forward_backward, hip_forward_state, oracle_forward,
                      oracle_forward_backward, relerr, synthetic, unstable_pixels)
 
 pytestmark = pytest.mark.gpu
@@ -162,15 +162,17 @@ GRAD_KEYS = ["dL_dmeans3D", "dL_dopacities", "dL_dsh", "dL_dscales", "dL_drotati
 
 def sharp_backward_check(sc, K, keys=GRAD_KEYS, depth=True, seed=5, **kw):
     """The per-component / per-Gaussian checker (helpers.assert_grads_close): every gradient COLUMN against its own
-    scale and every Gaussian against its own magnitude, bar 1e-4 or 4x the fp32 rounding noise the reference algorithm
-    itself shows on that component (oracle accumulating in emulated fp32 vs in double), upstream gradient zero on the
-    pixels whose oracle traversal sits on a threshold."""
+    scale and every Gaussian against its own magnitude, flat bars 1e-4 / 1e-3, an explicit (asserted tiny) set of ill-conditioned Gaussians for the
+    outputs behind the covariance chain, upstream gradient zero on the pixels whose oracle traversal sits on a
+    threshold."""
     run = OracleRun(sc, K, **kw)
     gC, gD = _grads(sc, K, seed=seed, depth=depth)
     gC, gD = run.mask(gC, gD)
     hip = hip_forward_backward(sc, K, gC, gD, **kw)
     rep = []
-    assert_grads_close(hip, run.backward(gC, gD), keys, report=rep)
+    # + the compositing backward at its well-conditioned output (dL_dconic per (subframe, Gaussian), read from the
+    # backward scratch) and dL_dcov3D before the scale / rotation chain
+    assert_grads_close(hip, run.backward(gC, gD), list(keys) + ["dL_dconic", "dL_dcov3D"], report=rep)
     return hip, run, rep
 
 
@@ -327,7 +329,7 @@ def test_tile_cull_gradients_bitwise_equal(gpu, depth):
         assert np.array_equal(a[key], b[key]), key
 
 
-def test_compact_keys_and_key_value_lists_agree(gpu, monkeypatch):
+def test_compact_keys_and_key_value_lists_agree(gpu):
     """With tile culling the sorted record is ONE 64-bit word, tile | Gaussian | emission index, whenever the three
     fit (DgsLayout.pack_*; every config but the 5M / 4K / K=31 stress one); otherwise key (tile | emission index) +
     value (Gaussian) arrays.  Both storages must give the same lists, images and gradients."""
@@ -335,11 +337,11 @@ def test_compact_keys_and_key_value_lists_agree(gpu, monkeypatch):
     gC, gD = _grads(sc, sc["K"], depth=True)
     out = {}
     for compact in ("1", "0"):
-        monkeypatch.setenv("DGS_COMPACT_KEYS", compact)
-        st = hip_forward_state(sc, sc["K"], cull=True)
-        assert st["compact_keys"] == (compact == "1")
-        with tile_cull(True):
-            out[compact] = (st, hip_forward_backward(sc, sc["K"], gC, gD))
+        with wide_records(compact == "0"):      # DgsProblem.wide_records (a field of the problem, not process state)
+            st = hip_forward_state(sc, sc["K"], cull=True)
+            assert st["compact_keys"] == (compact == "1")
+            with tile_cull(True):
+                out[compact] = (st, hip_forward_backward(sc, sc["K"], gC, gD))
     (a, ga), (b, gb) = out["1"], out["0"]
     for key in ("keys", "point_list", "ranges", "color", "depth", "n_contrib"):
         assert np.array_equal(a[key], b[key]), key
@@ -718,7 +720,10 @@ def test_fuzz_shapes_against_oracle(gpu, P, W, H, K, seed, sigma, deg, kw):
     # and per component / per Gaussian, away from the unstable pixels, against the noise-aware bar
     run = OracleRun(sc, K, **kw)
     gCm, gDm = run.mask(gC, gD)
-    assert_grads_close(hip_forward_backward(sc, K, gCm, gDm, **kw), run.backward(gCm, gDm), GRAD_KEYS)
+    # (the adversarial sprinkles -- needles, degenerate scales, near-plane crossers -- are a few % of this cloud: they may
+    # all land in the explicit ill-conditioned set; everything else is held to the flat bars)
+    assert_grads_close(hip_forward_backward(sc, K, gCm, gDm, **kw), run.backward(gCm, gDm),
+                       GRAD_KEYS + ["dL_dconic", "dL_dcov3D"], ill_frac=0.05)
 
 
 def test_scale_modifier_and_side_stream(gpu):

@@ -1,6 +1,6 @@
 """One-off stress run: random small problems (sizes that are multiples of nothing, K from 1 to 31, tiny to huge splats):
 reference duplicate lists against the oracle bit for bit, tile-culled results bit-equal to them, capacity mode equal to
-the two-phase path, both record storages (DGS_COMPACT_KEYS) equal.  Prints one line per case; exits non-zero on the
+the two-phase path, both record storages (DgsProblem.wide_records) equal.  Prints one line per case; exits non-zero on the
 first mismatch.    python tools/stress_lists.py [cases] [seed]"""
 import os
 import sys
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from helpers import synthetic, hip_forward_state, hip_forward_backward, oracle_forward, tile_cull
+from helpers import synthetic, hip_forward_state, hip_forward_backward, oracle_forward, tile_cull, wide_records
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -40,12 +40,11 @@ for case in range(n_cases):
         assert c["R"] == b["R"] and not c["overflow"]
         assert np.array_equal(b["keys"], c["keys"][:b["R"]]) and np.array_equal(b["point_list"], c["point_list"][:b["R"]])
         assert np.array_equal(b["ranges"], c["ranges"]) and np.array_equal(b["color"], c["color"])
-    os.environ["DGS_COMPACT_KEYS"] = "0"
-    d = hip_forward_state(sc, K, cull=True)
     gC = rng.normal(size=(K, 3, H, W)).astype(np.float32)
-    with tile_cull(True):
-        g0 = hip_forward_backward(sc, K, gC)
-    os.environ["DGS_COMPACT_KEYS"] = "1"
+    with wide_records(True):
+        d = hip_forward_state(sc, K, cull=True)
+        with tile_cull(True):
+            g0 = hip_forward_backward(sc, K, gC)
     with tile_cull(True):
         g1 = hip_forward_backward(sc, K, gC)
     with tile_cull(False):
