@@ -64,35 +64,77 @@ def parse_args(argv=None):
 
 
 # ------------------------------------------------------------------------------------------------ N-rank launcher
+def count_gpus_without_hip():
+    """GPUs of this node from the KFD topology in sysfs -- the parent of an N-rank run never calls into the HIP runtime
+    (a process that initialised the GPU must not be the one that spawns or re-execs).  None if sysfs has no answer."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            return len([x for x in os.environ[var].split(",") if x.strip()])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(base):
+            with open(os.path.join(base, d, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:      # CPU nodes have simd_count 0
+                n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def launch_ranks(args):
     """Parent of an N-GPU run: spawns N fresh rank processes and relays rank 0's JSON line.  Makes NO GPU call itself
-    (torch.cuda.device_count() does not initialise the device on this image), never re-execs."""
-    import torch
+    (devices are counted through sysfs), never re-execs.  All children are watched: the first non-zero exit or the
+    overall timeout (DGS_BENCH_TIMEOUT_S, default 1500 s) terminates the others and the launcher returns non-zero."""
     n = args.gpus
     one_device = os.environ.get("DGS_DIST_ONE_DEVICE", "0") == "1"
-    have = torch.cuda.device_count()
-    if have < n and not one_device:
+    have = count_gpus_without_hip()
+    if have is not None and have < n and not one_device:
         print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible; refusing to report a smaller run as "
               f"n_gpus={n}", file=sys.stderr)
         return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import tempfile
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")       # rank 0's stdout: a file, so that no pipe can fill up while we poll
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + float(os.environ.get("DGS_BENCH_TIMEOUT_S", "1500"))
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = f"rank(s) {bad} exited non-zero" if bad else "timeout"
+            for p in procs:                     # our own children, by handle (never by pattern)
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            rcs = [p.returncode for p in procs]
+            break
+        time.sleep(0.2)
+    out0.seek(0)
     line = None
-    for ln in (out0 or "").splitlines():
+    for ln in out0.read().splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
-    if any(rc != 0 for rc in rcs) or line is None:
-        print(f"bench.py: rank exit codes {rcs}; no result line" if line is None else
-              f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+    if failed is not None or any(rc != 0 for rc in rcs) or line is None:
+        why = failed or ("no result line" if line is None else "non-zero exit")
+        print(f"bench.py: {why}; rank exit codes {rcs}", file=sys.stderr)
         return 1
     if json.loads(line)["n_gpus"] != n:
         print(f"bench.py: the ranks saw {json.loads(line)['n_gpus']} peers, not {n}", file=sys.stderr)
@@ -313,7 +355,7 @@ def run_rank(args):
         dgr.TILE_CULL = False
         if loop._fused is not None:
             loop._fused._poll(block=True)
-            loop._fused._seen = []          # the reference's lists are longer: learn their count afresh
+            loop._fused.invalidate()        # the reference's lists are longer: learn their count afresh
         try:
             for _ in range(3):
                 step()
@@ -382,6 +424,7 @@ def run_rank(args):
                                      ("fused_step.FusedStep (C ABI, no autograd, duplicate arrays sized ahead)"
                                       if loop._fused is not None else "CameraMotionModule.query + torch autograd")),
                        "dropped_steps": (loop._fused.dropped if loop._fused is not None else 0),
+                       "retried_steps": loop.retried,
                        "tile_cull": bool(dgr.TILE_CULL),
                        "sharding": (args.shard if world > 1 else "none"), "ranks_in_process_group": world,
                        "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
@@ -435,6 +478,12 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
+    selftest = os.environ.get("DGS_BENCH_SELFTEST")      # launcher test hook (tests/test_host_logic.py): no GPU work
+    if selftest:
+        kind, _, who = selftest.partition(":")
+        if kind == "die" and os.environ.get("RANK") == who:
+            sys.exit(3)
+        time.sleep(3600)
     run_rank(args)
 
 

@@ -19,11 +19,15 @@ Why: at DeblurGS's real scene sizes (1e4..1e5 Gaussians) the autograd path is ho
 autograd bookkeeping and one blocking read of num_rendered per step cost more than the kernels.  Here a step is ~12
 ctypes calls.
 
-Sizing ahead (`speculative=True`): the duplicate arrays of step t are sized from the duplicate counts observed in earlier
-steps (+25 %), which are read from pinned memory only once their copy has completed -- never blocking.  If a step's count
-exceeds its capacity the kernels set a device flag instead of writing out of bounds; the flag makes the optimiser step
-and the densification statistics of THAT step no-ops (FusedAdam.skip_flag_ptr), so a truncated gradient is never
-applied: the iteration is dropped like a skipped mini-batch, the capacity grows, `dropped` counts it.
+Sizing ahead (`speculative=True`): the duplicate arrays of a step are sized from the duplicate counts observed in earlier
+steps OF THE SAME (view, subframe count) (+25 %), which are read from pinned memory only once their copy has completed --
+never blocking.  A (view, subframe count) that has no count yet -- a view drawn for the first time, the switch from one
+subframe to all of them at curve_start_iter, any view after a densification -- takes the exact two-phase forward (one
+host read), so those changes never overflow.  If a step's count still exceeds its capacity the kernels set a device flag
+instead of writing out of bounds; the flag makes the optimiser step and the densification statistics of THAT step
+no-ops (FusedAdam.skip_flag_ptr), so a truncated gradient is never applied.  Such a step is counted (`dropped`) and
+queued (`retry`): TrainingLoop re-runs the view through the exact path as soon as the flag has been read, so every view
+still gets its update (the reference applies every step).
 """
 import ctypes
 import math
@@ -39,7 +43,7 @@ def _ptr(t, offset_elems=0):
 
 
 class _Pending:
-    __slots__ = ("host", "event", "capacity", "speculative")
+    __slots__ = ("host", "event", "capacity", "speculative", "key", "generation", "request")
 
 
 class FusedStep:
@@ -51,7 +55,9 @@ class FusedStep:
         self.speculative = bool(speculative)
         self.tile_cull = tile_cull
         self.dropped = 0            # steps whose duplicate count exceeded the capacity (their update was skipped)
-        self._seen = []             # recent duplicate counts
+        self.retry = []             # their (cam_idx, subframe_indice): to be re-run by the caller (pop from here)
+        self._seen = {}             # (cam_idx, subframe count) -> recent duplicate counts of that view
+        self._generation = 0        # bumped when the cloud changes size: counts of older forwards are not learnt
         self._pending = []          # forwards whose counts have not been read back yet
         self._free_hosts = []
         self._keep = None           # buffers of the last step (the skip flag lives in its geometry blob)
@@ -69,17 +75,26 @@ class FusedStep:
                     raise RuntimeError("num_rendered exceeds 32 bits: render fewer subframes per call")
                 if pnd.speculative and overflow:
                     self.dropped += 1
-                self._seen = (self._seen + [R])[-16:]
+                    self.retry.append(pnd.request)
+                if pnd.generation == self._generation:
+                    self._seen[pnd.key] = (self._seen.get(pnd.key, []) + [R])[-4:]
                 self._free_hosts.append(pnd.host)
             else:
                 still.append(pnd)
         self._pending = still
 
-    def _capacity(self):
-        if not self._seen:
+    def _capacity(self, key):
+        seen = self._seen.get(key)
+        if not seen:
             return None
-        need = max(self._seen)
+        need = max(seen)
         return need + need // 4 + 16384
+
+    def invalidate(self):
+        """The cloud changed (densification, pruning, a restored checkpoint): forget the learnt counts -- also those still
+        on their way back -- so that every view takes the exact path once."""
+        self._generation += 1
+        self._seen = {}
 
     def _host_words(self):
         if self._free_hosts:
@@ -88,7 +103,7 @@ class FusedStep:
             return h
         return torch.zeros(4, dtype=torch.int32).pin_memory()
 
-    def _empty_slice(self, gt, lambda_t, K_total, P, H, W, ct_all, cr_all, nu_raw, need_blur):
+    def _empty_slice(self, gt, lambda_t, K_total, P, H, W, ct_all, cr_all, nu_raw, need_blur, lambda_depth_tv=0.0):
         """"subframes" sharding with more ranks than subframes: this rank rasterises nothing but takes part in the loss
         block's exchanges; all its gradients are zero."""
         from . import sharding
@@ -104,15 +119,20 @@ class FusedStep:
             m._trans._control_points.grad, m._rot._control_points.grad = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
             if nu_raw.numel() > 0:
                 m._nu.grad = torch.zeros_like(nu_raw)
+        depth_tv = None
+        if lambda_depth_tv > 0.0:      # this rank's share of the depth-smoothness value is zero
+            import torch.distributed as dist
+            depth_tv = torch.zeros((), **f32)
+            dist.all_reduce(depth_tv)
         return {"losses": torch.stack([l1.reshape(()), sm.reshape(())]).float(), "blur": None,
                 "radii": torch.zeros((0, P), dtype=torch.int32, device=dev), "viewspace_grad": torch.zeros((0, P, 3), **f32),
                 "K": K_total, "subframes": color, "depths": torch.zeros((0, 1, H, W), **f32), "skip_flag_ptr": None,
-                "depth_tv": None}
+                "depth_tv": depth_tv}
 
     # ------------------------------------------------------------------------------------------------- the step
     @torch.no_grad()
     def run(self, cam_idx, lambda_t, gt, background, subframe_indice="all", need_blur=False, uniform=None,
-            lambda_depth_tv=0.0, shard=None):
+            lambda_depth_tv=0.0, shard=None, exact=False):
         """gt: [3,H,W] ground truth of view cam_idx (already tone-mapped / noised by the caller); background: [3].
         lambda_depth_tv > 0 adds the reference's optional depth-smoothness term (train.py:150-153,
         utils/loss_utils.py:66-78): its gradient on the K depth images is formed with a few torch ops and handed to the
@@ -122,6 +142,7 @@ class FusedStep:
         (sharding.subframe_sharded_loss_grad: one all-reduce of the partial blur sum, one boundary frame each way), the
         gradients are this rank's PARTIAL sums (the caller adds them over the ranks; the opacity hinge is added on rank 0
         only); 'radii' / 'viewspace_grad' / 'subframes' hold the local slice, 'K' the view's subframe count.
+        exact=True forces the two-phase forward (one host read) whatever has been learnt.
         Returns a dict: 'losses' (device float32 [2]: L1(blur, gt), smoothness -- no host read), 'blur' ([3,H,W] if
         need_blur), 'radii' [K,P] int32, 'viewspace_grad' [K,P,3], 'K', 'skip_flag_ptr' (int or None)."""
         L = _lib.lib()
@@ -178,7 +199,7 @@ class FusedStep:
         P = cloud._xyz.shape[0]
         H, W = int(m.ref_cam.image_height), int(m.ref_cam.image_width)
         if K == 0:
-            return self._empty_slice(gt, lambda_t, K_total, P, H, W, ct_all, cr_all, nu_raw, need_blur)
+            return self._empty_slice(gt, lambda_t, K_total, P, H, W, ct_all, cr_all, nu_raw, need_blur, lambda_depth_tv)
         rest = cloud._features_rest if cloud._features_rest.shape[1] > 0 else None
         Mr = 0 if rest is None else rest.shape[1]
         color = torch.empty((K, 3, H, W), **f32)
@@ -206,9 +227,11 @@ class FusedStep:
         out.num_rendered_host = ctypes.c_void_p(host.data_ptr())
 
         self._poll()
-        cap = self._capacity() if self.speculative else None
+        key = (cam, K_total, k0)
+        cap = self._capacity(key) if (self.speculative and not exact) else None
         pnd = _Pending()
-        pnd.host, pnd.speculative = host, cap is not None
+        pnd.host, pnd.speculative, pnd.key, pnd.generation = host, cap is not None, key, self._generation
+        pnd.request = (cam_idx, subframe_indice)
         if cap is not None:
             binning = torch.empty(L.dgs_binning_state_bytes(cap, W, H, K), dtype=torch.uint8, device=dev)
             prob.binning_state, prob.binning_bytes = ctypes.c_void_p(binning.data_ptr()), binning.numel()
@@ -267,11 +290,17 @@ class FusedStep:
         depth_tv, g_depth = None, None
         if lambda_depth_tv > 0.0:
             from . import losses as _losses
+            # tv_loss is a mean over the view's K depth images of per-image terms (utils/loss_utils.py:66-78): a rank
+            # holding K of the K_total subframes contributes K / K_total of it and needs no other rank's depths
+            share = K / float(K_total)
             with torch.enable_grad():
                 dleaf = depth.detach().requires_grad_(True)
-                depth_tv = _losses.tv_loss(dleaf)
+                depth_tv = _losses.tv_loss(dleaf) * share
                 g_depth, = torch.autograd.grad(float(lambda_depth_tv) * depth_tv, dleaf)
             g_depth, depth_tv = g_depth.contiguous(), depth_tv.detach()
+            if shard is not None:
+                import torch.distributed as dist
+                dist.all_reduce(depth_tv)          # the value only (logging); the gradient is local
         io.radii, io.dL_dout_color, io.dL_dout_depth = ctypes.c_void_p(radii.data_ptr()), _ptr(dsub), _ptr(g_depth)
         io.scratch, io.scratch_bytes = ctypes.c_void_p(scratch.data_ptr()), scratch.numel()
         io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh = _ptr(g_xyz), _ptr(g_means2D), _ptr(g_dc)

@@ -122,11 +122,14 @@ class CameraMotionModule:
         return self._rot.device
 
     # ---- scene/motion.py:209-219
-    def _sample_nu_from_alignment(self, idx):
+    def _sample_nu_from_alignment(self, idx, uniform=None):
+        """uniform: the U(0,1) jitter samples to use when curve_random_sample is on (default: drawn here); ranks that
+        split ONE view's subframes must all use the same draw."""
         device = self._nu.device
         nu_mid = torch.sigmoid(self._nu[idx])
         if self.curve_random_sample:
-            nu_mid = nu_mid + torch.rand_like(nu_mid) / self.n_subframes - (1 / (2 * self.n_subframes))
+            u = torch.rand_like(nu_mid) if uniform is None else uniform.to(nu_mid).reshape(nu_mid.shape)
+            nu_mid = nu_mid + u / self.n_subframes - (1 / (2 * self.n_subframes))
         return torch.cat([torch.zeros(1, device=device), nu_mid, torch.ones(1, device=device)]).clamp(0.0, 1.0).sort().values
 
     # ---- scene/motion.py:221-256
@@ -171,7 +174,7 @@ class CameraMotionModule:
         return self.gt_images[idx]
 
     def query(self, cam_idx: int, subframe_indice="all", post_process=None, background="random",
-              compute_blurred=True, shard=None):
+              compute_blurred=True, shard=None, uniform=None):
         """Render a blurry view (scene/motion.py:78-160).  Returns the reference's dict: 'blurred', 'gt',
         'subframes' [f,3,H,W], 'depths' [f,1,H,W], 'render_pkgs' (list of f per-subframe dicts whose
         'viewspace_points' entries are views of ONE [f,P,3] grad carrier, exposed as 'viewspace_points_all').
@@ -187,9 +190,9 @@ class CameraMotionModule:
         else:
             bg = background
         if isinstance(subframe_indice, str) and subframe_indice == "all":
-            nu = None
+            nu = None if uniform is None else self._sample_nu_from_alignment(cam_idx, uniform)
         else:
-            nu = self._sample_nu_from_alignment(cam_idx)
+            nu = self._sample_nu_from_alignment(cam_idx, uniform)
             if isinstance(subframe_indice, int):
                 # NB: the reference's `== 1` special case is dead code (its result is overwritten,
                 # scene/motion.py:129-131): 1 selects index 0, i.e. nu = 0.

@@ -36,6 +36,14 @@ class FusedAdam(torch.optim.Optimizer):
         # untouched (include/dgs_hip.h, dgs_forward: gradients of a forward whose duplicate capacity overflowed)
         self.skip_flag_ptr = None
 
+    def note_skipped_steps(self, n=1):
+        """`n` earlier step() calls turned out to be no-ops on the device (skip_flag_ptr was set when their kernels ran):
+        take them out of the per-parameter step counters again, so that state["step"] -- the bias-correction exponent and
+        what a checkpoint stores -- equals the number of updates that were applied."""
+        for st in self.state.values():
+            if "step" in st and float(st["step"]) >= n:
+                st["step"] -= n
+
     def _check_group(self, group):
         for key, default in self._ADAM_DEFAULTS.items():
             v = group.get(key, default)

@@ -10,7 +10,8 @@ Two modes, both with all Gaussian and trajectory parameters replicated on every 
                a G-view mini-batch; gradients are averaged over the G views.
   "subframes"  the K subframes of ONE view are split over ranks (rank g gets k in [floor(gK/G), floor((g+1)K/G)));
                the loss couples them (mean over K, adjacent-k smoothness), so before the backward there is one
-               all-reduce of the partial blur sum [3,H,W] and a neighbour exchange of one boundary subframe;
+               all-reduce of the partial blur sum [3,H,W] and a point-to-point neighbour exchange of one boundary
+               subframe each way (batch_isend_irecv; which rank holds which subframes is computed on the host);
                after it the same flat gradient all-reduce (per-Gaussian + curve parameters).  Semantics are
                exactly the reference's single-view step.
 
@@ -23,12 +24,25 @@ import torch
 import torch.distributed as dist
 
 
+# DGS_DIST_FORCE_COLLECTIVES=1: issue every collective of the product path even in a one-rank group (values unchanged).
+# tools/rccl_smoke.py uses it to put the real RCCL library, init path and reduction ops under a TrainingLoop step on a
+# one-GPU box.
+FORCE_COLLECTIVES = os.environ.get("DGS_DIST_FORCE_COLLECTIVES", "0") == "1"
+
+
+def _init_timeout():
+    """Rendezvous / collective timeout: a rank that died must not leave the others waiting for torch's 10-minute default
+    (DGS_DIST_TIMEOUT_S overrides the 120 s)."""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("DGS_DIST_TIMEOUT_S", "120")))
+
+
 def init_distributed(device_type="cuda"):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("DGS_DIST_FORCE_INIT", "0") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # DGS_DIST_BACKEND=gloo and DGS_DIST_ONE_DEVICE=1 let the N-rank code path run on a box with ONE GPU
@@ -39,12 +53,12 @@ def init_distributed(device_type="cuda"):
         if device_type == "cuda":
             torch.cuda.set_device(local_rank)
             if backend == "nccl":
-                dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=_init_timeout(),
                                         device_id=torch.device("cuda", local_rank))
             else:
-                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=_init_timeout())
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=_init_timeout())
     return rank, world, local_rank
 
 
@@ -109,12 +123,12 @@ def _allreduce(flat, average, group):
             flat /= dist.get_world_size(group)
 
 
-def allreduce_small_grads(params, average=False, group=None):
+def allreduce_small_grads(params, average=False, group=None, force=False):
     """The trajectory parameters (curve control points, alignment) are replicated like the cloud; their gradients are a
     few KB, packed into one small buffer and reduced next to the per-Gaussian bucket.  A parameter without a gradient on
     this rank (its view was rendered elsewhere, or nothing reached it) contributes zeros, so that every rank calls the
-    collective with the same layout."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    collective with the same layout.  force: run the collective in a one-rank group too (the RCCL smoke test)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not (force or FORCE_COLLECTIVES)):
         return
     params = [p for p in params if p is not None and p.numel() > 0]
     if not params:
@@ -127,14 +141,15 @@ def allreduce_small_grads(params, average=False, group=None):
         o += p.numel()
 
 
-def flat_allreduce_grads(params, average=False, group=None, extra=None):
+def flat_allreduce_grads(params, average=False, group=None, extra=None, force=False):
     """Sum (or average) the .grad of `params` over ranks with ONE collective on a flat fp32 bucket.  Gradients that
     already are views of one flat buffer are reduced in place (no packing copies); RCCL averages inside the
-    collective.  `extra`: small replicated parameters (the trajectory groups) reduced by allreduce_small_grads."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    collective.  `extra`: small replicated parameters (the trajectory groups) reduced by allreduce_small_grads.
+    force: run the collectives in a one-rank group too (values unchanged; proves library load, init path and op support)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not (force or FORCE_COLLECTIVES)):
         return
     if extra:
-        allreduce_small_grads(extra, average=average, group=group)
+        allreduce_small_grads(extra, average=average, group=group, force=force)
     params = [p for p in params if p is not None]
     grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
     shared = None
@@ -164,7 +179,7 @@ def allreduce_densification_stats(cloud, prev, group=None):
     from ITS view since the last synchronisation are combined first (determinism caveat): the increments
     of xyz_gradient_accum and denom are summed over ranks, max_radii2D is maximised.  `prev` = (accum, denom)
     snapshots taken right after the previous call (or zeros); returns the new snapshots."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES):
         return cloud.xyz_gradient_accum.clone(), cloud.denom.clone()
     d_acc = cloud.xyz_gradient_accum - prev[0]
     d_den = cloud.denom - prev[1]
@@ -205,29 +220,33 @@ def subframe_sharded_loss_grad(local_subframes, gt, K, lambda_t, group=None):
     E = gt.numel()
     # ---- exchange 1: partial blur sum
     blur = S.sum(dim=0) if k_loc > 0 else torch.zeros_like(gt)
-    if world > 1:
+    every = world > 1 or (FORCE_COLLECTIVES and dist.is_initialized())
+    if every:
         dist.all_reduce(blur, op=dist.ReduceOp.SUM, group=group)
     blur = blur / K
-    # ---- exchange 2: boundary subframes (first/last non-empty neighbours share one frame each way)
+    # ---- exchange 2: boundary subframes, point to point ("send/recv of one boundary subframe"): a rank sends
+    # its first frame to the nearest lower rank that holds subframes and its last frame to the nearest higher one.  Who
+    # holds what follows from shard_range on the host -- no count gather, no host read of a device value.
     prev_last = None   # subframe k0-1
     next_first = None  # subframe k0+k_loc
-    if world > 1:
-        first = S[0].contiguous() if k_loc > 0 else torch.zeros_like(gt)
-        last = S[-1].contiguous() if k_loc > 0 else torch.zeros_like(gt)
-        firsts = [torch.empty_like(gt) for _ in range(world)]
-        lasts = [torch.empty_like(gt) for _ in range(world)]
-        counts = [torch.zeros(1, dtype=torch.int64, device=gt.device) for _ in range(world)]
-        dist.all_gather(firsts, first, group=group)
-        dist.all_gather(lasts, last, group=group)
-        dist.all_gather(counts, torch.tensor([k_loc], dtype=torch.int64, device=gt.device), group=group)
-        for r in range(rank - 1, -1, -1):
-            if int(counts[r]) > 0:
-                prev_last = lasts[r]
-                break
-        for r in range(rank + 1, world):
-            if int(counts[r]) > 0:
-                next_first = firsts[r]
-                break
+    if world > 1 and k_loc > 0:
+        holds = [shard_range(K, r, world) for r in range(world)]
+        assert holds[rank][1] - holds[rank][0] == k_loc, "local_subframes does not match shard_range(K, rank, world)"
+        lower = next((r for r in range(rank - 1, -1, -1) if holds[r][1] > holds[r][0]), None)
+        upper = next((r for r in range(rank + 1, world) if holds[r][1] > holds[r][0]), None)
+        peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+        ops = []
+        if lower is not None:
+            first = S[0].contiguous()
+            prev_last = torch.empty_like(gt)
+            ops += [dist.P2POp(dist.isend, first, peer(lower), group), dist.P2POp(dist.irecv, prev_last, peer(lower), group)]
+        if upper is not None:
+            last = S[-1].contiguous()
+            next_first = torch.empty_like(gt)
+            ops += [dist.P2POp(dist.isend, last, peer(upper), group), dist.P2POp(dist.irecv, next_first, peer(upper), group)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
     d = blur - gt
     g_l1 = _sgn(d) / (E * K)
     dS = g_l1[None].expand_as(S).clone() if k_loc > 0 else S
@@ -257,6 +276,6 @@ def subframe_sharded_loss_grad(local_subframes, gt, K, lambda_t, group=None):
         # each difference is counted once: a rank owns the differences whose LEFT frame it holds
         own = diff[lo:lo + n_right]
         sm_local = own.abs().sum() / (E * (K - 1))
-    if world > 1:
+    if every:
         dist.all_reduce(sm_local, op=dist.ReduceOp.SUM, group=group)
     return dS, d.abs().mean(), sm_local

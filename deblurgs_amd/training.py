@@ -71,6 +71,7 @@ class TrainingLoop:
                                             step_final=opt.iterations)                  # train.py:90-94
         cam_motion_module.alternate_optimization()      # train.py:102, unconditional: curve gradients off at the start
         self.log_losses = log_losses
+        self.retried = 0            # dropped fused steps that were re-run through the exact path
         self._fused = None
         if fused_step:
             try:
@@ -133,21 +134,30 @@ class TrainingLoop:
         self._tail(iteration, r, densification_threshold)
         return {"loss": loss.detach(), "l1": Ll1, "smooth": L_t, "hinge": L_hinge, "num_points": g._xyz.shape[0]}
 
-    def _step_fused(self, iteration, cam_idx, subframe_indice, lambda_t_smooth, densification_threshold):
+    def _shared_draws(self, bg):
+        """"subframes" sharding: the ranks rasterise slices of ONE view, so the random background (scene/motion.py:112-113)
+        and the alignment jitter (scene/motion.py:213-214, curve_random_sample) must be the same draw on all of them:
+        rank 0's, sent in one small broadcast.  Returns (bg [3], uniform [f-2] or None)."""
+        import torch.distributed as dist
+        m = self.motion
+        n = m._nu.shape[1] if (m.curve_random_sample and m._nu.ndim == 2) else 0
+        buf = torch.cat([bg.reshape(3).float(), torch.rand(n, device=bg.device)])
+        dist.broadcast(buf, src=0)
+        return buf[:3].contiguous(), (buf[3:].contiguous() if n > 0 else None)
+
+    def _step_fused(self, iteration, cam_idx, subframe_indice, lambda_t_smooth, densification_threshold, exact=False):
         """The same iteration with its device work enqueued by FusedStep (module docstring there)."""
         g = self.gaussians
         dev = g._xyz.device
         gt = self._ground_truth(cam_idx, self.motion.get_gt_image(cam_idx), iteration)
         bg = torch.rand(3, device=dev)                                   # scene/motion.py:112-113
-        shard = None
+        shard, uniform = None, None
         if self.mode == "subframes":
             import torch.distributed as dist
-            if self.opt.lambda_depth_tv > 0.0:
-                raise NotImplementedError("lambda_depth_tv with 'subframes' sharding")
             shard = (dist.get_rank(), dist.get_world_size())
-            dist.broadcast(bg, src=0)          # one view, one background: every rank composites over rank 0's draw
-        fr = self._fused.run(cam_idx, lambda_t_smooth, gt, bg, subframe_indice,
-                             lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0), shard=shard)
+            bg, uniform = self._shared_draws(bg)
+        fr = self._fused.run(cam_idx, lambda_t_smooth, gt, bg, subframe_indice, uniform=uniform,
+                             lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0), shard=shard, exact=exact)
         skip = fr["skip_flag_ptr"]
         if self.distributed:
             from . import sharding
@@ -169,9 +179,19 @@ class TrainingLoop:
         g.optimizer.skip_flag_ptr = skip
         r = {"viewspace_points_all": fr["viewspace_grad"], "radii_all": fr["radii"], "K_total": fr["K"],
              "skip_flag_ptr": skip}
-        self._tail(iteration, r, densification_threshold)
+        self._tail(iteration, r, densification_threshold, makeup=exact)
         out = {"l1": fr["losses"][0], "smooth": fr["losses"][1], "hinge": None, "num_points": g._xyz.shape[0],
-               "loss": None}
+               "loss": None, "dropped": self._fused.dropped, "retried": self.retried}
+        # A step whose duplicate capacity overflowed was a no-op on the device; once its flag has come back (usually one
+        # step later) the view is re-run here through the exact path, so that no view loses its update.  Single-process
+        # only: replicas would have to agree on the make-up step (sharded runs drop the step on every rank instead).
+        if not exact and not self.distributed:
+            while self._fused.retry:
+                cam_r, sub_r = self._fused.retry.pop(0)
+                g.optimizer.note_skipped_steps(1)
+                self.retried += 1
+                self._step_fused(iteration, cam_r, sub_r, lambda_t_smooth, densification_threshold, exact=True)
+            out["retried"] = self.retried
         if self.log_losses:
             out["loss"] = fr["losses"][0] + lambda_t_smooth * fr["losses"][1]    # (without the hinge term's value)
             if fr["depth_tv"] is not None:
@@ -183,13 +203,31 @@ class TrainingLoop:
         import torch.distributed as dist
         from . import sharding
         g, opt = self.gaussians, self.opt
-        if opt.lambda_depth_tv > 0.0:
-            raise NotImplementedError("lambda_depth_tv with 'subframes' sharding")
         rank, world = dist.get_rank(), dist.get_world_size()
+        # one view, one background, one alignment jitter: every rank uses rank 0's draws (the fused path does the same)
+        bg, uniform = self._shared_draws(torch.rand(3, device=g._xyz.device))
         r = self.motion.query(cam_idx=cam_idx, subframe_indice=subframe_indice, compute_blurred=False,
-                              shard=(rank, world))
+                              shard=(rank, world), background=bg, uniform=uniform)
         gt = self._ground_truth(cam_idx, r["gt"], iteration)
-        l1, sm = sharding.subframe_sharded_loss_backward(r["subframes"], gt, r["K_total"], r["k0"], lambda_t_smooth)
+        dS, l1, sm = sharding.subframe_sharded_loss_grad(r["subframes"], gt, r["K_total"], lambda_t_smooth)
+        roots, seeds = [], []
+        if r["subframes"].shape[0] > 0:
+            roots.append(r["subframes"])
+            seeds.append(dS)
+        depth_tv = None
+        if opt.lambda_depth_tv > 0.0:
+            # tv_loss averages per-image terms over the view's K depth images (utils/loss_utils.py:66-78): this rank's
+            # slice contributes k_loc / K of it and needs no other rank's depths; one backward pass for both terms
+            depth_tv = torch.zeros((), device=g._xyz.device)
+            if r["depths"].shape[0] > 0:
+                local = losses.tv_loss(r["depths"]) * (r["depths"].shape[0] / float(r["K_total"]))
+                roots.append(opt.lambda_depth_tv * local)
+                seeds.append(None)
+                depth_tv = local.detach()
+            dist.all_reduce(depth_tv)
+        if roots:
+            torch.autograd.backward(roots, seeds)
+        l1, sm = float(l1), float(sm)
         if L_hinge is not None:
             # every rank holds the whole cloud: the hinge gradient is added once, on rank 0, and reaches the others
             # through the gradient sum (after the rasteriser's backward, so that it accumulates into the bucket)
@@ -198,11 +236,15 @@ class TrainingLoop:
                                       extra=[p for p in self.motion.parameters() if p.requires_grad])
         self._tail(iteration, r, densification_threshold)
         loss = l1 + lambda_t_smooth * sm + (opt.lambda_hinge * float(L_hinge) if L_hinge is not None else 0.0)
+        if depth_tv is not None:
+            loss = loss + opt.lambda_depth_tv * float(depth_tv)
         return {"loss": torch.tensor(loss), "l1": torch.tensor(l1), "smooth": torch.tensor(sm), "hinge": L_hinge,
                 "num_points": g._xyz.shape[0]}
 
-    def _tail(self, iteration, r, densification_threshold):
-        """train.py:186-208: densification statistics, densify / reset on their schedule, the optimiser step."""
+    def _tail(self, iteration, r, densification_threshold, makeup=False):
+        """train.py:186-208: densification statistics, densify / reset on their schedule, the optimiser step.
+        makeup: the re-run of a dropped step -- statistics and the optimiser step only (the iteration's densification /
+        opacity reset already happened)."""
         from . import sharding
         g, opt = self.gaussians, self.opt
         with torch.no_grad():
@@ -213,7 +255,9 @@ class TrainingLoop:
                     add_densification_stats_subframes(r["viewspace_points_all"], r["radii_all"], g.max_radii2D,
                                                       g.xyz_gradient_accum, g.denom, K_total=r["K_total"],
                                                       skip_flag_ptr=r.get("skip_flag_ptr"))
-                if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+                if makeup:
+                    pass
+                elif iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
                     if self.distributed:
                         sharding.allreduce_densification_stats(g, self._stat_prev)
                         self._stat_prev = None          # densify_and_prune resets the statistics to zeros
@@ -222,10 +266,10 @@ class TrainingLoop:
                         gen = torch.Generator(device=g._xyz.device)
                         gen.manual_seed(1_000_003 * int(iteration) + 17)
                     g.densify_and_prune(densification_threshold, self.extent, generator=gen)
-                    if self._fused is not None:      # the cloud changed size: learn the duplicate count afresh
-                        self._fused._seen = []
-                if iteration % opt.opacity_reset_interval == 0 or (self.white_background and
-                                                                   iteration == opt.densify_from_iter):
+                    if self._fused is not None:      # the cloud changed size: learn the duplicate counts afresh
+                        self._fused.invalidate()
+                if not makeup and (iteration % opt.opacity_reset_interval == 0 or
+                                   (self.white_background and iteration == opt.densify_from_iter)):
                     g.reset_opacity()
             if iteration < opt.iterations:
                 g.optimizer.step()                      # clip_grad_value_ is fused into the step (FusedAdam.clip_value)

@@ -468,25 +468,26 @@ def test_fused_step_speculative_capacity_and_overflow(gpu):
     bg = torch.tensor([0.3, 0.3, 0.3], device="cuda")
     fs = FusedStep(cloud, m, lambda_hinge=0.1, speculative=True)
     a = fs.run(0, 1e-3, m.get_gt_image(0), bg)
-    assert a["skip_flag_ptr"] is None and fs._capacity() is None      # exact path, count not polled yet
+    key = (0, 5, 0)                                  # (view, subframes of the view, first subframe of this rank)
+    assert a["skip_flag_ptr"] is None and fs._capacity(key) is None      # exact path, count not polled yet
     ga = [p.grad.clone() for p in cloud.hot_parameters()]
     fs._poll(block=True)
-    R = fs._seen[-1]
-    assert R > 1000 and fs._capacity() > R
+    R = fs._seen[key][-1]
+    assert R > 1000 and fs._capacity(key) > R
     b = fs.run(0, 1e-3, m.get_gt_image(0), bg)
     assert b["skip_flag_ptr"] is not None and fs.last_capacity == R + R // 4 + 16384
     for x, y in zip(ga, [p.grad for p in cloud.hot_parameters()]):
         assert torch.equal(x, y)
     assert torch.equal(a["subframes"], b["subframes"]) and torch.equal(a["losses"], b["losses"])
     fs._poll(block=True)
-    assert fs.dropped == 0 and fs._seen[-1] == R
+    assert fs.dropped == 0 and fs._seen[key][-1] == R and not fs.retry
     # the step applies: parameters move
     before = cloud._xyz.detach().clone()
     cloud.optimizer.skip_flag_ptr = b["skip_flag_ptr"]
     cloud.optimizer.step()
     assert not torch.equal(before, cloud._xyz)
     # ---- overflow: pretend the cloud used to need far fewer duplicates
-    fs._seen = [R // 3]
+    fs._seen[key] = [R // 3]
     before = [p.detach().clone() for p in cloud.hot_parameters()]
     m_before = cloud.optimizer.state[cloud._xyz]["exp_avg"].clone()
     stats = [cloud.max_radii2D.clone(), cloud.xyz_gradient_accum.clone(), cloud.denom.clone()]
@@ -504,10 +505,60 @@ def test_fused_step_speculative_capacity_and_overflow(gpu):
         assert torch.equal(x, y)
     fs._poll(block=True)
     # the true count came back (the cloud moved by one Adam step since R was read): the next capacity fits
-    assert fs.dropped == 1 and abs(fs._seen[-1] - R) < 0.02 * R
+    assert fs.dropped == 1 and abs(fs._seen[key][-1] - R) < 0.02 * R
+    assert fs.retry == [(0, "all")]                  # queued for the caller's make-up step
     d = fs.run(0, 1e-3, m.get_gt_image(0), bg)
     fs._poll(block=True)
     assert fs.dropped == 1 and fs.last_capacity > R and bool(torch.isfinite(d["subframes"]).all())
+    # counts are kept per (view, subframe count): another view or another subframe count takes the exact path first
+    e = fs.run(1, 1e-3, m.get_gt_image(1), bg)
+    f1 = fs.run(0, 1e-3, m.get_gt_image(0), bg, subframe_indice=1)
+    assert e["skip_flag_ptr"] is None and f1["skip_flag_ptr"] is None
+    # the cloud changed: learnt counts (also those still in flight) are forgotten
+    g2 = fs.run(0, 1e-3, m.get_gt_image(0), bg)
+    assert g2["skip_flag_ptr"] is not None
+    fs.invalidate()
+    fs._poll(block=True)
+    assert fs._seen == {} and fs.run(0, 1e-3, m.get_gt_image(0), bg)["skip_flag_ptr"] is None
+
+
+def test_training_loop_makes_up_for_dropped_steps_and_views_differ(gpu):
+    """Views with very different duplicate counts, the 1 -> all subframes switch at curve_start_iter and a densification:
+    none of them may drop a step (counts are learnt per view and subframe count, forgotten when the cloud changes); a
+    forced overflow is dropped on the device, reported by step() and re-run through the exact path, and the optimiser's
+    step counters count applied updates only."""
+    import torch
+    from deblurgs_amd.training import TrainingLoop, default_optimization_params
+    sc, cloud, m = _fused_fixture(seed=8, K=5, P=4000)
+    with torch.no_grad():       # view 2 looks at the cloud from much closer: several times the duplicates of view 0
+        m._trans._control_points[2, :, 2] += 0.55
+    opt = default_optimization_params(iterations=200, curve_start_iter=6, densify_from_iter=8, densification_interval=5,
+                                      densify_until_iter=100, densify_grad_threshold_init=2e-5,
+                                      densify_grad_threshold_final=1e-5, opacity_reset_interval=1000)
+    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0)
+    fs = loop._fused
+    assert fs is not None and fs.speculative
+    sizes = set()
+    for it in range(1, 26):
+        out = loop.step(it, it % 3)
+        sizes.add(out["num_points"])
+    fs._poll(block=True)
+    assert len(sizes) > 1, "densification never changed the cloud"
+    counts = {k: v[-1] for k, v in fs._seen.items()}
+    assert max(counts.values()) > 1.5 * min(counts.values()), counts     # heterogeneous views indeed
+    assert fs.dropped == 0 and loop.retried == 0 and out["dropped"] == 0
+    steps_before = float(cloud.optimizer.state[cloud._xyz]["step"])
+    assert steps_before == 25
+    # ---- force an overflow of view 1
+    k1 = [k for k in fs._seen if k[0] == 1 and k[1] == 5][0]
+    fs._seen[k1] = [fs._seen[k1][-1] // 4]
+    out = loop.step(26, 1)                 # dropped on the device
+    fs._poll(block=True)
+    assert fs.dropped == 1 and fs.retry == [(1, "all")]
+    out = loop.step(27, 2)                 # ... and made up for right after this step
+    assert out["dropped"] == 1 and out["retried"] == 1 and not fs.retry
+    # 27 step() calls + 1 make-up - 1 dropped launch = 27 applied updates
+    assert float(cloud.optimizer.state[cloud._xyz]["step"]) == 27
 
 
 def test_training_loop_fused_and_autograd_paths_agree(gpu):
@@ -552,6 +603,21 @@ def _run(cmd, env, timeout=900):
     return r.stdout
 
 
+def test_rccl_one_rank_smoke(gpu):
+    """Backend "nccl" (= RCCL) has to load, initialise with device_id and support every collective the sharded step
+    issues (in-place ReduceOp.AVG on the gradient bucket, MAX on the int32 skip flag, broadcast, SUM) BEFORE the driver's
+    8-GPU run finds out: tools/rccl_smoke.py runs TrainingLoop steps in both modes in a one-rank nccl group with all
+    collectives forced on and checks that they are the identity."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DGS_DIST_BACKEND", "DGS_DIST_ONE_DEVICE"):
+        env.pop(k, None)
+    out = _run([sys.executable, os.path.join(root, "tools", "rccl_smoke.py")], env, timeout=600)
+    assert "rccl smoke ok: backend nccl, world 1" in out, out
+
+
 @pytest.mark.parametrize("mode", ["views", "subframes"])
 def test_two_ranks_on_one_gpu(gpu, mode, tmp_path):
     """The N-rank code path end to end with two ranks sharing this box's GPU (gloo collectives staged through the host:
@@ -567,7 +633,8 @@ def test_two_ranks_on_one_gpu(gpu, mode, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DGS_DIST_BACKEND="gloo", DGS_DIST_ONE_DEVICE="1", PYTHONPATH=root)
     tool = os.path.join(root, "tools", "dist_training_check.py")
-    out = _run([sys.executable, tool, "--ranks", "2", "--mode", mode], env)
+    # (the ranks draw DIFFERENT random numbers: shared draws -- background, alignment jitter -- come from rank 0)
+    out = _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--random-sample"], env)
     assert "identical: True" in out and "densified: True" in out, out
     if mode == "subframes":
         a, b = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")

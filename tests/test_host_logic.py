@@ -199,3 +199,44 @@ def test_densification_stats_are_combined_across_ranks(tmp_path):
     out = str(tmp_path / "stats.pt")
     mp.spawn(_worker_stats, args=(2, 29655, out), nprocs=2, join=True)
     assert torch.load(out) is True
+
+
+def _worker_subframes3(rank, world, port, K, out):
+    _worker_subframes(rank, world, port, K, out)
+
+
+@pytest.mark.parametrize("K", [2, 4])
+def test_subframe_sharding_three_ranks_with_an_empty_one(tmp_path, K):
+    """K = 2 over 3 ranks leaves rank 0 without subframes (shard_range: [0,0), [0,1), [1,2)): the point-to-point boundary
+    exchange must skip it (neighbours are computed from shard_range on the host), K = 4 gives slices of 1, 1, 2."""
+    from deblurgs_amd import losses
+    out = str(tmp_path / "sub3.pt")
+    mp.spawn(_worker_subframes3, args=(3, 29700 + K, K, out), nprocs=3, join=True)
+    got = torch.load(out)
+    torch.manual_seed(0)
+    params = [torch.randn(20, 3, requires_grad=True), torch.randn(7, requires_grad=True)]
+    view = (torch.eye(4)[None].repeat(K, 1, 1) + 0.01 * torch.randn(K, 4, 4)).requires_grad_(True)
+    proj = (torch.eye(4)[None].repeat(K, 1, 1) + 0.01 * torch.randn(K, 4, 4)).requires_grad_(True)
+    gt = torch.rand(3, 6, 5)
+    total, blur, l1, sm = losses.blur_loss_torch(_standin_render(params, view, proj), gt, 0.05)
+    total.backward()
+    assert abs(got["l1"] - float(l1)) < 1e-6 and abs(got["sm"] - float(sm)) < 1e-6
+    for a, p in zip(got["g"], params + [view, proj]):
+        assert torch.allclose(a, p.grad, atol=1e-6), (a - p.grad).abs().max()
+
+
+@pytest.mark.parametrize("how", ["die:1", "timeout"])
+def test_bench_launcher_does_not_wait_for_a_dead_rank(how):
+    """bench.py --gpus N started plainly: when a rank exits non-zero (or the overall timeout passes) the launcher ends the
+    other ranks and returns non-zero within seconds -- it never sits in communicate() until a collective times out."""
+    import subprocess
+    import time
+    env = dict(os.environ, DGS_BENCH_SELFTEST=how if how != "timeout" else "hang:0", DGS_DIST_ONE_DEVICE="1",
+               DGS_BENCH_TIMEOUT_S="3")
+    env.pop("RANK", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 1, (r.returncode, r.stderr[-500:])
+    assert time.time() - t0 < 60
+    assert ("exited non-zero" in r.stderr) if how != "timeout" else ("timeout" in r.stderr)

@@ -30,6 +30,9 @@ def parse():
     ap.add_argument("--no-densify", action="store_true")
     ap.add_argument("--out", default=None)
     ap.add_argument("--curve-start", type=int, default=2, help="curve_start_iter (all K subframes from this iteration)")
+    ap.add_argument("--same-seed", action="store_true",
+                    help="seed every rank identically per iteration (only for comparing a 1-rank with an N-rank run)")
+    ap.add_argument("--random-sample", action="store_true", help="curve_random_sample on (alignment jitter)")
     return ap.parse_args()
 
 
@@ -67,7 +70,7 @@ def main():
     n_views = max(world, 2)
     torch.manual_seed(100)                        # the SAME module (ground truths, curves) on every rank
     gt = torch.rand(n_views, 3, sc["H"], sc["W"], device=dev) * 0.5
-    m = CameraMotionModule(ref, gt, curve_order=3, num_subframes=K, device=dev)
+    m = CameraMotionModule(ref, gt, curve_order=3, num_subframes=K, device=dev, curve_random_sample=args.random_sample)
     with torch.no_grad():
         base = torch.from_numpy(sc["ctrl_trans"])[None].to(dev)
         m._trans._control_points.copy_(base + 0.01 * torch.arange(n_views, device=dev).reshape(-1, 1, 1))
@@ -98,7 +101,7 @@ def main():
     cloud.optimizer.step = _step_spy
     for it in range(1, args.iters + 1):
         snap["it"] = it
-        torch.manual_seed(it)                     # same random background on every rank
+        torch.manual_seed(it if args.same_seed else 7919 * (rank + 1) + it)   # ranks draw DIFFERENT random numbers
         cam = (it + rank) % n_views if args.mode == "views" else it % n_views
         out = loop.step(it, cam)
         sizes.append(out["num_points"])

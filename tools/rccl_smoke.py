@@ -1,0 +1,87 @@
+"""RCCL smoke test on a ONE-GPU box: a one-rank process group on backend "nccl" (= RCCL) with every collective of the
+product path forced on (DGS_DIST_FORCE_COLLECTIVES=1), under real TrainingLoop steps.
+
+    python tools/rccl_smoke.py
+
+Proves, before the driver's 8-GPU run does: librccl loads, init_process_group(backend="nccl", device_id=...) works,
+ReduceOp.AVG on the in-place gradient bucket, ReduceOp.MAX on the int32 skip flag, broadcast of the shared draws, the
+all-reduces of the "subframes" loss block, the packed small-gradient all-reduce and the densification-statistics
+reduction are all supported -- and that with one rank every one of them is the identity: the trained parameters are
+bit-identical to the same run with the collectives skipped.
+"""
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+
+
+def train(mode, iters=12):
+    import torch
+    from deblurgs_amd import synthetic
+    from deblurgs_amd.cloud import GaussianCloud
+    from deblurgs_amd.motion import CameraMotionModule, RefCamera
+    from deblurgs_amd.training import TrainingLoop, default_optimization_params
+    dev = torch.device("cuda", 0)
+    K = 5
+    sc = synthetic.make_scene(3000, 128, 96, K=K, seed=21, sigma_px=3.0)
+    cloud = GaussianCloud.from_scene(sc, dev)
+    ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device=dev)
+    torch.manual_seed(100)
+    gt = torch.rand(2, 3, sc["H"], sc["W"], device=dev) * 0.5
+    m = CameraMotionModule(ref, gt, curve_order=3, num_subframes=K, device=dev, curve_random_sample=True)
+    with torch.no_grad():
+        m._trans._control_points.copy_(torch.from_numpy(sc["ctrl_trans"])[None].to(dev).expand(2, -1, -1))
+        m._rot._control_points.copy_(torch.from_numpy(sc["ctrl_rot"])[None].to(dev).expand(2, -1, -1))
+    opt = default_optimization_params(iterations=iters + 10, curve_start_iter=2, densify_from_iter=3,
+                                      densification_interval=4, densify_until_iter=iters - 2,
+                                      densify_grad_threshold_init=2e-5, densify_grad_threshold_final=1e-5,
+                                      opacity_reset_interval=1000, curve_alignment_lr=1e-3, curve_alignment_start=4,
+                                      lambda_depth_tv=0.01)
+    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=mode)
+    for it in range(1, iters + 1):
+        torch.manual_seed(it)
+        loop.step(it, it % 2)
+    torch.cuda.synchronize()
+    return [p.detach().clone() for p in list(cloud.hot_parameters()) + list(m.parameters())]
+
+
+def main():
+    os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      DGS_DIST_FORCE_INIT="1", DGS_DIST_FORCE_COLLECTIVES="1")
+    os.environ.setdefault("MASTER_PORT", "29731")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from deblurgs_amd import sharding
+    rank, world, local = sharding.init_distributed("cuda")
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    # the raw pieces first: in-place AVG on a bucket, MAX on an int32 word, broadcast, p2p-free loss block
+    flat = torch.arange(64, dtype=torch.float32, device="cuda") * 0.25
+    views = [torch.nn.Parameter(torch.zeros(10, 3, device="cuda")), torch.nn.Parameter(torch.zeros(7, device="cuda"))]
+    views[0].grad, views[1].grad = flat[0:30].view(10, 3), flat[32:39]
+    keep = flat.clone()
+    small = torch.nn.Parameter(torch.ones(5, device="cuda"))
+    small.grad = torch.full((5,), 3.0, device="cuda")
+    sharding.flat_allreduce_grads(views, average=True, extra=[small], force=True)
+    assert torch.equal(flat, keep) and views[0].grad.data_ptr() == flat.data_ptr(), "in-place AVG all-reduce"
+    assert torch.equal(small.grad, torch.full((5,), 3.0, device="cuda"))
+    flag = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    assert flag.tolist() == [0, 1]
+    for mode in ("views", "subframes"):
+        sharding.FORCE_COLLECTIVES = False     # one rank: the gradient / loss-block / statistics collectives are skipped
+        base = train(mode)
+        sharding.FORCE_COLLECTIVES = True      # ... and now every one of them goes through RCCL
+        got = train(mode)
+        for i, (a, b) in enumerate(zip(base, got)):
+            assert a.shape == b.shape and torch.equal(a, b), f"mode {mode}: parameter {i} changed by a one-rank collective"
+        print(f"rccl smoke: mode {mode}: {len(got)} parameter tensors bit-identical with and without the collectives",
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rccl smoke ok: backend nccl, world 1", flush=True)
+
+
+if __name__ == "__main__":
+    main()
