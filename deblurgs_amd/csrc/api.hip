@@ -217,6 +217,38 @@ struct StageTimer {
 // traffic between the fused forward and backward.
 __device__ __forceinline__ float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 
+// Deterministic totals: a block's two sums (fixed-order fp32 trees of non-negative terms) are added as 2^-24 fixed-point
+// integers -- integer addition is associative, so the result does not depend on the order in which the blocks arrive,
+// unlike float atomics -- and the last block to arrive converts them.  losses is an 8-word work area: [0] L1,
+// [1] smoothness, [2..3] / [4..5] the two 64-bit accumulators, [6] arrival counter, [7] sticky "not representable" flag
+// (all zeroed by the launcher).  The fixed point covers totals below 2^40 ~ 1.1e12 at a resolution far below the fp32
+// rounding of the block sums; a block sum that is NaN / Inf (a diverged render, a NaN in the ground truth) or a total that
+// leaves the range sets the flag and both losses come back NaN, as float arithmetic would have reported them.
+__device__ __forceinline__ void loss_totals_publish(float a, float c, float* __restrict__ losses, size_t E, int K) {
+  constexpr double FX = 16777216.0;   // 2^24
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(losses + 2);
+  unsigned int* flag = reinterpret_cast<unsigned int*>(losses + 7);
+  const bool fin = __builtin_isfinite(a) && __builtin_isfinite(c) && a < 5.0e11f && c < 5.0e11f;
+  if (!fin) {
+    atomicOr(flag, 1u);
+  } else {
+    const unsigned long long ia = (unsigned long long)__double2ll_rn((double)a * FX);
+    const unsigned long long ic = (unsigned long long)__double2ll_rn((double)c * FX);
+    const unsigned long long oa = atomicAdd(&acc[0], ia), oc = atomicAdd(&acc[1], ic);
+    if (oa + ia < oa || oc + ic < oc) atomicOr(flag, 1u);   // the 64-bit accumulator wrapped
+  }
+  __threadfence();
+  const unsigned int ticket = atomicAdd(reinterpret_cast<unsigned int*>(losses + 6), 1u);
+  if (ticket == gridDim.x - 1) {
+    __threadfence();
+    const unsigned long long t0 = atomicAdd(&acc[0], 0ull), t1 = atomicAdd(&acc[1], 0ull);
+    const bool bad = atomicOr(flag, 0u) != 0u;
+    const float nanv = __int_as_float(0x7fc00000);
+    losses[0] = bad ? nanv : (float)(((double)t0 / FX) / (double)E);
+    losses[1] = bad ? nanv : ((K > 1) ? (float)(((double)t1 / FX) / ((double)E * (double)(K - 1))) : 0.0f);
+  }
+}
+
 // MODE 0: blur + loss values (forward).  MODE 1: dL/dsubframes, multiplied by the upstream scalar *scale read
 // from device memory (backward; no host sync, no extra elementwise pass over [K,3,H,W]).  MODE 2: both at once.
 template <int MODE, int V>  // V = elements per thread (4 -> 16-byte loads/stores when E % 4 == 0, else 1)
@@ -301,23 +333,9 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    // Deterministic totals: the block sums (fixed-order fp32 trees of non-negative terms) are added as 2^-32 fixed-point
-    // integers -- integer addition is associative, so the result does not depend on the order in which the blocks
-    // arrive, unlike float atomics -- and the last block to arrive converts them.  losses is an 8-word work area:
-    // [0] L1, [1] smoothness, [2..3] / [4..5] the two 64-bit accumulators, [6] arrival counter (zeroed by the launcher).
     const float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     const float c = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(losses + 2);
-    atomicAdd(&acc[0], (unsigned long long)__double2ll_rn((double)a * 4294967296.0));
-    atomicAdd(&acc[1], (unsigned long long)__double2ll_rn((double)c * 4294967296.0));
-    __threadfence();
-    const unsigned int ticket = atomicAdd(reinterpret_cast<unsigned int*>(losses + 6), 1u);
-    if (ticket == gridDim.x - 1) {
-      __threadfence();
-      const unsigned long long t0 = atomicAdd(&acc[0], 0ull), t1 = atomicAdd(&acc[1], 0ull);
-      losses[0] = (float)(((double)t0 / 4294967296.0) / (double)E);
-      losses[1] = (K > 1) ? (float)(((double)t1 / 4294967296.0) / ((double)E * (double)(K - 1))) : 0.0f;
-    }
+    loss_totals_publish(a, c, losses, E, K);
   }
 }
 
@@ -379,20 +397,10 @@ blur_loss_all_kernel(const float* __restrict__ sub, const float* __restrict__ gt
     red[1][w] = sm;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {   // deterministic fixed-point totals, as in blur_loss_kernel
+  if (threadIdx.x == 0) {   // deterministic fixed-point totals
     const float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     const float c = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    unsigned long long* accp = reinterpret_cast<unsigned long long*>(losses + 2);
-    atomicAdd(&accp[0], (unsigned long long)__double2ll_rn((double)a * 4294967296.0));
-    atomicAdd(&accp[1], (unsigned long long)__double2ll_rn((double)c * 4294967296.0));
-    __threadfence();
-    const unsigned int ticket = atomicAdd(reinterpret_cast<unsigned int*>(losses + 6), 1u);
-    if (ticket == gridDim.x - 1) {
-      __threadfence();
-      const unsigned long long t0 = atomicAdd(&accp[0], 0ull), t1 = atomicAdd(&accp[1], 0ull);
-      losses[0] = (float)(((double)t0 / 4294967296.0) / (double)E);
-      losses[1] = (K > 1) ? (float)(((double)t1 / 4294967296.0) / ((double)E * (double)(K - 1))) : 0.0f;
-    }
+    loss_totals_publish(a, c, losses, E, K);
   }
 }
 

@@ -1,15 +1,15 @@
 """Pose path of the blur-integration loop: Bezier curve in se(3) -> SE(3) -> rasteriser cameras.
 
-Mirrors (behaviour, names and argument meaning) of the reference's
+Same names, argument meaning and error behaviour as the reference's
   scene/bezier.py:14-85                      BezierModel
-  utils/pytorch3d_functions.py:218-247       _so3_exp_map
-  utils/pytorch3d_functions.py:337-372       hat
-  utils/pytorch3d_functions.py:373-457       se3_exp_map
-  utils/pytorch3d_functions.py:546-573       _se3_V_matrix
+  utils/pytorch3d_functions.py:373-540       se3_exp_map / se3_log_map / so3_exp_map / so3_log_map
   scene/motion.py:258-294                    _c2w_to_minicam  (batched here: no Python loop over K)
   scene/cameras.py:63-74                     MiniCam
   utils/graphics_utils.py:51-71              getProjectionMatrix
-The se3/so3 maps are pinned by tests/golden/pose_golden.npz (generated from the reference's own module).
+The exponential / logarithm maps are this package's own formulation (Rodrigues pieces shared between the maps); they run
+at initialisation and on the CPU -- the training step evaluates the pose path on the device (csrc/pose.hip).  Both are
+checked against tests/golden/pose_golden.npz (generated from the reference's own module) and against the function-by-
+function restatement of the reference kept as test infrastructure in oracle/pose_oracle.py.
 """
 import math
 
@@ -17,104 +17,104 @@ import torch
 import torch.nn as nn
 
 
-def hat(v: torch.Tensor) -> torch.Tensor:
-    """Skew-symmetric matrices of a batch of 3-vectors (pytorch3d_functions.py:337-372)."""
-    N, dim = v.shape
-    if dim != 3:
+def _cross_matrices(w: torch.Tensor) -> torch.Tensor:
+    """[N,3] -> [N,3,3] with  K(w) x = w cross x."""
+    if w.ndim != 2 or w.shape[1] != 3:
         raise ValueError("Input vectors have to be 3-dimensional.")
-    x, y, z = v.unbind(1)
-    zero = torch.zeros_like(x)
-    return torch.stack((zero, -z, y, z, zero, -x, -y, x, zero), dim=1).reshape(N, 3, 3)
+    K = w.new_zeros(w.shape[0], 3, 3)
+    K[:, 0, 1], K[:, 0, 2] = -w[:, 2], w[:, 1]
+    K[:, 1, 0], K[:, 1, 2] = w[:, 2], -w[:, 0]
+    K[:, 2, 0], K[:, 2, 1] = -w[:, 1], w[:, 0]
+    return K
 
 
-def _so3_exp_map(log_rot: torch.Tensor, eps: float = 0.0001):
-    _, dim = log_rot.shape
-    if dim != 3:
-        raise ValueError("Input tensor shape has to be Nx3.")
-    nrms = (log_rot * log_rot).sum(1)
-    rot_angles = torch.clamp(nrms, eps).sqrt()
-    rot_angles_inv = 1.0 / rot_angles
-    fac1 = rot_angles_inv * rot_angles.sin()
-    fac2 = rot_angles_inv * rot_angles_inv * (1.0 - rot_angles.cos())
-    skews = hat(log_rot)
-    skews_square = torch.bmm(skews, skews)
-    R = (fac1[:, None, None] * skews + fac2[:, None, None] * skews_square
-         + torch.eye(3, dtype=log_rot.dtype, device=log_rot.device)[None])
-    return R, rot_angles, skews, skews_square
+def _rodrigues(w: torch.Tensor, eps: float):
+    """The pieces of Rodrigues' formula for a batch of rotation vectors: the angle (its SQUARE clamped from below by eps,
+    the reference's guard against the 0/0 at the identity, utils/pytorch3d_functions.py:236-238), K(w) and K(w)^2."""
+    theta = (w * w).sum(dim=1).clamp(min=eps).sqrt()
+    K = _cross_matrices(w)
+    return theta, K, K @ K
 
 
 def so3_exp_map(log_rot: torch.Tensor, eps: float = 0.0001) -> torch.Tensor:
-    return _so3_exp_map(log_rot, eps=eps)[0]
+    """Rotation vectors [N,3] -> rotation matrices [N,3,3]:  R = I + sin(t)/t K + (1 - cos t)/t^2 K^2."""
+    if log_rot.ndim != 2 or log_rot.shape[1] != 3:
+        raise ValueError("Input tensor shape has to be Nx3.")
+    theta, K, K2 = _rodrigues(log_rot, eps)
+    inv = 1.0 / theta
+    eye = torch.eye(3, dtype=log_rot.dtype, device=log_rot.device)
+    return eye + (inv * theta.sin())[:, None, None] * K + (inv * inv * (1.0 - theta.cos()))[:, None, None] * K2
 
 
-def _se3_V_matrix(log_rotation, log_rotation_hat, log_rotation_hat_square, rotation_angles, eps: float = 1e-4):
-    return (torch.eye(3, dtype=log_rotation.dtype, device=log_rotation.device)[None]
-            + log_rotation_hat * ((1 - torch.cos(rotation_angles)) / (rotation_angles ** 2))[:, None, None]
-            + log_rotation_hat_square
-            * ((rotation_angles - torch.sin(rotation_angles)) / (rotation_angles ** 3))[:, None, None])
+def _left_jacobian(theta, K, K2):
+    """V = I + (1 - cos t)/t^2 K + (t - sin t)/t^3 K^2: maps the translation logarithm to the translation."""
+    eye = torch.eye(3, dtype=K.dtype, device=K.device)
+    return (eye + ((1.0 - theta.cos()) / theta ** 2)[:, None, None] * K
+            + ((theta - theta.sin()) / theta ** 3)[:, None, None] * K2)
 
 
 def se3_exp_map(log_transform: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
-    """[N,6] (log_translation | log_rotation) -> [N,4,4] SE(3) in the row-vector convention [[R,0],[T,1]]."""
+    """[N,6] (translation logarithm | rotation vector) -> [N,4,4] rigid transforms in the row-vector convention
+    [[R^T, 0], [t, 1]] the reference uses (utils/pytorch3d_functions.py:373-457; checked against tests/golden/
+    pose_golden.npz and oracle/pose_oracle.py).  The training step itself evaluates this on the device
+    (dgs_pose_forward, csrc/pose.hip); this is the initialisation / CPU implementation."""
     if log_transform.ndim != 2 or log_transform.shape[1] != 6:
         raise ValueError("Expected input to be of shape (N, 6).")
-    N, _ = log_transform.shape
-    log_translation = log_transform[..., :3]
-    log_rotation = log_transform[..., 3:]
-    R, rotation_angles, log_rotation_hat, log_rotation_hat_square = _so3_exp_map(log_rotation, eps=eps)
-    V = _se3_V_matrix(log_rotation, log_rotation_hat, log_rotation_hat_square, rotation_angles, eps=eps)
-    T = torch.bmm(V, log_translation[:, :, None])[:, :, 0]
-    transform = torch.zeros(N, 4, 4, dtype=log_transform.dtype, device=log_transform.device)
-    transform[:, :3, :3] = R
-    transform[:, :3, 3] = T
-    transform[:, 3, 3] = 1.0
-    return transform.permute(0, 2, 1)
+    u, w = log_transform[:, :3], log_transform[:, 3:]
+    theta, K, K2 = _rodrigues(w, eps)
+    inv = 1.0 / theta
+    eye = torch.eye(3, dtype=w.dtype, device=w.device)
+    R = eye + (inv * theta.sin())[:, None, None] * K + (inv * inv * (1.0 - theta.cos()))[:, None, None] * K2
+    t = (_left_jacobian(theta, K, K2) @ u[:, :, None])[:, :, 0]
+    out = log_transform.new_zeros(log_transform.shape[0], 4, 4)
+    out[:, :3, :3] = R.transpose(1, 2)
+    out[:, 3, :3] = t
+    out[:, 3, 3] = 1.0
+    return out
 
 
-def _acos_linear_extrapolation(x, bound):
-    """acos(x) inside (-bound, bound), its first-order Taylor line outside (pytorch3d_functions.py:26-81)."""
-    def line(x0):
-        return (x - x0) * (-1.0 / math.sqrt(1.0 - x0 * x0)) + math.acos(x0)
-    inner = torch.acos(x.clamp(-bound, bound))
-    return torch.where(x >= bound, line(bound), torch.where(x <= -bound, line(-bound), inner))
+def _acos_guarded(x: torch.Tensor, bound: float) -> torch.Tensor:
+    """acos on [-bound, bound], continued outside by its tangent line at +-bound: finite slope for traces that rounding
+    pushed to (or past) 3 and -1 (the reference's acos_linear_extrapolation, utils/pytorch3d_functions.py:26-81)."""
+    slope = -1.0 / math.sqrt(1.0 - bound * bound)
+    hi = math.acos(bound) + (x - bound) * slope
+    lo = math.acos(-bound) + (x + bound) * slope
+    return torch.where(x >= bound, hi, torch.where(x <= -bound, lo, torch.acos(x.clamp(-bound, bound))))
 
 
 def so3_log_map(R: torch.Tensor, eps: float = 0.0001, cos_bound: float = 1e-4) -> torch.Tensor:
-    """[N,3,3] rotation matrices -> [N,3] logarithms (pytorch3d_functions.py:248-300 with so3_rotation_angle
-    :121-176 and hat_inv :303-336): angle from the trace through the linearly extrapolated acos, factor
-    phi / (2 sin phi) with its second-order Taylor value where |sin phi| <= eps / 2."""
+    """Rotation matrices [N,3,3] -> rotation vectors [N,3]: the angle from the trace (guarded acos), then
+    w = t / (2 sin t) * vee(R - R^T), with the series 1/2 + t^2/12 for that factor where |sin t| <= eps / 2
+    (utils/pytorch3d_functions.py:121-176, 248-300)."""
     if R.ndim != 3 or R.shape[1:] != (3, 3):
         raise ValueError("Input has to be a batch of 3x3 Tensors.")
-    rot_trace = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
-    if ((rot_trace < -1.0 - eps) + (rot_trace > 3.0 + eps)).any():
+    trace = R.diagonal(dim1=1, dim2=2).sum(dim=1)
+    if bool(((trace < -1.0 - eps) | (trace > 3.0 + eps)).any()):
         raise ValueError("A matrix has trace outside valid range [-1-eps,3+eps].")
-    phi_cos = (rot_trace - 1.0) * 0.5
-    phi = _acos_linear_extrapolation(phi_cos, 1.0 - cos_bound) if cos_bound > 0.0 else torch.acos(phi_cos)
-    phi_sin = torch.sin(phi)
-    ok = phi_sin.abs() > (0.5 * eps)
-    safe = torch.where(ok, phi_sin, torch.ones_like(phi_sin))
-    phi_factor = torch.where(ok, phi / (2.0 * safe), 0.5 + (phi ** 2) * (1.0 / 12))
-    h = phi_factor[:, None, None] * (R - R.permute(0, 2, 1))
-    if float(torch.abs(h + h.permute(0, 2, 1)).max()) > 1e-5:
+    c = 0.5 * (trace - 1.0)
+    theta = _acos_guarded(c, 1.0 - cos_bound) if cos_bound > 0.0 else torch.acos(c)
+    s = theta.sin()
+    regular = s.abs() > 0.5 * eps
+    factor = torch.where(regular, theta / (2.0 * torch.where(regular, s, torch.ones_like(s))),
+                         0.5 + theta * theta / 12.0)
+    A = factor[:, None, None] * (R - R.transpose(1, 2))
+    if float((A + A.transpose(1, 2)).abs().max()) > 1e-5:
         raise ValueError("One of input matrices is not skew-symmetric.")
-    return torch.stack((h[:, 2, 1], h[:, 0, 2], h[:, 1, 0]), dim=1)
+    return torch.stack((A[:, 2, 1], A[:, 0, 2], A[:, 1, 0]), dim=1)
 
 
 def se3_log_map(transform: torch.Tensor, eps: float = 1e-4, cos_bound: float = 1e-4) -> torch.Tensor:
-    """[N,4,4] SE(3) matrices in the row-vector convention [[R,0],[T,1]] -> [N,6] (log_translation | log_rotation)
-    (pytorch3d_functions.py:462-540): so3_log_map of the transposed upper-left block, translation = V^-1 T.
-    Used once, at initialisation, on the dataset's camera poses (scene/motion.py:196-205)."""
+    """[N,4,4] rigid transforms (row-vector convention, last column (0,0,0,1)) -> [N,6] (translation logarithm | rotation
+    vector): the inverse of se3_exp_map (utils/pytorch3d_functions.py:462-540).  Used once, at initialisation, on the
+    dataset's camera poses (scene/motion.py:196-205)."""
     if transform.ndim != 3 or transform.shape[1:] != (4, 4):
         raise ValueError("Input tensor shape has to be (N, 4, 4).")
     if not torch.allclose(transform[:, :3, 3], torch.zeros_like(transform[:, :3, 3])):
         raise ValueError("All elements of `transform[:, :3, 3]` should be 0.")
-    log_rotation = so3_log_map(transform[:, :3, :3].permute(0, 2, 1), eps=eps, cos_bound=cos_bound)
-    nrms = (log_rotation ** 2).sum(-1)
-    rotation_angles = torch.clamp(nrms, eps).sqrt()
-    skew = hat(log_rotation)
-    V = _se3_V_matrix(log_rotation, skew, torch.bmm(skew, skew), rotation_angles, eps=eps)
-    log_translation = torch.linalg.solve(V, transform[:, 3, :3][:, :, None])[:, :, 0]
-    return torch.cat((log_translation, log_rotation), dim=1)
+    w = so3_log_map(transform[:, :3, :3].transpose(1, 2), eps=eps, cos_bound=cos_bound)
+    theta, K, K2 = _rodrigues(w, eps)
+    u = torch.linalg.solve(_left_jacobian(theta, K, K2), transform[:, 3, :3][:, :, None])[:, :, 0]
+    return torch.cat((u, w), dim=1)
 
 
 # ---- unit quaternions <-> rotation matrices for curve_type="quarternion_cartesian" (scene/motion.py:191-194,242-246).

@@ -230,7 +230,8 @@ int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t*
 /* Fused loss-gradient image (train.py:143-165, utils/loss_utils.py:17-18,80-93): from the K rendered subframes
  * and the target, produces blur = mean_k, the L1 and temporal-smoothness loss values and/or dL/dsubframes in one pass.
  * `losses` is an 8-float (32-byte) work area whose first two words receive {l1, smooth}; the totals are formed with
- * integer (fixed-point) atomics and are therefore bitwise reproducible.  Forward call: blur + losses non-null, dL_dsubframes NULL.  Backward call: losses
+ * integer (2^-24 fixed-point) atomics and are therefore bitwise reproducible; a NaN / Inf among the inputs, or a total
+ * beyond the fixed-point range (2^40), makes both values NaN.  Forward call: blur + losses non-null, dL_dsubframes NULL.  Backward call: losses
  * NULL, dL_dsubframes non-null, `upstream` = device pointer to the scalar dL/d(l1 + lambda_t*smooth) (NULL = 1); blur
  * is then an optional INPUT (the forward call's blur, which saves re-summing the K subframes; NULL = recompute).
  * All three outputs non-null computes everything at once. */

@@ -209,3 +209,70 @@ def test_cfg5_stress_as_benchmarked(gpu):
     for r in report:
         print("   ", r)
     print(f"[cfg5] {time.time() - t0:.0f} s")
+
+
+def test_fused_step_capacity_mode_as_benchmarked_at_metric_size(gpu):
+    """What bench.py times is FusedStep.run -> dgs_forward(capacity): the duplicate arrays are sized ahead, the count
+    stays on the device (n_dev paths of the sort / ranges kernels).  At the metric size (37 M duplicates) that path must
+    give, bit for bit, what the exact two-phase forward gives, and both must equal the autograd path
+    (render_subframes + loss.backward) that test_config_as_benchmarked holds against the oracle -- same cameras, same
+    upstream gradient -- so the oracle check covers the benchmarked kernels transitively."""
+    import torch
+    from deblurgs_amd import gaussian_renderer
+    from deblurgs_amd.cloud import GaussianCloud
+    from deblurgs_amd.fused_step import FusedStep
+    from deblurgs_amd.motion import CameraMotionModule, RefCamera
+    sc = synthetic.make_config("metric")
+    K, P, W, H = sc["K"], sc["P"], sc["W"], sc["H"]
+    C = synthetic.CONFIGS["metric"]["C"]
+    dev = "cuda"
+    cloud = GaussianCloud.from_scene(sc, dev)
+    ref = RefCamera(W, H, sc["FoVx"], sc["FoVy"], device=dev)
+    gt = torch.rand((1, 3, H, W), generator=torch.Generator().manual_seed(1234)).to(dev)
+    m = CameraMotionModule(ref, gt, curve_order=C, num_subframes=K, device=dev)
+    traj = synthetic.make_trajectory(K, C, sc["projection_matrix"], seed=0)
+    with torch.no_grad():
+        m._trans._control_points.copy_(torch.from_numpy(traj["ctrl_trans"])[None].to(dev))
+        m._rot._control_points.copy_(torch.from_numpy(traj["ctrl_rot"])[None].to(dev))
+    m.link_gaussian(cloud)
+    assert m.is_optimizing()                        # the benchmarked step optimises the curves too
+    bg = torch.tensor([0.3, 0.6, 0.1], device=dev)
+    fs = FusedStep(cloud, m, lambda_hinge=0.0, speculative=True)
+    names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+
+    def snapshot(fr):
+        torch.cuda.synchronize()
+        g = {n: p.grad.clone() for n, p in zip(names, cloud.hot_parameters())}
+        g.update(subframes=fr["subframes"].clone(), viewspace=fr["viewspace_grad"].clone(), radii=fr["radii"].clone(),
+                 losses=fr["losses"].clone(), ct=m._trans._control_points.grad.clone(),
+                 cr=m._rot._control_points.grad.clone())
+        return g
+
+    a_fr = fs.run(0, 1e-3, m.get_gt_image(0), bg)                      # exact two-phase forward: learns the count
+    assert a_fr["skip_flag_ptr"] is None
+    a = snapshot(a_fr)
+    dsub, view, full, campos = (fs._keep[i].clone() for i in (6, 7, 8, 9))
+    fs._poll(block=True)
+    R = fs._seen[(0, K, 0)][-1]
+    assert R > 30_000_000
+    b_fr = fs.run(0, 1e-3, m.get_gt_image(0), bg)                      # capacity mode, as benchmarked
+    assert b_fr["skip_flag_ptr"] is not None and fs.last_capacity == R + R // 4 + 16384
+    b = snapshot(b_fr)
+    fs._poll(block=True)
+    assert fs.dropped == 0 and fs._seen[(0, K, 0)][-1] == R
+    for key in a:
+        assert torch.equal(a[key], b[key]), f"capacity mode vs exact forward: {key}"
+    del a_fr, b_fr, fs
+    torch.cuda.empty_cache()
+    # the autograd path on the same cameras with the same upstream gradient
+    for p in cloud.hot_parameters():
+        p.grad = None
+    view.requires_grad_(True)
+    full.requires_grad_(True)
+    pkg = gaussian_renderer.render_subframes(view, full, campos, ref, cloud, bg)
+    assert torch.equal(pkg["render"], a["subframes"]) and torch.equal(pkg["radii"], a["radii"])
+    (pkg["render"] * dsub).sum().backward()
+    torch.cuda.synchronize()
+    for n, p in zip(names, cloud.hot_parameters()):
+        assert torch.equal(p.grad, b[n]), f"fused step vs autograd path: {n}"
+    assert torch.equal(pkg["viewspace_points"].grad, b["viewspace"])

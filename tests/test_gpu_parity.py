@@ -522,6 +522,35 @@ def test_fused_blur_loss_vs_golden(gpu):
     assert np.abs(blur.cpu().numpy() - g["sub"].mean(0)).max() <= 1e-6
 
 
+@pytest.mark.parametrize("where", ["sub_nan", "gt_inf", "huge"])
+def test_fused_blur_loss_reports_non_finite_inputs(gpu, where):
+    """The loss totals are sums of fixed-point integers (bitwise reproducible); a NaN / Inf in the rendered subframes or
+    the ground truth, or a total beyond the fixed-point range, must still come back as NaN -- never as a finite number that
+    hides a divergence -- in the forward-only call and in the all-in-one call of the fused step."""
+    import ctypes
+    import torch
+    from deblurgs_amd import _lib
+    torch.manual_seed(3)
+    K, H, W = 5, 40, 64
+    sub = torch.rand(K, 3, H, W, device="cuda")
+    gt = torch.rand(3, H, W, device="cuda")
+    if where == "sub_nan":
+        sub[2, 1, 7, 9] = float("nan")
+    elif where == "gt_inf":
+        gt[0, 3, 3] = float("inf")
+    else:
+        sub[1] = 3.0e8                       # |sub[1] - sub[0]| summed over 7680 elements leaves the 2^40 range
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for all_in_one in (False, True):
+        blur = torch.empty_like(gt)
+        work = torch.empty(8, device="cuda")
+        dsub = torch.empty_like(sub) if all_in_one else None
+        _lib.check(_lib.lib().dgs_blur_loss_grad(sub.data_ptr(), gt.data_ptr(), K, 3, H * W, 1e-3, None, blur.data_ptr(),
+                                                 None if dsub is None else dsub.data_ptr(), work.data_ptr(), st), "loss")
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(work[0])) and bool(torch.isnan(work[1])), (where, all_in_one, work[:2].tolist())
+
+
 # ------------------------------------------------------------- BASELINE-size, size-independent properties
 def test_metric_size_properties(gpu):
     """cfg2-sized fused run (100k Gaussians, 800x800, K=9): sortedness, range/key consistency, checksum of

@@ -33,6 +33,30 @@ def test_pose_path_matches_reference_se3_exp_map():
     assert np.abs(back.numpy() - g["exp64"]).max() <= 1e-9
 
 
+def test_pose_oracle_is_pinned_and_checks_the_product_maps():
+    """oracle/pose_oracle.py (the function-by-function restatement of utils/pytorch3d_functions.py, test infrastructure)
+    against the reference-generated golden vectors, and the product's own formulation (deblurgs_amd/pose.py) against it on
+    fresh inputs: exact zeros, tiny angles (the eps clamp), angles near pi."""
+    from deblurgs_amd import pose
+    from oracle import pose_oracle as po
+    g = load("pose_golden.npz")
+    se3 = torch.tensor(g["se3"])
+    assert np.abs(po.se3_exp_map(se3.double()).numpy() - g["exp64"]).max() <= 1e-12
+    assert np.abs(po.se3_exp_map(se3).numpy() - g["exp32"]).max() <= 2e-6
+    assert np.abs(po.se3_log_map(torch.tensor(g["exp64"])).numpy() - g["log_of_exp64"]).max() <= 1e-12
+    torch.manual_seed(11)
+    x = torch.randn(200, 6, dtype=torch.float64)
+    x[:20, 3:] *= 1e-5
+    x[20] = 0.0
+    x[21:40, 3:] *= 3.1 / x[21:40, 3:].norm(dim=1, keepdim=True)
+    for dt, tol in ((torch.float64, 1e-13), (torch.float32, 1e-6)):
+        T = po.se3_exp_map(x.to(dt))
+        assert float((pose.se3_exp_map(x.to(dt)) - T).abs().max()) <= tol
+        assert float((pose.so3_exp_map(x[:, 3:].to(dt)) - po.so3_exp_map(x[:, 3:].to(dt))).abs().max()) <= tol
+        assert float((pose.se3_log_map(T) - po.se3_log_map(T)).abs().max()) <= tol * 10
+        assert float((pose.so3_log_map(T[:, :3, :3]) - po.so3_log_map(T[:, :3, :3])).abs().max()) <= tol * 10
+
+
 def test_se3_log_map_matches_reference():
     """pose.se3_log_map against the reference's own se3_log_map outputs (utils/pytorch3d_functions.py:462-540, golden
     `log_of_exp64`), including the exact-zero, near-zero (Taylor branch of phi / 2 sin phi) and large-angle rows."""
