@@ -254,8 +254,9 @@ __device__ __forceinline__ void loss_totals_publish(float a, float c, float* __r
 template <int MODE, int V>  // V = elements per thread (4 -> 16-byte loads/stores when E % 4 == 0, else 1)
 __global__ void __launch_bounds__(256)
 blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, int K, size_t E, float lambda_t,
-                 const float* __restrict__ scale, float* __restrict__ blur, float* __restrict__ dsub,
-                 float* __restrict__ losses) {
+                 const float* __restrict__ lambda_dev, const float* __restrict__ scale, float* __restrict__ blur,
+                 float* __restrict__ dsub, float* __restrict__ losses) {
+  if (lambda_dev != nullptr) lambda_t = lambda_dev[0];   // graph replay: the scheduled weight lives in device memory
   __shared__ float red[2][4];
   typedef float vec __attribute__((ext_vector_type(V)));
   float l1 = 0.0f, sm = 0.0f;
@@ -345,8 +346,9 @@ blur_loss_kernel(const float* __restrict__ sub, const float* __restrict__ gt, in
 template <int KMAX, int V>
 __global__ void __launch_bounds__(256)
 blur_loss_all_kernel(const float* __restrict__ sub, const float* __restrict__ gt, int K, size_t E, float lambda_t,
-                     const float* __restrict__ scale, float* __restrict__ blur, float* __restrict__ dsub,
-                     float* __restrict__ losses) {
+                     const float* __restrict__ lambda_dev, const float* __restrict__ scale, float* __restrict__ blur,
+                     float* __restrict__ dsub, float* __restrict__ losses) {
+  if (lambda_dev != nullptr) lambda_t = lambda_dev[0];
   __shared__ float red[2][4];
   typedef float vec __attribute__((ext_vector_type(V)));
   float l1 = 0.0f, sm = 0.0f;
@@ -432,7 +434,8 @@ densify_stats_kernel(const float* __restrict__ vgrad, const int32_t* __restrict_
 }  // namespace
 
 hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t,
-                                const float* scale, float* blur, float* dsub, float* losses, hipStream_t s) {
+                                const float* lambda_dev, const float* scale, float* blur, float* dsub, float* losses,
+                                hipStream_t s) {
   const size_t E = (size_t)C * HW;
   if (losses != nullptr) {
     hipError_t e = hipMemsetAsync(losses, 0, 8 * sizeof(float), s);   // results + accumulators + arrival counter
@@ -449,10 +452,10 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
 #define DGS_BL(MODE)                                                                                              \
   do {                                                                                                            \
     if (v4)                                                                                                       \
-      hipLaunchKernelGGL((blur_loss_kernel<MODE, 4>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, \
+      hipLaunchKernelGGL((blur_loss_kernel<MODE, 4>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, lambda_dev, scale, blur, \
                          dsub, losses);                                                                           \
     else                                                                                                          \
-      hipLaunchKernelGGL((blur_loss_kernel<MODE, 1>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, \
+      hipLaunchKernelGGL((blur_loss_kernel<MODE, 1>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, lambda_dev, scale, blur, \
                          dsub, losses);                                                                           \
   } while (0)
   if (dsub == nullptr)
@@ -460,10 +463,10 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
   else if (losses == nullptr)
     DGS_BL(1);
   else if (v4 && K <= 16)
-    hipLaunchKernelGGL((blur_loss_all_kernel<16, 4>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, dsub,
+    hipLaunchKernelGGL((blur_loss_all_kernel<16, 4>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, lambda_dev, scale, blur, dsub,
                        losses);
   else if (v4 && K <= 32)
-    hipLaunchKernelGGL((blur_loss_all_kernel<32, 2>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, scale, blur, dsub,
+    hipLaunchKernelGGL((blur_loss_all_kernel<32, 2>), grid, dim3(256), 0, s, sub, gt, K, E, lambda_t, lambda_dev, scale, blur, dsub,
                        losses);
   else
     DGS_BL(2);
@@ -496,9 +499,9 @@ size_t dgs_binning_state_bytes(uint64_t R, int32_t W, int32_t H, int32_t K) {
   return L.binning_total;
 }
 size_t dgs_backward_scratch_bytes(uint64_t R, int32_t P, int32_t K) {
-  // contribution rows [R] + their per-pair totals by natural index [K*P] (48 bytes each) + pose-gradient partials
+  // contribution rows [R] + their per-pair totals by natural index [K*P] (48 bytes each) + pose-gradient partials (f64)
   return up((size_t)R * DGS_CONTRIB_F * 4) + up((size_t)K * (size_t)P * DGS_CONTRIB_F * 4) +
-         up((size_t)dgs_geometry_bwd_blocks(P) * (size_t)K * 24 * 4) + ALIGN;
+         up((size_t)dgs_geometry_bwd_blocks(P) * (size_t)K * 24 * 8) + ALIGN;
 }
 int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, int32_t wide_records, DgsLayout* out) {
   if (out == nullptr) return fail(DGS_E_ARG, "null DgsLayout");
@@ -566,12 +569,11 @@ static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, ui
                                hipStream_t s) {
   int rc = check_problem(p);
   if (rc != DGS_OK) return rc;
-  if (out == nullptr || out->out_color == nullptr || out->out_depth == nullptr)
-    return fail(DGS_E_ARG, "DgsForwardOut: out_color / out_depth are null");
+  if (out == nullptr || out->out_color == nullptr) return fail(DGS_E_ARG, "DgsForwardOut: out_color is null");
   const size_t N = (size_t)p->W * p->H;
   if (p->P == 0) {  // the reference returns zero-filled images when P == 0 (rasterize_points.cu:70-71,85)
     hipError_t e = hipMemsetAsync(out->out_color, 0, (size_t)p->K * 3 * N * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(out->out_depth, 0, (size_t)p->K * N * 4, s);
+    if (e == hipSuccess && out->out_depth != nullptr) e = hipMemsetAsync(out->out_depth, 0, (size_t)p->K * N * 4, s);
     return e == hipSuccess ? DGS_OK : fail_hip(e, "memset outputs");
   }
   DgsLayout L;
@@ -636,7 +638,9 @@ int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity
     make_layout(p->P, p->W, p->H, p->K, 0, p->wide_records != 0, &L);
     DgsCarve c;
     carve(p, L, &c);
-    hipError_t e = dgs_launch_finalize_count(c, p->tile_cull != 0, capacity, s);
+    hipError_t e = dgs_launch_finalize_count(c, p->tile_cull != 0, capacity, out->drop_counter, s);
+    if (e == hipSuccess && out->drop_counter != nullptr)   // [4] = overflowed forwards so far (caller's running counter)
+      e = hipMemcpyAsync(out->num_rendered_host + 4, out->drop_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess)   // [2] = overflow flag, [3] = the count the lists were built with (0 on overflow)
       e = hipMemcpyAsync(out->num_rendered_host + 2, c.num_rendered + 5, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess)
@@ -687,8 +691,8 @@ int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stre
   }
   float* contrib = reinterpret_cast<float*>(io->scratch);
   float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(io->scratch) + up((size_t)R * DGS_CONTRIB_F * 4));
-  float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(sums) +
-                                             up((size_t)p->K * (size_t)p->P * DGS_CONTRIB_F * 4));
+  double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(sums) +
+                                               up((size_t)p->K * (size_t)p->P * DGS_CONTRIB_F * 4));
   DGS_STAGE(DGS_STAGE_COMPOSITE_BWD, "composite backward",
             dgs_launch_composite_bwd(v, c, p->bg, io->dL_dout_color, io->dL_dout_depth, contrib, s));
   DGS_STAGE(DGS_STAGE_GEOMETRY_BWD, "geometry backward", dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s));
@@ -735,17 +739,28 @@ int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t*
   return e == hipSuccess ? DGS_OK : fail_hip(e, "sort");
 }
 
-int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW, float lambda_t,
-                       const float* upstream, float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream) {
+static int blur_loss_impl(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW, float lambda_t,
+                          const float* lambda_dev, const float* upstream, float* blur, float* dL_dsubframes, float* losses,
+                          dgs_stream_t stream) {
   const bool fwd = (blur != nullptr && losses != nullptr);
   // losses given: blur is an output (forward, or forward + backward when dL_dsubframes is given too);
   // losses NULL: backward only, blur (optional) is the forward's blur handed back in
   if (subframes == nullptr || gt == nullptr || K < 1 || C < 1 || HW < 1 || (!fwd && dL_dsubframes == nullptr) ||
       (losses != nullptr && blur == nullptr))
     return fail(DGS_E_ARG, "blur_loss_grad: bad argument");
-  hipError_t e = dgs_launch_blur_loss(subframes, gt, K, C, HW, lambda_t, upstream, blur, dL_dsubframes, losses,
-                                      reinterpret_cast<hipStream_t>(stream));
+  hipError_t e = dgs_launch_blur_loss(subframes, gt, K, C, HW, lambda_t, lambda_dev, upstream, blur, dL_dsubframes,
+                                      losses, reinterpret_cast<hipStream_t>(stream));
   return e == hipSuccess ? DGS_OK : fail_hip(e, "blur_loss_grad");
+}
+int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW, float lambda_t,
+                       const float* upstream, float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream) {
+  return blur_loss_impl(subframes, gt, K, C, HW, lambda_t, nullptr, upstream, blur, dL_dsubframes, losses, stream);
+}
+int dgs_blur_loss_grad_dev(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW,
+                           const float* lambda_t_dev, const float* upstream, float* blur, float* dL_dsubframes,
+                           float* losses, dgs_stream_t stream) {
+  if (lambda_t_dev == nullptr) return fail(DGS_E_ARG, "blur_loss_grad_dev: lambda_t_dev is null");
+  return blur_loss_impl(subframes, gt, K, C, HW, 0.0f, lambda_t_dev, upstream, blur, dL_dsubframes, losses, stream);
 }
 
 int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t K_total, int32_t P,

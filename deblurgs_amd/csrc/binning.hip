@@ -411,11 +411,12 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
 // c.num_rendered: [0] rectangle total, [1] its high half (u32 overflow), [2] surviving total (tile_cull), [4] the count
 // the sort / ranges kernels use = min(count, capacity), [5] overflow flag (the lists are truncated: every consumer that
 // indexes by duplicate offset returns early, the caller re-runs with a larger capacity).
-__global__ void finalize_count_kernel(uint32_t* __restrict__ nr, int cull, uint32_t cap) {
+__global__ void finalize_count_kernel(uint32_t* __restrict__ nr, int cull, uint32_t cap, uint32_t* __restrict__ drops) {
   const uint32_t n = cull ? nr[2] : nr[0];
   const bool bad = (nr[1] != 0u) || (n > cap);
   nr[4] = bad ? 0u : n;
   nr[5] = bad ? 1u : 0u;
+  if (bad && drops != nullptr) drops[0] += 1u;   // the caller's running count of overflowed forwards (graph replays)
 }
 
 // ---------------------------------------------------------------------------------------------- ranges
@@ -1014,8 +1015,8 @@ PassPlan plan_passes(int begin_bit, int end_bit) {
 
 }  // namespace
 
-hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, hipStream_t s) {
-  hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, s, c.num_rendered, cull, cap);
+hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, uint32_t* drops, hipStream_t s) {
+  hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, s, c.num_rendered, cull, cap, drops);
   return hipGetLastError();
 }
 

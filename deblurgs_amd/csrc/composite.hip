@@ -15,6 +15,8 @@
 //       [sum w*dx, sum w*dy, sum w*dx*dx, sum w*dx*dy, sum w*dy*dy, sum w, dL_dr, dL_dg, dL_db, dL_ddepth].  geometry_bwd.hip sums a Gaussian's rows in
 //     duplicate order, so the whole backward is bitwise reproducible (the reference issues 10 float
 //     atomicAdds per (pixel, Gaussian), backward.cu:599-637).
+#include <type_traits>
+
 #include "dgs_common.h"
 
 namespace {
@@ -65,11 +67,22 @@ __device__ __forceinline__ float dgs_power2(float A, float B, float C, float dx,
   return fmaf(C * dy, dy, dx * u);
 }
 
+// v_min_f32 without the canonicalising v_max_f32 x, x that fminf() of a value merged from two control-flow paths gets
+// (au is never a signalling NaN: it comes out of v_mul / v_cndmask)
+__device__ __forceinline__ float dgs_min_raw(float c, float x) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(c), "v"(x));
+  return r;
+}
+
 using CullGauss = DgsCull;
 #define make_cull dgs_make_cull
 #define cull_hit dgs_cull_hit
 
 // ------------------------------------------------------------------------------------------------ forward
+// WITHDEPTH = false: the caller does not consume the depth image (DgsForwardOut.out_depth == NULL; the default training
+// loss never reads it): the depth channel drops out of the per-pair math and nothing is stored for it.
+template <bool WITHDEPTH>
 __global__ void __launch_bounds__(64 * CW)
 composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
                      const uint32_t* __restrict__ point_list, const uint64_t* __restrict__ keys,
@@ -120,6 +133,11 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       Cc = rp[2];
     }
     const CullGauss cg = make_cull(A.z, A.w, B.x, B.y);
+    // entries whose conic is positive definite (as evaluated in fp32 by make_cull -- the SAME predicate in the forward
+    // and the backward): power = -q/2 <= 0 for every pixel in exact arithmetic, so the reference's `power > 0` skip
+    // (forward.cu:354-355) can only fire through rounding, on pixels the parity tests already classify as unstable;
+    // those entries take the pass variant without the compare
+    const uint64_t pdm = __ballot(!cg.always);
     uint64_t m[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -138,7 +156,12 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    uint64_t mu = m[0] | m[1] | m[2] | m[3];
+    // The batch loop exists twice: without the `power <= 0` compare when every entry that can contribute has a positive
+    // definite conic (all but pathological batches), with it otherwise.  One wave-uniform decision per batch.
+    const uint64_t mu_all = m[0] | m[1] | m[2] | m[3];
+    auto run_batch = [&](auto checkc) {
+    constexpr bool CHECK = decltype(checkc)::value;
+    uint64_t mu = mu_all;
     while (mu) {
       const int j = __builtin_ctzll(mu);
       mu &= mu - 1;
@@ -150,16 +173,16 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       // select below needs a v_mov per quadrant pass (a select cannot take an SGPR mask and an SGPR source)
       uint32_t posv = base + (uint32_t)j + 1u;
       asm volatile("" : "+v"(posv));
+      // forward.cu:348-380, branch-free per lane: a pair that fails one of the reference's tests gets alpha = 0, which
+      // leaves T, C, D and `last` untouched (T >= 1e-4 always, so alpha = 0 can never terminate).
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         if ((m[q] >> j) & 1ull) {  // wave-uniform: this Gaussian can reach quadrant q
           const float dx = a.x - ((q & 1) ? pxf1 : pxf0);
           const float dy = a.y - ((q >> 1) ? pyf1 : pyf0);
-          // forward.cu:348-380, branch-free: a pair that fails one of the reference's tests gets alpha = 0,
-          // which leaves T, C, D and `last` untouched (T >= 1e-4 always, so alpha = 0 can never terminate).
           const float power = dgs_power2(a.z, a.w, b.x, dx, dy);  // log2(e) * the reference's `power`
           const float alpha_raw = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
-          const bool ok = (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
+          const bool ok = (!CHECK || power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
           const float alpha = ok ? alpha_raw : 0.0f;
           const float test_T = T[q] * (1.0f - alpha);
           const bool stop = test_T < 0.0001f;      // also every pair of a pixel that is already done (T < 0)
@@ -167,12 +190,17 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           C0[q] += b.z * wgt;
           C1[q] += b.w * wgt;
           C2[q] += c.x * wgt;
-          Dd[q] += c.y * wgt;
+          if (WITHDEPTH) Dd[q] += c.y * wgt;
           T[q] = stop ? -fabsf(T[q]) : test_T;     // alpha = 0 leaves a live T unchanged
           last[q] = (ok && !stop) ? posv : last[q];
         }
       }
     }
+    };
+    if ((~pdm & mu_all) == 0ull)
+      run_batch(std::false_type{});
+    else
+      run_batch(std::true_type{});
 #pragma unroll
     for (int q = 0; q < 4; q++) alive[q] = __ballot(T[q] > 0.0f);
     __builtin_amdgcn_wave_barrier();  // LDS rows are rewritten by the next batch
@@ -192,7 +220,7 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       oc[pix] = C0[q] + Tf * bg0;
       oc[N + pix] = C1[q] + Tf * bg1;
       oc[2 * N + pix] = C2[q] + Tf * bg2;
-      out_depth[(size_t)t.k * N + pix] = Dd[q] + Tf * v.z_far;
+      if (WITHDEPTH) out_depth[(size_t)t.k * N + pix] = Dd[q] + Tf * v.z_far;
     }
   }
 }
@@ -304,8 +332,10 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       }
     }
     uint64_t m[4] = {0, 0, 0, 0};
+    uint64_t pdm = 0;   // entries with a positive definite conic (same predicate as the forward): no `power <= 0` compare
     if (base < maxc) {
       const CullGauss cg = make_cull(A.z, A.w, B.x, B.y);
+      pdm = __ballot(!cg.always);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const float ex = A.x - (qx0 + (float)((q & 1) * 8)), ey = A.y - (qy0 + (float)((q >> 1) * 8));
@@ -324,7 +354,11 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    uint64_t mu = m[0] | m[1] | m[2] | m[3];
+    // (two copies of the batch loop, with and without the `power <= 0` compare: see the forward)
+    const uint64_t mu_all = m[0] | m[1] | m[2] | m[3];
+    auto run_batch = [&](auto checkc) {
+    constexpr bool CHECK = decltype(checkc)::value;
+    uint64_t mu = mu_all;
     while (mu) {
       const int j = 63 - __builtin_clzll(mu);  // back to front
       mu &= ~(1ull << j);
@@ -345,19 +379,17 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         if ((m[q] >> j) & 1ull) {  // wave-uniform
           const float dx = a.x - ((q & 1) ? pxf1 : pxf0);
           const float dy = a.y - ((q >> 1) ? pyf1 : pyf0);
-          // backward.cu:566-637, branch-free.  A pair that the reference skips gets alpha = 0: then
-          // T/(1-alpha) = T, every gradient term is an exact 0 and the colour-behind recurrence below is the
-          // identity (0*c + 1*acc), so the results are bit-identical to skipping.  The recurrence is applied
-          // eagerly (acc <- alpha*c + (1-alpha)*acc right after the pair is used) instead of one pair late with a
-          // remembered last_alpha / last_color as in the reference: same operations in the same order, 5 fewer
-          // live registers per pixel.
+          // backward.cu:566-637, branch-free per lane.  A pair that the reference skips gets alpha = 0: then
+          // T/(1-alpha) = T, every gradient term is an exact 0 and the colour-behind recurrence below is the identity,
+          // so the results are bit-identical to skipping.  The recurrence is applied eagerly (right after the pair is
+          // used) instead of one pair late with a remembered last_alpha / last_color as in the reference: same
+          // operations in the same order, 5 fewer live registers per pixel.
           const float power = dgs_power2(a.z, a.w, b.x, dx, dy);  // log2(e) * the reference's `power`
           const float au_any = b.y * __builtin_amdgcn_exp2f(power);
-          const bool ok = (pos < last[q]) && (power <= 0.0f) && (au_any >= 1.0f / 255.0f);
+          const bool ok = (pos < last[q]) && (!CHECK || power <= 0.0f) && (au_any >= 1.0f / 255.0f);
           const float au = ok ? au_any : 0.0f;  // opacity * G: the unclamped alpha the backward differentiates
-          const float alpha = fminf(0.99f, au);
-          const float oma = 1.0f - alpha;
-          const float inv1ma = __builtin_amdgcn_rcpf(oma);
+          const float alpha = dgs_min_raw(0.99f, au);
+          const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
           T[q] = T[q] * inv1ma;
           const float dchannel_dcolor = alpha * T[q];
           // dL_dalpha = sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch] (backward.cu:590-600) only ever uses the
@@ -365,22 +397,22 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           // recurrence as the colour itself (it is linear): keep the one scalar per pixel instead of four channels
           float cg = fmaf(colB.x, gB[q].x, fmaf(colA.y, gA[q].y, colA.x * gA[q].x));
           if (HASDEPTH) cg = fmaf(colB.y, gB[q].y, cg);
-          float dL_dalpha = cg - accg[q];
+          const float behind = cg - accg[q];
+          // acc <- alpha c + (1 - alpha) acc in its lerp form: reuses cg - acc (the identity for alpha = 0)
+          accg[q] = fmaf(alpha, behind, accg[q]);
+          const float wgt = au * (behind * T[q]);  // au == 0 for a skipped pair
+          const float wx = wgt * dx, wy = wgt * dy;
           // (scalar FMAs: a packed v_pk_fma_f32 was measured slower than the two scalar ones it replaces)
           sA.x = fmaf(gA[q].x, dchannel_dcolor, sA.x);
           sA.y = fmaf(gA[q].y, dchannel_dcolor, sA.y);
           sB.x = fmaf(gB[q].x, dchannel_dcolor, sB.x);
           if (HASDEPTH) sB.y = fmaf(gB[q].y, dchannel_dcolor, sB.y);
-          accg[q] = cg * alpha + accg[q] * oma;
-          dL_dalpha *= T[q];
-          const float wgt = au * dL_dalpha;  // au == 0 for a skipped pair
-          const float wx = wgt * dx, wy = wgt * dy;
           S_w += wgt;
           S_wx += wx;
           S_wy += wy;
-          S_xx += wx * dx;
-          S_xy += wx * dy;
-          S_yy += wy * dy;
+          S_xx = fmaf(wx, dx, S_xx);
+          S_xy = fmaf(wx, dy, S_xy);
+          S_yy = fmaf(wy, dy, S_yy);
         }
       }
       {  // (every dup that reaches here passed the quadrant test for >= 1 quadrant; 98 % of those passes contribute)
@@ -401,6 +433,11 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         if (wslot >= 0) reinterpret_cast<float*>(&s_acc[w][0][0])[j * DGS_CONTRIB_F + wslot] = tot;
       }
     }
+    };
+    if ((~pdm & mu_all) == 0ull)
+      run_batch(std::false_type{});
+    else
+      run_batch(std::true_type{});
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -426,8 +463,12 @@ hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const f
                                     float* out_depth, hipStream_t s) {
   const uint32_t per = per_xcd_blocks(v);
   if (per == 0) return hipSuccess;
-  hipLaunchKernelGGL(composite_fwd_kernel, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
-                     c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth);
+  if (out_depth != nullptr)
+    hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
+                       c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth);
+  else
+    hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
+                       c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth);
   return hipGetLastError();
 }
 

@@ -214,7 +214,7 @@ hipError_t dgs_launch_mark_visible(int P, const float* means3D, const float* vie
 hipError_t dgs_launch_cloud_activations(int P, const float* scales, const float* rotations, const float* opacities,
                                         float scale_lb, float* out_scales, float* out_rotations, float* out_opacities,
                                         hipStream_t s);
-hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, hipStream_t s);
+hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, uint32_t* drops, hipStream_t s);
 hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s,
                              const uint32_t* n_dev = nullptr, int tile_shift = 32);
 hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, uint32_t* total,
@@ -233,9 +233,10 @@ hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const f
 hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const float* bg, const float* dL_dpix,
                                     const float* dL_ddepth, float* contrib, hipStream_t s);
 hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const DgsCarve& c, const DgsBackwardIO& io,
-                                   const float* contrib, float* sums, float* partials, hipStream_t s);
+                                   const float* contrib, float* sums, double* partials, hipStream_t s);
 hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t,
-                                const float* scale, float* blur, float* dsub, float* losses, hipStream_t s);
+                                const float* lambda_dev, const float* scale, float* blur, float* dsub, float* losses,
+                                hipStream_t s);
 
 hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
                                  uint32_t P, uint32_t* tmp, const uint32_t* gather_src, uint32_t* gather_dst,

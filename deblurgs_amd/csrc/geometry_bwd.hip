@@ -55,6 +55,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // duplicates were laid out in ((k, depth, index): consecutive quads read consecutive row segments).
 // The geometry kernel then reads its totals with coalesced, independent loads -- no duplicate offset to chase, and the
 // emit pass of the forward no longer stores one.  A visible pair whose every tile was culled gets zeros.
+// (Round 3 tried a streaming variant -- a wave owns 64 consecutive pairs and pulls their contiguous row span through LDS
+// with fully coalesced 1 KB loads -- and measured the same time, 0.82 vs 0.80 ms: the kernel is bound by the 11.8 M
+// scattered 48-byte WRITES of the totals to their natural index, not by how the rows are read.)
 __global__ void __launch_bounds__(256)
 contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ status, const uint32_t* __restrict__ order,
                       const uint32_t* __restrict__ tt_visible, const uint32_t* __restrict__ tiles,
@@ -122,7 +125,7 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
                     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dsh, float* __restrict__ dL_dsh_rest,
                     float* __restrict__ dL_dcolors,
                     float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales, float* __restrict__ dL_drots,
-                    float* __restrict__ dL_dcov3D_out, float* __restrict__ partials) {
+                    float* __restrict__ dL_dcov3D_out, double* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float s_part[];  // [waves][K][NMAT]
   if (status[5] != 0u) return;  // capacity mode, truncated lists (see contrib_reduce_kernel); the caller discards the step
   const int idx = blockIdx.x * GB_THREADS + threadIdx.x;
@@ -550,13 +553,16 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     }
   }
 
-  // ---- combine the 4 waves in wave order and publish this block's partial pose gradients
+  // ---- combine the 4 waves in wave order and publish this block's partial pose gradients.  Beyond the wave sums
+  // everything is added in double: dL_dview is a sum of ~10^6 signed terms that cancel to a small total, and fp32
+  // partial sums of growing magnitude would put an error of several 1e-4 of the result on it (the reference's float
+  // atomics do; the parity tests compare with a double-accumulating oracle)
   __syncthreads();
   const int total = v.K * NMAT;
   for (int i = threadIdx.x; i < total; i += GB_THREADS) {
-    float acc = 0.0f;
+    double acc = 0.0;
 #pragma unroll
-    for (int ww = 0; ww < GB_THREADS / 64; ww++) acc += s_part[(size_t)ww * total + i];
+    for (int ww = 0; ww < GB_THREADS / 64; ww++) acc += (double)s_part[(size_t)ww * total + i];
     partials[(size_t)blockIdx.x * total + i] = acc;
   }
 }
@@ -565,16 +571,16 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
 // blocks t, t+256, ... in order for all 21 values at once (one 84-byte row per block), then a fixed-shape tree
 // over the 256 threads combines them.
 __global__ void __launch_bounds__(256)
-pose_grad_reduce_kernel(int K, int nblocks, const float* __restrict__ partials, float* __restrict__ dL_dview,
+pose_grad_reduce_kernel(int K, int nblocks, const double* __restrict__ partials, float* __restrict__ dL_dview,
                         float* __restrict__ dL_dproj) {
-  __shared__ float red[256][21 + 1];
+  __shared__ double red[256][21 + 1];
   const int k = blockIdx.x;
   const size_t stride = (size_t)K * NMAT;
-  float acc[21];
+  double acc[21];
 #pragma unroll
-  for (int i = 0; i < 21; i++) acc[i] = 0.0f;
+  for (int i = 0; i < 21; i++) acc[i] = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 256) {
-    const float* p = partials + (size_t)b * stride + (size_t)k * NMAT;
+    const double* p = partials + (size_t)b * stride + (size_t)k * NMAT;
 #pragma unroll
     for (int i = 0; i < 21; i++) acc[i] += p[i];
   }
@@ -599,7 +605,7 @@ pose_grad_reduce_kernel(int K, int nblocks, const float* __restrict__ partials, 
       if (c < 2) src = 12 + r * 2 + c;  // proj[4r+c], c in {0,1}
       if (c == 3) src = 20;             // proj[3], [7], [11], [15]
     }
-    const float v = src >= 0 ? red[0][src] : 0.0f;
+    const float v = src >= 0 ? (float)red[0][src] : 0.0f;
     if (i < 16)
       dL_dview[16 * k + i] = v;
     else
@@ -612,7 +618,7 @@ pose_grad_reduce_kernel(int K, int nblocks, const float* __restrict__ partials, 
 int dgs_geometry_bwd_blocks(int P) { return (P + GB_THREADS - 1) / GB_THREADS; }
 
 hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const DgsCarve& c, const DgsBackwardIO& io,
-                                   const float* contrib, float* sums, float* partials, hipStream_t s) {
+                                   const float* contrib, float* sums, double* partials, hipStream_t s) {
   const int blocks = dgs_geometry_bwd_blocks(v.P);
   const size_t lds = (size_t)(GB_THREADS / 64) * v.K * NMAT * sizeof(float);
   const int ncoef = (p.shs != nullptr) ? (v.D + 1) * (v.D + 1) : 1;

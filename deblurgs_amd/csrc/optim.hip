@@ -21,21 +21,24 @@ struct AdamArgs {
   float neg_step_size[DGS_ADAM_MAX_GROUPS];  // -(lr / (1 - beta1^step))
   float bc2_sqrt[DGS_ADAM_MAX_GROUPS];       // sqrt(1 - beta2^step)
   uint8_t vec4[DGS_ADAM_MAX_GROUPS];         // all four pointers 16-byte aligned: float4 accesses
+  uint8_t slot[DGS_ADAM_MAX_GROUPS];         // index of the group in the caller's array (dev_scalars is laid out by it)
   int n;
   float beta2, w1, w2, eps, clip;  // w1 = 1 - beta1, w2 = 1 - beta2
   const uint32_t* skip;            // optional device word: non-zero = leave everything untouched
+  const float* dev_scalars;        // optional [2 n]: (neg_step_size, bc2_sqrt) per group read from device memory
 };
 
 constexpr int ADAM_THREADS = 256;
 constexpr int ADAM_PER_BLOCK = ADAM_THREADS * 4;
 
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, int gi) {
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float neg_step_size,
+                                         float bc2_sqrt) {
   if (a.clip > 0.0f) g = fminf(a.clip, fmaxf(-a.clip, g));   // clip_grad_value_ (train.py:204-205)
   m = m + a.w1 * (g - m);                                     // exp_avg.lerp_(grad, 1 - beta1)
   v = v * a.beta2;                                            // exp_avg_sq.mul_(beta2)
   v = v + (a.w2 * g) * g;                                     //   .addcmul_(grad, grad, value = 1 - beta2)
-  const float denom = sqrtf(v) / a.bc2_sqrt[gi] + a.eps;      // (exp_avg_sq.sqrt() / sqrt(bc2)).add_(eps)
-  p = p + a.neg_step_size[gi] * (m / denom);                  // param.addcdiv_(exp_avg, denom, value = -step_size)
+  const float denom = sqrtf(v) / bc2_sqrt + a.eps;            // (exp_avg_sq.sqrt() / sqrt(bc2)).add_(eps)
+  p = p + neg_step_size * (m / denom);                        // param.addcdiv_(exp_avg, denom, value = -step_size)
 }
 
 __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(AdamArgs a) {
@@ -48,6 +51,10 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(AdamArgs a) {
   const uint64_t base = (uint64_t)(blockIdx.x - first) * ADAM_PER_BLOCK + (uint64_t)threadIdx.x * 4;
   const uint64_t n = a.numel[gi];
   if (base >= n) return;
+  // graph replay: this step's bias-corrected step size and sqrt(1 - beta2^t) come from device memory (the host wrote
+  // them, computed exactly as below in dgs_adam_step, before launching the graph)
+  const float nss = a.dev_scalars != nullptr ? a.dev_scalars[2 * a.slot[gi]] : a.neg_step_size[gi];
+  const float bcs = a.dev_scalars != nullptr ? a.dev_scalars[2 * a.slot[gi] + 1] : a.bc2_sqrt[gi];
   float* p = a.param[gi] + base;
   const float* g = a.grad[gi] + base;
   float* m = a.m[gi] + base;
@@ -57,17 +64,17 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_kernel(AdamArgs a) {
     const float4 G4 = *reinterpret_cast<const float4*>(g);
     float4 M4 = *reinterpret_cast<float4*>(m);
     float4 V4 = *reinterpret_cast<float4*>(v);
-    adam_one(P4.x, G4.x, M4.x, V4.x, a, gi);
-    adam_one(P4.y, G4.y, M4.y, V4.y, a, gi);
-    adam_one(P4.z, G4.z, M4.z, V4.z, a, gi);
-    adam_one(P4.w, G4.w, M4.w, V4.w, a, gi);
+    adam_one(P4.x, G4.x, M4.x, V4.x, a, nss, bcs);
+    adam_one(P4.y, G4.y, M4.y, V4.y, a, nss, bcs);
+    adam_one(P4.z, G4.z, M4.z, V4.z, a, nss, bcs);
+    adam_one(P4.w, G4.w, M4.w, V4.w, a, nss, bcs);
     *reinterpret_cast<float4*>(p) = P4;
     *reinterpret_cast<float4*>(m) = M4;
     *reinterpret_cast<float4*>(v) = V4;
   } else {
     for (int i = 0; i < 4 && base + i < n; i++) {
       float pp = p[i], mm = m[i], vv = v[i];
-      adam_one(pp, g[i], mm, vv, a, gi);
+      adam_one(pp, g[i], mm, vv, a, nss, bcs);
       p[i] = pp;
       m[i] = mm;
       v[i] = vv;
@@ -189,8 +196,16 @@ extern int dgs_fail_hip(hipError_t e, const char* where);
 
 extern "C" {
 
-int dgs_adam_step(const DgsAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps,
-                  double clip_value, const uint32_t* skip_flag, dgs_stream_t stream) {
+static void adam_scalars_of(const DgsAdamGroup& g, double beta1, double beta2, float* neg_step_size, float* bc2_sqrt) {
+  // torch/optim/adam.py (_single_tensor_adam): python-float bias corrections, cast to fp32 at the tensor op
+  const double bc1 = 1.0 - pow(beta1, (double)g.step);
+  const double bc2 = 1.0 - pow(beta2, (double)g.step);
+  *neg_step_size = (float)(-(g.lr / bc1));
+  *bc2_sqrt = (float)sqrt(bc2);
+}
+
+static int adam_step_impl(const DgsAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps,
+                          double clip_value, const uint32_t* skip_flag, const float* dev_scalars, dgs_stream_t stream) {
   if (n_groups < 0 || n_groups > DGS_ADAM_MAX_GROUPS || (n_groups > 0 && groups == nullptr))
     return dgs_fail_arg("adam_step: 0..DGS_ADAM_MAX_GROUPS groups");
   AdamArgs a;
@@ -211,18 +226,17 @@ int dgs_adam_step(const DgsAdamGroup* groups, int32_t n_groups, double beta1, do
     blocks += (g.numel + ADAM_PER_BLOCK - 1) / ADAM_PER_BLOCK;
     if (blocks >= (1ull << 31)) return dgs_fail_arg("adam_step: too many elements for one launch");
     a.block_end[j] = (uint32_t)blocks;
-    // torch/optim/adam.py (_single_tensor_adam): python-float bias corrections, cast to fp32 at the tensor op
-    const double bc1 = 1.0 - pow(beta1, (double)g.step);
-    const double bc2 = 1.0 - pow(beta2, (double)g.step);
-    a.neg_step_size[j] = (float)(-(g.lr / bc1));
-    a.bc2_sqrt[j] = (float)sqrt(bc2);
+    a.slot[j] = (uint8_t)i;
+    adam_scalars_of(g, beta1, beta2, &a.neg_step_size[j], &a.bc2_sqrt[j]);
   }
   if (a.n == 0) return DGS_OK;
   for (int j = a.n; j < DGS_ADAM_MAX_GROUPS; j++) {
     a.param[j] = nullptr; a.grad[j] = nullptr; a.m[j] = nullptr; a.v[j] = nullptr;
     a.numel[j] = 0; a.block_end[j] = (uint32_t)blocks; a.neg_step_size[j] = 0.0f; a.bc2_sqrt[j] = 1.0f;
     a.vec4[j] = 0;
+    a.slot[j] = 0;
   }
+  a.dev_scalars = dev_scalars;
   a.beta2 = (float)beta2;
   a.w1 = (float)(1.0 - beta1);
   a.w2 = (float)(1.0 - beta2);
@@ -232,6 +246,25 @@ int dgs_adam_step(const DgsAdamGroup* groups, int32_t n_groups, double beta1, do
   hipLaunchKernelGGL(adam_kernel, dim3((uint32_t)blocks), dim3(ADAM_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? DGS_OK : dgs_fail_hip(e, "adam_step");
+}
+
+int dgs_adam_step(const DgsAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps,
+                  double clip_value, const uint32_t* skip_flag, dgs_stream_t stream) {
+  return adam_step_impl(groups, n_groups, beta1, beta2, eps, clip_value, skip_flag, nullptr, stream);
+}
+int dgs_adam_step_dev(const DgsAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps,
+                      double clip_value, const uint32_t* skip_flag, const float* dev_scalars, dgs_stream_t stream) {
+  if (dev_scalars == nullptr) return dgs_fail_arg("adam_step_dev: dev_scalars is null");
+  return adam_step_impl(groups, n_groups, beta1, beta2, eps, clip_value, skip_flag, dev_scalars, stream);
+}
+int dgs_adam_scalars(const DgsAdamGroup* groups, int32_t n_groups, double beta1, double beta2, float* out) {
+  if (n_groups < 0 || n_groups > DGS_ADAM_MAX_GROUPS || (n_groups > 0 && (groups == nullptr || out == nullptr)))
+    return dgs_fail_arg("adam_scalars: bad argument");
+  for (int i = 0; i < n_groups; i++) {
+    if (groups[i].step < 1) return dgs_fail_arg("adam_scalars: step < 1");
+    adam_scalars_of(groups[i], beta1, beta2, &out[2 * i], &out[2 * i + 1]);
+  }
+  return DGS_OK;
 }
 
 size_t dgs_densify_tmp_bytes(int32_t P) { return dgs_scan_tmp_words((uint64_t)(P < 0 ? 0 : P)) * 4 + 256; }

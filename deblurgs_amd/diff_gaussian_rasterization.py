@@ -63,7 +63,7 @@ _pinned = {}
 def _pinned_word(device):
     key = (device.type, device.index)
     if key not in _pinned:
-        _pinned[key] = torch.zeros(4, dtype=torch.int32).pin_memory()
+        _pinned[key] = torch.zeros(8, dtype=torch.int32).pin_memory()
     return _pinned[key]
 
 

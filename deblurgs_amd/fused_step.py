@@ -43,7 +43,7 @@ def _ptr(t, offset_elems=0):
 
 
 class _Pending:
-    __slots__ = ("host", "event", "capacity", "speculative", "key", "generation", "request")
+    __slots__ = ("host", "event", "capacity", "speculative", "key", "generation", "request", "shared_host")
 
 
 class FusedStep:
@@ -62,6 +62,14 @@ class FusedStep:
         self._free_hosts = []
         self._keep = None           # buffers of the last step (the skip flag lives in its geometry blob)
         self.last_capacity = None
+        self._sel_cache = {}
+        self._drops_dev = None      # device word: forwards that overflowed so far (DgsForwardOut.drop_counter)
+        self._graphs = {}           # captured steps by what they bake in (replay)
+        self._pool = None           # one memory pool for all of them: replays never overlap
+        self._ring, self._ring_pos = [], 0
+        self.max_graphs = 256
+        self.captured = 0
+        self.replayed = 0
 
     # ------------------------------------------------------------------------------------------ capacity policy
     def _poll(self, block=False):
@@ -78,7 +86,8 @@ class FusedStep:
                     self.retry.append(pnd.request)
                 if pnd.generation == self._generation:
                     self._seen[pnd.key] = (self._seen.get(pnd.key, []) + [R])[-4:]
-                self._free_hosts.append(pnd.host)
+                if not getattr(pnd, "shared_host", False):     # (a captured step's count words belong to its graph)
+                    self._free_hosts.append(pnd.host)
             else:
                 still.append(pnd)
         self._pending = still
@@ -95,13 +104,14 @@ class FusedStep:
         on their way back -- so that every view takes the exact path once."""
         self._generation += 1
         self._seen = {}
+        self._graphs = {}
 
     def _host_words(self):
         if self._free_hosts:
             h = self._free_hosts.pop()
             h.zero_()
             return h
-        return torch.zeros(4, dtype=torch.int32).pin_memory()
+        return torch.zeros(8, dtype=torch.int32).pin_memory()
 
     def _empty_slice(self, gt, lambda_t, K_total, P, H, W, ct_all, cr_all, nu_raw, need_blur, lambda_depth_tv=0.0):
         """"subframes" sharding with more ranks than subframes: this rank rasterises nothing but takes part in the loss
@@ -129,10 +139,122 @@ class FusedStep:
                 "K": K_total, "subframes": color, "depths": torch.zeros((0, 1, H, W), **f32), "skip_flag_ptr": None,
                 "depth_tv": depth_tv}
 
+    def _linspace_sel(self, f, n, dev):
+        key = (f, n, str(dev))
+        if key not in self._sel_cache:
+            self._sel_cache[key] = torch.linspace(0, f - 1, n, device=dev).long()
+        return self._sel_cache[key]
+
+    def _drop_counter(self, dev):
+        if self._drops_dev is None:
+            self._drops_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        return self._drops_dev
+
+    # ------------------------------------------------------------------------------------------ captured replay
+    HYPER_FLOATS = 64        # [0] lambda_t, [1:4] background, [8:8 + 2 * 16] Adam scalars, [48:] alignment jitter (f <= 16)
+
+    def _hyper_words(self, f):
+        return max(self.HYPER_FLOATS, 48 + f)
+
+    def replay(self, cam_idx, lambda_t, gt, subframe_indice, optimizer, tail, signature=(), background=None):
+        """One training iteration as ONE hipGraph launch (SURVEY 8f / DESIGN 2b): alignment -> cameras -> dgs_forward
+        (capacity sized ahead) -> loss -> dgs_backward -> camera gradients -> `tail` (densification statistics + the
+        optimiser launch).  At DeblurGS's real scene sizes a step is ~60 kernels of a few microseconds each; replayed
+        from a graph they cost one launch instead of ~20 ctypes calls and their driver round trips.
+
+        What changes from step to step travels through one small device block written before the launch: lambda_t, the
+        random background, the alignment jitter and Adam's step-size scalars (optimizer.step_scalars).  Everything else
+        -- the view, the subframe selection, the active SH degree, which parameters are optimised, the capacity of the
+        duplicate arrays, every buffer address -- is baked into the graph: one graph per distinct combination, captured
+        the first time it is needed (and re-captured when the cloud is rebuilt or a capacity grows).
+
+        Returns the result dict of run(), or None when this step cannot be replayed yet (no duplicate count learnt for
+        the view: the caller runs the eager step, which learns it)."""
+        cloud, m = self.cloud, self.motion
+        dev = cloud._xyz.device
+        f = m.n_subframes
+        self._poll()
+        K_total = f if (isinstance(subframe_indice, str) and subframe_indice == "all") else (
+            int(subframe_indice) if isinstance(subframe_indice, int) else len(subframe_indice))
+        ckey = (int(cam_idx), K_total, 0)
+        cap = self._capacity(ckey) if self.speculative else None
+        if cap is None or isinstance(subframe_indice, (list, tuple)) or torch.is_tensor(subframe_indice):
+            return None
+        cap = -(-cap // (1 << 18)) << 18      # quantised: small count drifts do not force a re-capture
+        hot = list(cloud.hot_parameters())
+        gkey = (int(cam_idx), subframe_indice, int(cloud.active_sh_degree), bool(m.is_optimizing()),
+                bool(m.curve_random_sample), cap, self._generation, gt.data_ptr(),
+                tuple(p.data_ptr() for p in hot), tuple(signature))
+        ent = self._graphs.get(gkey)
+        if ent is None:
+            ent = self._capture(gkey, cam_idx, gt, subframe_indice, cap, optimizer, tail)
+        # ---- this step's scalars: host block -> device block (the ring keeps a block alive until its copy has run)
+        slot = self._ring[self._ring_pos % len(self._ring)] if self._ring else None
+        if slot is None or slot[0].numel() != ent["hyper"].numel():
+            self._ring = [(torch.zeros(ent["hyper"].numel(), dtype=torch.float32).pin_memory(), torch.cuda.Event())
+                          for _ in range(8)]
+            self._ring_pos = 0
+            slot = self._ring[0]
+        self._ring_pos += 1
+        hbuf, hev = slot
+        hev.synchronize()                      # (recorded 8 replays ago: never waits in practice)
+        hv = hbuf.numpy()
+        hv[0] = float(lambda_t)
+        hv[1:4] = (torch.rand(3) if background is None else background.detach().float().cpu()).numpy()   # motion.py:112-113
+        if m.curve_random_sample and f > 2:
+            hv[48:48 + f - 2] = torch.rand(f - 2).numpy()                 # scene/motion.py:213-214
+        for p, g in ent["grads"]:              # the step's gradients live in the graph's buffers
+            p.grad = g
+        optimizer.skip_flag_ptr = ent["result"]["skip_flag_ptr"]
+        optimizer.step_scalars(hv[8:8 + 2 * _lib.ADAM_MAX_GROUPS])
+        ent["hyper"].copy_(hbuf, non_blocking=True)
+        hev.record(torch.cuda.current_stream(dev))
+        ent["graph"].replay()
+        pnd = _Pending()
+        pnd.host, pnd.speculative, pnd.key, pnd.generation = ent["host"], True, ckey, self._generation
+        pnd.request, pnd.capacity = (cam_idx, subframe_indice), cap
+        pnd.event = torch.cuda.Event()
+        pnd.event.record(torch.cuda.current_stream(dev))
+        pnd.shared_host = True
+        self._pending.append(pnd)
+        self.last_capacity = cap
+        self.replayed += 1
+        return ent["result"]
+
+    def _capture(self, gkey, cam_idx, gt, subframe_indice, cap, optimizer, tail):
+        cloud, m = self.cloud, self.motion
+        dev = cloud._xyz.device
+        f = m.n_subframes
+        if len(self._graphs) >= self.max_graphs:      # (views x subframe selections of one run; bounded all the same)
+            self._graphs.pop(next(iter(self._graphs)))
+        hyper = torch.zeros(self._hyper_words(f), dtype=torch.float32, device=dev)
+        host = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self._drop_counter(dev)
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        ent = {"hyper": hyper, "host": host}
+        cap_args = {"capacity": cap, "host": host, "lambda_ptr": hyper.data_ptr(),
+                    "tail": (lambda fr: tail(fr, hyper.data_ptr() + 4 * 8)) if tail is not None else None}
+        bg = hyper[1:4]
+        uniform = hyper[48:48 + f - 2] if (m.curve_random_sample and f > 2) else None
+        params = list(cloud.hot_parameters()) + (list(m.parameters()) if m.is_optimizing() else [])
+        optimizer.ensure_state(params)
+        for p in params:
+            p.grad = None
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
+            fr = self.run(cam_idx, 0.0, gt, bg, subframe_indice, uniform=uniform, _cap=cap_args)
+        ent["graph"], ent["result"] = graph, fr
+        ent["grads"] = [(p, p.grad) for p in params if p.grad is not None]
+        self._graphs[gkey] = ent
+        self.captured += 1
+        return ent
+
     # ------------------------------------------------------------------------------------------------- the step
     @torch.no_grad()
     def run(self, cam_idx, lambda_t, gt, background, subframe_indice="all", need_blur=False, uniform=None,
-            lambda_depth_tv=0.0, shard=None, exact=False):
+            lambda_depth_tv=0.0, shard=None, exact=False, need_depth=False, _cap=None):
         """gt: [3,H,W] ground truth of view cam_idx (already tone-mapped / noised by the caller); background: [3].
         lambda_depth_tv > 0 adds the reference's optional depth-smoothness term (train.py:150-153,
         utils/loss_utils.py:66-78): its gradient on the K depth images is formed with a few torch ops and handed to the
@@ -143,6 +265,10 @@ class FusedStep:
         gradients are this rank's PARTIAL sums (the caller adds them over the ranks; the opacity hinge is added on rank 0
         only); 'radii' / 'viewspace_grad' / 'subframes' hold the local slice, 'K' the view's subframe count.
         exact=True forces the two-phase forward (one host read) whatever has been learnt.
+        need_depth=True renders the K depth images too ('depths'; implied by lambda_depth_tv > 0), else 'depths' is None.
+        _cap: internal, set by replay() while the step is being CAPTURED into a hipGraph -- the capacity, the pinned count
+        words, the device words lambda_t is read from and the tail (statistics + optimiser launch) to enqueue; no host
+        bookkeeping happens then.
         Returns a dict: 'losses' (device float32 [2]: L1(blur, gt), smoothness -- no host read), 'blur' ([3,H,W] if
         need_blur), 'radii' [K,P] int32, 'viewspace_grad' [K,P,3], 'K', 'skip_flag_ptr' (int or None)."""
         L = _lib.lib()
@@ -162,6 +288,8 @@ class FusedStep:
         raw_ptr = _ptr(nu_raw, cam * nrow) if nrow > 0 else None
         if uniform is None and m.curve_random_sample and nrow > 0:
             uniform = torch.rand(nrow, **f32)
+        if not m.curve_random_sample:
+            uniform = None
         _lib.check(L.dgs_alignment_forward(raw_ptr, _ptr(uniform), f, f, _ptr(nu_all), _ptr(src), stream),
                    "dgs_alignment_forward")
         sel = None
@@ -169,7 +297,7 @@ class FusedStep:
             nu = nu_all
         else:
             if isinstance(subframe_indice, int):     # scene/motion.py:129-131 (1 selects index 0)
-                sel = torch.linspace(0, f - 1, subframe_indice, device=dev).long()
+                sel = self._linspace_sel(f, subframe_indice, dev)
             else:
                 sel = torch.as_tensor(subframe_indice, device=dev).long()
             nu = nu_all[sel].contiguous()
@@ -203,7 +331,9 @@ class FusedStep:
         rest = cloud._features_rest if cloud._features_rest.shape[1] > 0 else None
         Mr = 0 if rest is None else rest.shape[1]
         color = torch.empty((K, 3, H, W), **f32)
-        depth = torch.empty((K, 1, H, W), **f32)
+        # the depth images are rendered only if somebody reads them (the reference always renders them, and its default
+        # loss, lambda_depth_tv = 0, never looks at them: train.py:150-153)
+        depth = torch.empty((K, 1, H, W), **f32) if (need_depth or lambda_depth_tv > 0.0) else None
         radii = torch.empty((K, P), dtype=torch.int32, device=dev)
         geom = torch.empty(L.dgs_geom_state_bytes(P, K), dtype=torch.uint8, device=dev)
         image = torch.empty(L.dgs_image_state_bytes(W, H, K), dtype=torch.uint8, device=dev)
@@ -223,15 +353,18 @@ class FusedStep:
         prob.image_state, prob.image_bytes = ctypes.c_void_p(image.data_ptr()), image.numel()
         out = _lib.DgsForwardOut()
         out.out_color, out.out_depth, out.radii = _ptr(color), _ptr(depth), ctypes.c_void_p(radii.data_ptr())
-        host = self._host_words()
-        out.num_rendered_host = ctypes.c_void_p(host.data_ptr())
-
-        self._poll()
         key = (cam, K_total, k0)
-        cap = self._capacity(key) if (self.speculative and not exact) else None
-        pnd = _Pending()
-        pnd.host, pnd.speculative, pnd.key, pnd.generation = host, cap is not None, key, self._generation
-        pnd.request = (cam_idx, subframe_indice)
+        if _cap is None:
+            host = self._host_words()
+            self._poll()
+            cap = self._capacity(key) if (self.speculative and not exact) else None
+            pnd = _Pending()
+            pnd.host, pnd.speculative, pnd.key, pnd.generation = host, cap is not None, key, self._generation
+            pnd.request = (cam_idx, subframe_indice)
+        else:
+            host, cap, pnd = _cap["host"], int(_cap["capacity"]), None
+            out.drop_counter = ctypes.c_void_p(self._drop_counter(dev).data_ptr())
+        out.num_rendered_host = ctypes.c_void_p(host.data_ptr())
         if cap is not None:
             binning = torch.empty(L.dgs_binning_state_bytes(cap, W, H, K), dtype=torch.uint8, device=dev)
             prob.binning_state, prob.binning_bytes = ctypes.c_void_p(binning.data_ptr()), binning.numel()
@@ -248,10 +381,11 @@ class FusedStep:
             prob.binning_state, prob.binning_bytes = ctypes.c_void_p(binning.data_ptr()), binning.numel()
             _lib.check(L.dgs_forward_render(ctypes.byref(prob), ctypes.byref(out), R, stream), "dgs_forward_render")
             skip_ptr = None
-        pnd.capacity = R
-        pnd.event = torch.cuda.Event()
-        pnd.event.record(stream_obj)
-        self._pending.append(pnd)
+        if pnd is not None:
+            pnd.capacity = R
+            pnd.event = torch.cuda.Event()
+            pnd.event.record(stream_obj)
+            self._pending.append(pnd)
         self.last_capacity = R
 
         # ---- loss: blur, both values and dL/dsubframes in one pass (train.py:143-165 image terms)
@@ -260,7 +394,11 @@ class FusedStep:
         dsub = torch.empty((K, 3, H, W), **f32)
         work = torch.empty(8, **f32)          # dgs_blur_loss_grad's work area: [l1, smooth | accumulators, counter]
         losses = work[:2]
-        if shard is None:
+        if _cap is not None:      # the scheduled weight is read from device memory when the replayed kernel runs
+            _lib.check(L.dgs_blur_loss_grad_dev(_ptr(color), _ptr(gtc), K, 3, H * W, ctypes.c_void_p(_cap["lambda_ptr"]),
+                                                None, _ptr(blur), _ptr(dsub), _ptr(work), stream),
+                       "dgs_blur_loss_grad_dev")
+        elif shard is None:
             _lib.check(L.dgs_blur_loss_grad(_ptr(color), _ptr(gtc), K, 3, H * W, float(lambda_t), None, _ptr(blur),
                                             _ptr(dsub), _ptr(work), stream), "dgs_blur_loss_grad")
         else:   # the loss block across the ranks holding the view's other subframes
@@ -340,5 +478,11 @@ class FusedStep:
                                                     _ptr(d_raw_all, cam * nrow), stream), "dgs_alignment_backward")
                 m._nu.grad = d_raw_all
         self._keep = (geom, image, binning, scratch, color, depth, dsub, view, full, campos, nu, gtc, bg, flat, g_depth)
-        return {"losses": losses, "blur": blur if need_blur else None, "radii": radii, "viewspace_grad": g_means2D,
-                "K": K_total, "subframes": color, "depths": depth, "skip_flag_ptr": skip_ptr, "depth_tv": depth_tv}
+        fr = {"losses": losses, "blur": blur if need_blur else None, "radii": radii, "viewspace_grad": g_means2D,
+              "K": K_total, "subframes": color, "depths": depth, "skip_flag_ptr": skip_ptr, "depth_tv": depth_tv}
+        if _cap is not None:
+            fr["_keep"] = self._keep + (nu_all, src, proj, work, blur, g_colors, g_cov3D, g_view, g_proj, radii,
+                                        g_means2D, sel, uniform)
+            if _cap.get("tail") is not None:
+                _cap["tail"](fr)
+        return fr

@@ -91,6 +91,86 @@ class FusedAdam(torch.optim.Optimizer):
                                            _stream(device)), "dgs_adam_step")
         return loss
 
+    # ---- captured (hipGraph) steps: the launch is recorded once, the per-step scalars travel through device memory
+    def _active(self):
+        """[(group, param)] that step() would update now, in launch order; one (beta1, beta2, eps) for all of them."""
+        act, hyper = [], None
+        for group in self.param_groups:
+            self._check_group(group)
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                h = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]))
+                if hyper is not None and h != hyper:
+                    raise RuntimeError("captured FusedAdam steps need one (betas, eps) for all groups")
+                hyper = h
+                act.append((group, p))
+        if len(act) > _lib.ADAM_MAX_GROUPS:
+            raise RuntimeError("captured FusedAdam steps support at most ADAM_MAX_GROUPS parameters")
+        return act, hyper
+
+    def _groups_array(self, act, bump):
+        gs = []
+        for group, p in act:
+            state = self.state[p]
+            if len(state) == 0:
+                state["step"] = torch.tensor(0.0)
+                state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if bump:
+                state["step"] += 1
+            gs.append(_lib.DgsAdamGroup(p.data_ptr(), p.grad.data_ptr(), state["exp_avg"].data_ptr(),
+                                        state["exp_avg_sq"].data_ptr(), p.numel(), float(group["lr"]),
+                                        max(int(state["step"].item()), 1)))
+        return (_lib.DgsAdamGroup * len(gs))(*gs)
+
+    @torch.no_grad()
+    def ensure_state(self, params):
+        """Creates the Adam moments of `params` now (a captured step must not allocate them inside its graph)."""
+        for p in params:
+            state = self.state[p]
+            if len(state) == 0:
+                state["step"] = torch.tensor(0.0)
+                state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    @torch.no_grad()
+    def signature(self):
+        """What a captured step bakes in: which tensors are updated, through which buffers."""
+        act, hyper = self._active()
+        sig = [hyper, self.clip_value]
+        for _, p in act:
+            st = self.state.get(p, {})
+            sig.append((p.data_ptr(), p.grad.data_ptr(), p.numel(),
+                        st["exp_avg"].data_ptr() if "exp_avg" in st else 0))
+        return tuple(sig)
+
+    @torch.no_grad()
+    def step_scalars(self, out):
+        """Host half of a captured step: counts the step (state["step"] += 1) and writes this step's
+        (-(lr / (1 - beta1^t)), sqrt(1 - beta2^t)) per active parameter into `out` (float32 numpy view, 2 per
+        parameter, dgs_adam_scalars) for the caller to copy into the device block the captured kernel reads."""
+        import numpy as np
+        act, hyper = self._active()
+        arr = self._groups_array(act, bump=True)
+        tmp = (ctypes.c_float * (2 * len(act)))()
+        _lib.check(_lib.lib().dgs_adam_scalars(arr, len(act), hyper[0], hyper[1], tmp), "dgs_adam_scalars")
+        out[:2 * len(act)] = np.frombuffer(tmp, dtype=np.float32)
+        return len(act)
+
+    @torch.no_grad()
+    def step_enqueue(self, dev_scalars_ptr):
+        """Device half: enqueues the update with the scalars read from device memory (capturable; does not count the
+        step -- step_scalars does, once per replay)."""
+        act, hyper = self._active()
+        if not act:
+            return
+        arr = self._groups_array(act, bump=False)
+        _lib.check(_lib.lib().dgs_adam_step_dev(arr, len(act), hyper[0], hyper[1], hyper[2], self.clip_value,
+                                                ctypes.c_void_p(self.skip_flag_ptr) if self.skip_flag_ptr else None,
+                                                ctypes.c_void_p(dev_scalars_ptr), _stream(act[0][1].device)),
+                   "dgs_adam_step_dev")
+
 
 _pinned_counts = {}
 

@@ -28,7 +28,7 @@ def default_optimization_params(**overrides):
 
 class TrainingLoop:
     def __init__(self, gaussians, cam_motion_module, opt, cameras_extent, white_background=False, spatial_lr_scale=None,
-                 distributed=False, tone_mapping=None, fused_step="auto", speculative=True, log_losses=True):
+                 distributed=False, tone_mapping=None, fused_step="auto", speculative=True, log_losses=True, graph="auto"):
         """distributed = "views" (or True): every rank steps on its own view (the caller passes each rank its cam_idx);
         the per-Gaussian AND trajectory gradients are averaged over ranks (one flat all-reduce + one few-KB one) before
         the Adam step and the densification statistics are combined before every densify_and_prune, so the replicas
@@ -44,6 +44,10 @@ class TrainingLoop:
         autograd graph, no host synchronisation; `speculative` sizes the duplicate arrays ahead, see that module) whenever
         the cloud allows it (fused activations), and falls
         back to the autograd path (CameraMotionModule.query + losses) otherwise; False forces the autograd path.
+        graph: "auto" (default) replays the fused iteration -- including the densification statistics and the optimiser
+        launch -- as ONE captured hipGraph per (view, subframe selection, SH degree, ...) whenever that is possible
+        (single process, no depth-smoothness term, no ground-truth noise, not an iteration that densifies or resets
+        opacities), falling back to the eager fused step otherwise; False never captures.  FusedStep.replay has the details.
         log_losses=False skips forming the scalar "loss" entry of step()'s result (two tiny launches).
         Not carried over from train.py: logging / visualiser / checkpoint-saving calls and `args.flag`."""
         self.gaussians, self.motion, self.opt, self.extent = gaussians, cam_motion_module, opt, cameras_extent
@@ -71,6 +75,8 @@ class TrainingLoop:
                                             step_final=opt.iterations)                  # train.py:90-94
         cam_motion_module.alternate_optimization()      # train.py:102, unconditional: curve gradients off at the start
         self.log_losses = log_losses
+        self.graph = bool(graph)
+        self.fixed_background = None    # a [3] tensor here replaces the random background (scene/motion.py:112-113)
         self.retried = 0            # dropped fused steps that were re-run through the exact path
         self._fused = None
         if fused_step:
@@ -150,7 +156,12 @@ class TrainingLoop:
         g = self.gaussians
         dev = g._xyz.device
         gt = self._ground_truth(cam_idx, self.motion.get_gt_image(cam_idx), iteration)
-        bg = torch.rand(3, device=dev)                                   # scene/motion.py:112-113
+        if self.graph and not exact and self._graphable(iteration):
+            out = self._step_graph(iteration, cam_idx, subframe_indice, lambda_t_smooth, gt)
+            if out is not None:
+                return out
+        bg = (torch.rand(3, device=dev) if self.fixed_background is None          # scene/motion.py:112-113
+              else self.fixed_background.to(dev, torch.float32))
         shard, uniform = None, None
         if self.mode == "subframes":
             import torch.distributed as dist
@@ -196,6 +207,51 @@ class TrainingLoop:
             out["loss"] = fr["losses"][0] + lambda_t_smooth * fr["losses"][1]    # (without the hinge term's value)
             if fr["depth_tv"] is not None:
                 out["loss"] = out["loss"] + self.opt.lambda_depth_tv * fr["depth_tv"]
+        return out
+
+    # ---- the iteration as one captured hipGraph
+    def _graphable(self, iteration):
+        opt = self.opt
+        if not hasattr(self.gaussians.optimizer, "step_enqueue"):
+            return False
+        if self.distributed or opt.lambda_depth_tv > 0.0 or self.noise_func(iteration) > 0.0 or iteration >= opt.iterations:
+            return False
+        if iteration < opt.densify_until_iter:      # densify_and_prune / reset_opacity go BETWEEN statistics and step
+            if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+                return False
+            if iteration % opt.opacity_reset_interval == 0 or (self.white_background and
+                                                               iteration == opt.densify_from_iter):
+                return False
+        return True
+
+    def _step_graph(self, iteration, cam_idx, subframe_indice, lambda_t_smooth, gt):
+        g, opt = self.gaussians, self.opt
+        stats_on = iteration < opt.densify_until_iter
+
+        def tail(fr, dev_scalars_ptr):         # recorded into the graph right after the backward (train.py:186-208)
+            if stats_on:
+                add_densification_stats_subframes(fr["viewspace_grad"], fr["radii"], g.max_radii2D, g.xyz_gradient_accum,
+                                                  g.denom, K_total=fr["K"], skip_flag_ptr=fr["skip_flag_ptr"])
+            g.optimizer.skip_flag_ptr = fr["skip_flag_ptr"]
+            g.optimizer.step_enqueue(dev_scalars_ptr)
+
+        sig = (stats_on, g.max_radii2D.data_ptr(), g.xyz_gradient_accum.data_ptr(), g.denom.data_ptr(),
+               float(self._fused.lambda_hinge), float(g.optimizer.clip_value))
+        fr = self._fused.replay(cam_idx, lambda_t_smooth, gt, subframe_indice, g.optimizer, tail, signature=sig,
+                                background=self.fixed_background)
+        if fr is None:
+            return None
+        g.optimizer.skip_flag_ptr = None
+        out = {"l1": fr["losses"][0], "smooth": fr["losses"][1], "hinge": None, "num_points": g._xyz.shape[0],
+               "loss": None, "dropped": self._fused.dropped, "retried": self.retried, "replayed": True}
+        if self.log_losses:
+            out["loss"] = fr["losses"][0] + lambda_t_smooth * fr["losses"][1]
+        while self._fused.retry:               # a replayed step that overflowed is made up for like an eager one
+            cam_r, sub_r = self._fused.retry.pop(0)
+            g.optimizer.note_skipped_steps(1)
+            self.retried += 1
+            self._step_fused(iteration, cam_r, sub_r, lambda_t_smooth, self.densify_threshold_func(iteration), exact=True)
+        out["retried"] = self.retried
         return out
 
     def _step_subframe_sharded(self, iteration, cam_idx, subframe_indice, lambda_t_smooth, L_hinge,

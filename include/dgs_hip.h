@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 6
+#define DGS_ABI_VERSION 7
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -96,10 +96,14 @@ typedef struct DgsProblem {
 
 typedef struct DgsForwardOut {
   float* out_color;   /* [K,3,H,W] */
-  float* out_depth;   /* [K,1,H,W] */
+  float* out_depth;   /* [K,1,H,W], or NULL: the caller does not consume the depth image (the default training loss
+                       * never reads it) -- the depth channel then drops out of the compositing */
   int32_t* radii;     /* [K,P] */
-  uint32_t* num_rendered_host; /* pinned host uint32[2]: dgs_forward_geometry enqueues an async copy of
-                                * {R, overflow}; overflow != 0 means the duplicate count exceeded 32 bits */
+  uint32_t* num_rendered_host; /* pinned host uint32[2] (dgs_forward: [5]): dgs_forward_geometry enqueues an async copy
+                                * of {R, overflow}; overflow != 0 means the duplicate count exceeded 32 bits */
+  uint32_t* drop_counter;      /* dgs_forward only, optional device word owned by the caller: incremented by every
+                                * forward whose capacity overflowed and copied to num_rendered_host[4].  A caller that
+                                * replays a captured graph reads its running value instead of one flag per replay. */
 } DgsForwardOut;
 
 typedef struct DgsBackwardIO {
@@ -203,7 +207,8 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t n
  * dgs_binning_state_bytes(capacity, ...).  num_rendered_host (pinned, >= 4 words) receives asynchronously
  * [0] the true duplicate count, [1] its u32-overflow word, [2] overflow flag (count > capacity or [1] != 0: the lists
  * were NOT built, the outputs are meaningless and dgs_backward on this state returns garbage-but-in-bounds results;
- * re-run with a larger capacity), [3] the count the lists were built with.  The same flag is the device word at
+ * re-run with a larger capacity), [3] the count the lists were built with, [4] the running drop_counter (if given).
+ * The same flag is the device word at
  * geom_state + DgsLayout.num_rendered + 20 bytes, which dgs_adam_step / dgs_densify_stats accept as `skip_flag` so that
  * a whole training step can be enqueued without any host synchronisation and still never apply a truncated gradient.
  * dgs_backward takes num_rendered = capacity for such a state. */
@@ -237,6 +242,12 @@ int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t*
  * All three outputs non-null computes everything at once. */
 int dgs_blur_loss_grad(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW, float lambda_t,
                        const float* upstream, float* blur, float* dL_dsubframes, float* losses, dgs_stream_t stream);
+
+/* The same with lambda_t read from device memory when the kernel runs: the scheduled weight of a captured (hipGraph)
+ * training step changes between replays without re-capturing. */
+int dgs_blur_loss_grad_dev(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW,
+                           const float* lambda_t_dev, const float* upstream, float* blur, float* dL_dsubframes,
+                           float* losses, dgs_stream_t stream);
 
 /* Densification-statistic consumers of the rasteriser's per-subframe outputs (train.py:188-193 with
  * scene/gaussian_model.py:456-458), for all K subframes in one pass and in subframe order:
@@ -280,6 +291,15 @@ typedef struct DgsCloudArrays {
   float* exp_avg[6];
   float* exp_avg_sq[6];
 } DgsCloudArrays;
+/* For captured (hipGraph) training steps: the per-group scalars that depend on the step count and the learning rate --
+ * out[2 i] = -(lr_i / (1 - beta1^step_i)), out[2 i + 1] = sqrt(1 - beta2^step_i), exactly as dgs_adam_step forms them --
+ * are computed on the host by dgs_adam_scalars, copied by the caller into device memory before every replay, and read
+ * from there (dev_scalars, same group order) by the kernel that dgs_adam_step_dev enqueues; the lr / step fields of the
+ * groups passed to dgs_adam_step_dev itself are not used. */
+int dgs_adam_scalars(const DgsAdamGroup* groups, int32_t n_groups, double beta1, double beta2, float* out);
+int dgs_adam_step_dev(const DgsAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps,
+                      double clip_value, const uint32_t* skip_flag, const float* dev_scalars, dgs_stream_t stream);
+
 size_t dgs_densify_tmp_bytes(int32_t P);
 /* plan: per Gaussian, grads = xyz_gradient_accum / denom (NaN -> 0); clone if |grads| >= grad_threshold and
  * max(exp(scaling)+scale_lb) <= size_threshold (= percent_dense * extent); split if grads >= grad_threshold and

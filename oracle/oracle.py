@@ -17,10 +17,13 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libdgs_oracle.so")
-_LIB_OMP_PATH = os.path.join(_HERE, "libdgs_oracle_omp.so")   # bench.py cpu_baseline only
+_LIB_OMP_PATH = os.path.join(_HERE, "libdgs_oracle_omp.so")   # bench.py cpu_baseline, full-size parity tests
+_LIB_FMA_PATH = os.path.join(_HERE, "libdgs_oracle_fma.so")   # the OpenMP build with FMA contraction (as nvcc --fmad=true)
 _lib = None
 _lib_omp = None
+_lib_fma = None
 _use_omp = False
+_use_fma = False
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 _i32p = ctypes.POINTER(ctypes.c_int32)
@@ -32,7 +35,7 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 def build(force=False):
     """Compile oracle/libdgs_oracle.so with the committed Makefile (g++, -ffp-contract=off)."""
     src = os.path.join(_HERE, "dgs_oracle.cpp")
-    for path in (_LIB_PATH, _LIB_OMP_PATH):
+    for path in (_LIB_PATH, _LIB_OMP_PATH, _LIB_FMA_PATH):
         if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             subprocess.check_call(["make", "-C", _HERE, "-s", os.path.basename(path)])
     return _LIB_PATH
@@ -54,6 +57,14 @@ def use_openmp(on=True):
     return lib().dgs_oracle_threads()
 
 
+def use_fma(on=True):
+    """Route backward() / chain_backward() to the FMA-contracted OpenMP build (the arithmetic nvcc's default --fmad=true
+    gives the reference).  Forward states must come from the uncontracted build: tile lists are compared bit for bit."""
+    global _use_fma
+    assert _use_omp or not on, "the FMA build is an OpenMP (deterministic, double-accumulating) build"
+    _use_fma = bool(on)
+
+
 def set_accum_f32(on):
     """OpenMP build only: accumulate the compositing backward in emulated fp32 (same deterministic order as the default
     double accumulation).  |double - f32| is the rounding-noise floor the parity tests put next to their 1e-4 bar."""
@@ -62,9 +73,13 @@ def set_accum_f32(on):
 
 
 def lib():
-    global _lib, _lib_omp
-    if not os.path.exists(_LIB_PATH) or not os.path.exists(_LIB_OMP_PATH):
+    global _lib, _lib_omp, _lib_fma
+    if not os.path.exists(_LIB_PATH) or not os.path.exists(_LIB_OMP_PATH) or not os.path.exists(_LIB_FMA_PATH):
         build()
+    if _use_omp and _use_fma:
+        if _lib_fma is None:
+            _lib_fma = _load(_LIB_FMA_PATH)
+        return _lib_fma
     if _use_omp:
         if _lib_omp is None:
             _lib_omp = _load(_LIB_OMP_PATH)
@@ -169,6 +184,37 @@ def backward(st, dL_dcolor, dL_ddepth=None):
         _p(st["n_contrib"], _u32p), _p(dL_dcolor, _f32p), _p(dL_ddepth, _f32p), ctypes.c_float(inp["z_far"]),
         _p(g["dL_dmeans2D"], _f32p), _p(g["dL_dconic"], _f32p), _p(g["dL_dopacity"], _f32p),
         _p(g["dL_dcolors"], _f32p), _p(g["dL_ddepths"], _f32p))
+    cov3D = inp["cov3D_precomp"] if inp["cov3D_precomp"] is not None else st["cov3D"]
+    L.dgs_oracle_preprocess_backward(
+        P, D, M, W, H, _p(inp["means3D"], _f32p), _p(st["radii"], _i32p), _p(inp["sh"], _f32p),
+        _p(st["pre_sigmoid"], _f32p), _p(inp["scales"], _f32p), _p(inp["rotations"], _f32p),
+        ctypes.c_float(inp["scale_modifier"]), _p(cov3D, _f32p), _p(inp["viewmatrix"], _f32p),
+        _p(inp["projmatrix"], _f32p), _p(inp["campos"], _f32p), ctypes.c_float(inp["tanfovx"]),
+        ctypes.c_float(inp["tanfovy"]), int(inp["use_sigmoid"]), _p(g["dL_dmeans2D"], _f32p),
+        _p(g["dL_dconic"], _f32p), _p(g["dL_dmeans3D"], _f32p), _p(g["dL_dcolors"], _f32p),
+        _p(g["dL_ddepths"], _f32p), _p(g["dL_dcov3D"], _f32p), _p(g["dL_dsh"], _f32p), _p(g["dL_dscales"], _f32p),
+        _p(g["dL_drotations"], _f32p), _p(g["dL_dviewmatrix"], _f32p), _p(g["dL_dprojmatrix"], _f32p))
+    g["dL_dviewmatrix"] = g["dL_dviewmatrix"].reshape(4, 4)
+    g["dL_dprojmatrix"] = g["dL_dprojmatrix"].reshape(4, 4)
+    return g
+
+
+def chain_backward(st, dL_dmeans2D, dL_dconic, dL_dcolors, dL_ddepths=None):
+    """Only the per-Gaussian half of the reference backward -- BACKWARD::preprocess = computeCov2DCUDA + preprocessCUDA
+    (backward.cu:145-460) -- on GIVEN outputs of the compositing backward for one subframe: dL_dmeans2D [P,3] (NDC-scaled),
+    dL_dconic [P,4] (.x, .y, .w used), dL_dcolors [P,3], dL_ddepths [P,1].  Lets a test feed the chain with another
+    implementation's compositing results and so check that implementation's chain in isolation."""
+    L = lib()
+    inp = st["inputs"]
+    P, M, D, W, H = st["P"], st["M"], st["D"], st["W"], st["H"]
+    g = dict(
+        dL_dmeans2D=_f(dL_dmeans2D).reshape(P, 3).copy(), dL_dconic=_f(dL_dconic).reshape(P, 4).copy(),
+        dL_dcolors=_f(dL_dcolors).reshape(P, 3).copy(),
+        dL_ddepths=np.zeros((P, 1), np.float32) if dL_ddepths is None else _f(dL_ddepths).reshape(P, 1).copy(),
+        dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dcov3D=np.zeros((P, 6), np.float32),
+        dL_dsh=np.zeros((P, M, 3), np.float32), dL_dscales=np.zeros((P, 3), np.float32),
+        dL_drotations=np.zeros((P, 4), np.float32), dL_dviewmatrix=np.zeros(16, np.float32),
+        dL_dprojmatrix=np.zeros(16, np.float32))
     cov3D = inp["cov3D_precomp"] if inp["cov3D_precomp"] is not None else st["cov3D"]
     L.dgs_oracle_preprocess_backward(
         P, D, M, W, H, _p(inp["means3D"], _f32p), _p(st["radii"], _i32p), _p(inp["sh"], _f32p),
