@@ -58,6 +58,11 @@ def parse_args(argv=None):
     ap.add_argument("--lambda-t", type=float, default=1e-3)
     ap.add_argument("--autograd-path", action="store_true",
                     help="run the step through CameraMotionModule.query + torch autograd instead of the fused step")
+    ap.add_argument("--ar-chunks", type=int, default=4,
+                    help="N > 1 GPUs: all-reduce the per-Gaussian gradient bucket in this many Gaussian-index chunks on a side "
+                         "stream, each as soon as the backward has produced it (1 = one collective after the backward)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="enqueue every step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="time query + loss + backward (+ all-reduce) only, without densification stats and Adam")
     return ap.parse_args(argv)
@@ -282,7 +287,8 @@ def run_rank(args):
                                       curve_alignment_lr=0.0)
     mode = False if world == 1 else args.shard
     loop = TrainingLoop(cloud, motion, opt, cameras_extent=1.0, spatial_lr_scale=1.0, distributed=mode,
-                        fused_step=False if args.autograd_path else "auto", log_losses=False)
+                        fused_step=False if args.autograd_path else "auto", log_losses=False,
+                        graph=False if args.no_graph else "auto", ar_chunks=args.ar_chunks)
     # The ground truth is noise, so real learning rates would pull the cloud away from the configured workload within
     # the timed region (opacities collapse and the step gets ~5 % cheaper).  The Adam kernel does the same work for
     # any learning rate; scale the rates down so that every timed step renders the workload BASELINE.json names.
@@ -342,11 +348,25 @@ def run_rank(args):
                              shard=(rank, world) if subframes_mode else None)
         Pv_tot = int((probe["radii_all"] > 0).sum().item())
         del probe
-    dt = timed(args.steps, profile=True)
-    prof = _lib.profile_read()
+    replaying = world == 1 and loop.graph and loop._fused is not None and not args.autograd_path and not args.no_graph
+    dt = timed(args.steps, profile=not replaying)
     allreduce_ms = None
     if ar_events:
         allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
+    graph_info = None
+    if replaying:
+        # The timed region replayed the captured step (one hipGraph launch per iteration): HIP events cannot be recorded
+        # between the kernels of a graph, so the per-stage durations come from a second, EAGER region of the same step
+        # (same kernels, same arguments) right after it.
+        graph_info = {"captured": loop._fused.captured, "replayed": loop._fused.replayed}
+        loop.graph = False
+        for _ in range(2):
+            step()
+        n_prof = max(10, min(args.steps, 30))
+        dt_eager = timed(n_prof, profile=True)
+        graph_info["eager_ms_per_step"] = round(dt_eager / n_prof * 1e3, 3)
+        loop.graph = True
+    prof = _lib.profile_read()
 
     # the same step on the reference's duplicate lists (tile_cull = 0: sort keys / point lists bit-identical to the
     # reference's), reported beside the headline value
@@ -421,19 +441,23 @@ def run_rank(args):
                                 ("" if args.no_optimizer else " + densification stats + fused Adam (all groups; learning "
                                  "rates x1e-6 so the synthetic workload stays stationary)")),
                        "step_path": ("deblurgs_amd.training.TrainingLoop.step via " +
-                                     ("fused_step.FusedStep (C ABI, no autograd, duplicate arrays sized ahead)"
+                                     ("fused_step.FusedStep (C ABI, no autograd, duplicate arrays sized ahead" +
+                                      (", the iteration replayed as one captured hipGraph)" if graph_info else ")")
                                       if loop._fused is not None else "CameraMotionModule.query + torch autograd")),
+                       "graph": graph_info,
                        "dropped_steps": (loop._fused.dropped if loop._fused is not None else 0),
                        "retried_steps": loop.retried,
                        "tile_cull": bool(dgr.TILE_CULL),
                        "sharding": (args.shard if world > 1 else "none"), "ranks_in_process_group": world,
+                       "ar_chunks": (args.ar_chunks if world > 1 and loop._fused is not None else None),
                        "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
                        "Pv_total": Pv_tot, "R_total": int(R_tot),
                        "pixel_gaussian_evals_upper_bound_per_step": int(256 * R_tot)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 5), "traffic": None,
                          "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["avg_ms"],
-                         "avg_launch_ms_source": "HIP events on the launch stream inside this run (dgs_profile_*)",
+                         "avg_launch_ms_source": "HIP events on the launch stream inside this run (dgs_profile_*)" +
+                                                 (", recorded in the eager region that follows the replayed one" if graph_info else ""),
                          "note": "compositing is VALU/LDS-bound, not HBM-bound (SURVEY 8d); frac is the honest HBM "
                                  "fraction of the byte model"},
             "pipeline_hbm": {"alg_bytes_per_step": int(total_bytes),

@@ -95,6 +95,11 @@ EXPORTS = {
     "dgs_forward_render": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsForwardOut),
                                           ctypes.c_uint32, ctypes.c_void_p]),
     "dgs_backward": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsBackwardIO), ctypes.c_void_p]),
+    "dgs_backward_composite": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsBackwardIO),
+                                              ctypes.c_void_p]),
+    "dgs_backward_geometry": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsBackwardIO), ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_void_p]),
+    "dgs_backward_pose": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsBackwardIO), ctypes.c_void_p]),
     "dgs_mark_visible": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p]),
     "dgs_scan_tmp_bytes": (ctypes.c_size_t, [ctypes.c_uint64]),

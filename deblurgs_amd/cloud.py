@@ -242,12 +242,15 @@ class GaussianCloud(nn.Module):
     @torch.no_grad()
     def densify_and_prune(self, max_grad, extent, noise=None, generator=None):
         """scene/gaussian_model.py:436-448 in three kernels + four scans.  `noise` ([2 m, 3] standard normals for
-        the m split-selected Gaussians x 2 copies) is drawn here when absent (the reference's torch.normal)."""
+        the m split-selected Gaussians x 2 copies) is drawn here when absent (the reference's torch.normal); a callable is
+        called with m and returns them."""
         from . import optim
         min_opacity = self.alpha_lower_bound + (1 - self.alpha_lower_bound) * 0.005
         counts, flags, offs = optim.densify_plan(self.xyz_gradient_accum, self.denom, self._scaling.detach(),
                                                  self._opacity.detach(), max_grad, self.percent_dense * extent,
                                                  min_opacity, self.scale_lower_bound, isotropic=self.use_isotrophic)
+        if callable(noise):      # (tests: the same normal draws as another implementation of the same step)
+            noise = torch.as_tensor(noise(counts[3]), dtype=torch.float32, device=self._xyz.device)
         if noise is None:
             noise = torch.randn((2 * counts[3], 3), device=self._xyz.device, generator=generator)
         m, v, states = self._moments()

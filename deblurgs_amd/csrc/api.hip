@@ -653,14 +653,16 @@ int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity
   return forward_render_impl(p, out, capacity, true, s);
 }
 
-int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream) {
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+// which != 0: 1 = compositing backward + per-pair totals, 2 = per-Gaussian kernel for [g_begin, g_end), 4 = pose sums
+static int backward_impl(const DgsProblem* p, const DgsBackwardIO* io, int which, int32_t g_begin, int32_t g_end,
+                         hipStream_t s) {
   int rc = check_problem(p);
   if (rc != DGS_OK) return rc;
   if (io == nullptr) return fail(DGS_E_ARG, "null DgsBackwardIO");
   if (io->dL_dviewmatrix == nullptr || io->dL_dprojmatrix == nullptr)
     return fail(DGS_E_ARG, "dL_dviewmatrix / dL_dprojmatrix are null");
   if (p->P == 0) {
+    if (!(which & 4)) return DGS_OK;
     hipError_t e = hipMemsetAsync(io->dL_dviewmatrix, 0, (size_t)p->K * 64, s);
     if (e == hipSuccess) e = hipMemsetAsync(io->dL_dprojmatrix, 0, (size_t)p->K * 64, s);
     return e == hipSuccess ? DGS_OK : fail_hip(e, "memset grads");
@@ -673,6 +675,8 @@ int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stre
   if (p->raw_params && p->M > 1 && io->dL_dsh_rest == nullptr) return fail(DGS_E_ARG, "dL_dsh_rest is null");
   if (p->scales != nullptr && (io->dL_dscales == nullptr || io->dL_drotations == nullptr))
     return fail(DGS_E_ARG, "dL_dscales / dL_drotations are null");
+  if (g_begin < 0 || g_end > p->P || g_begin > g_end || (g_begin % 256) != 0)
+    return fail(DGS_E_ARG, "backward: bad Gaussian range (g_begin must be a multiple of 256)");
   const uint64_t R = io->num_rendered;
   DgsLayout L;
   make_layout(p->P, p->W, p->H, p->K, R, p->wide_records != 0, &L);
@@ -693,10 +697,26 @@ int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stre
   float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(io->scratch) + up((size_t)R * DGS_CONTRIB_F * 4));
   double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(sums) +
                                                up((size_t)p->K * (size_t)p->P * DGS_CONTRIB_F * 4));
-  DGS_STAGE(DGS_STAGE_COMPOSITE_BWD, "composite backward",
-            dgs_launch_composite_bwd(v, c, p->bg, io->dL_dout_color, io->dL_dout_depth, contrib, s));
-  DGS_STAGE(DGS_STAGE_GEOMETRY_BWD, "geometry backward", dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s));
+  if (which & 1)
+    DGS_STAGE(DGS_STAGE_COMPOSITE_BWD, "composite backward",
+              dgs_launch_composite_bwd(v, c, p->bg, io->dL_dout_color, io->dL_dout_depth, contrib, s));
+  DGS_STAGE(DGS_STAGE_GEOMETRY_BWD, "geometry backward",
+            dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s, which, g_begin, g_end));
   return DGS_OK;
+}
+
+int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream) {
+  return backward_impl(p, io, 7, 0, p != nullptr ? p->P : 0, reinterpret_cast<hipStream_t>(stream));
+}
+int dgs_backward_composite(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream) {
+  return backward_impl(p, io, 1, 0, 0, reinterpret_cast<hipStream_t>(stream));
+}
+int dgs_backward_geometry(const DgsProblem* p, const DgsBackwardIO* io, int32_t g_begin, int32_t g_end,
+                          dgs_stream_t stream) {
+  return backward_impl(p, io, 2, g_begin, g_end, reinterpret_cast<hipStream_t>(stream));
+}
+int dgs_backward_pose(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream) {
+  return backward_impl(p, io, 4, 0, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
 int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -125,11 +125,13 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
                     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dsh, float* __restrict__ dL_dsh_rest,
                     float* __restrict__ dL_dcolors,
                     float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales, float* __restrict__ dL_drots,
-                    float* __restrict__ dL_dcov3D_out, double* __restrict__ partials) {
+                    float* __restrict__ dL_dcov3D_out, double* __restrict__ partials, int g_begin, int g_end) {
   extern __shared__ __attribute__((aligned(16))) float s_part[];  // [waves][K][NMAT]
   if (status[5] != 0u) return;  // capacity mode, truncated lists (see contrib_reduce_kernel); the caller discards the step
-  const int idx = blockIdx.x * GB_THREADS + threadIdx.x;
-  const bool valid = idx < v.P;
+  // Gaussians [g_begin, g_end) (g_begin a multiple of the block size): a caller may run the per-Gaussian half in index
+  // chunks so that the all-reduce of one chunk's gradients overlaps the next chunk's kernel (dgs_backward_geometry)
+  const int idx = g_begin + blockIdx.x * GB_THREADS + threadIdx.x;
+  const bool valid = idx < g_end;
   const int gi = valid ? idx : 0;
   const int lane = dgs_lane(), w = threadIdx.x >> 6;
   const float mx = means3D[3 * gi], my = means3D[3 * gi + 1], mz = means3D[3 * gi + 2];
@@ -563,7 +565,7 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     double acc = 0.0;
 #pragma unroll
     for (int ww = 0; ww < GB_THREADS / 64; ww++) acc += (double)s_part[(size_t)ww * total + i];
-    partials[(size_t)blockIdx.x * total + i] = acc;
+    partials[((size_t)(g_begin / GB_THREADS) + blockIdx.x) * total + i] = acc;
   }
 }
 
@@ -617,21 +619,24 @@ pose_grad_reduce_kernel(int K, int nblocks, const double* __restrict__ partials,
 
 int dgs_geometry_bwd_blocks(int P) { return (P + GB_THREADS - 1) / GB_THREADS; }
 
+// phases: 1 = per-pair totals of the contribution rows, 2 = the per-Gaussian kernel for Gaussians [g_begin, g_end),
+// 4 = the final sum of the pose-gradient partials of ALL blocks (after every chunk has run)
 hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const DgsCarve& c, const DgsBackwardIO& io,
-                                   const float* contrib, float* sums, double* partials, hipStream_t s) {
-  const int blocks = dgs_geometry_bwd_blocks(v.P);
+                                   const float* contrib, float* sums, double* partials, hipStream_t s, int phases,
+                                   int g_begin, int g_end) {
+  const int all_blocks = dgs_geometry_bwd_blocks(v.P);
   const size_t lds = (size_t)(GB_THREADS / 64) * v.K * NMAT * sizeof(float);
   const int ncoef = (p.shs != nullptr) ? (v.D + 1) * (v.D + 1) : 1;
   const uint64_t kp = (uint64_t)v.K * v.P;
   // walk the (k, Gaussian) pairs in (k, depth, index) order: their row segments are then consecutive in memory
-  // (that is the order the duplicates were laid out in), so a wave streams one contiguous span of rows
-  // (tt_sorted / offs_sorted only exist when the forward produced duplicates)
+  // (that is the order the duplicates were laid out in)
   // (the depth order, tt_sorted / offs_sorted exist whenever a duplicate or -- with tile culling -- a visible pair does;
   // otherwise no pair is visible and the geometry kernel reads no total)
-  if (io.num_rendered > 0 || v.tile_cull)
+  if ((phases & 1) && (io.num_rendered > 0 || v.tile_cull))
     hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((4 * kp + 255) / 256)), dim3(256), 0, s, kp, c.num_rendered,
                      c.gsort_vals, c.tt_sorted, v.tile_cull ? c.tt_tight : c.tt_sorted,
                      v.tile_cull ? c.offs_tight : c.offs_sorted, contrib, sums);
+  const int blocks = (g_end - g_begin + GB_THREADS - 1) / GB_THREADS;
 #define DGS_GB_LAUNCH(MAXC)                                                                                          \
   hipLaunchKernelGGL(geometry_bwd_kernel<MAXC>, dim3(blocks), dim3(GB_THREADS), lds, s, v, p.means3D, p.shs,         \
                      p.shs_rest, p.opacities,                                                                        \
@@ -640,19 +645,23 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
                      c.pre_sigmoid, c.tiles_touched, sums, c.num_rendered, io.opacity_hinge_scale, io.dL_dmeans3D,  \
                      io.dL_dmeans2D, io.dL_dsh,                                                                       \
                      io.dL_dsh_rest,                                                                                 \
-                     io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations, io.dL_dcov3D, partials)
-  if (ncoef <= 1)
-    DGS_GB_LAUNCH(1);
-  else if (ncoef <= 4)
-    DGS_GB_LAUNCH(4);
-  else if (ncoef <= 9)
-    DGS_GB_LAUNCH(9);
-  else
-    DGS_GB_LAUNCH(16);
+                     io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations, io.dL_dcov3D, partials, g_begin, \
+                     g_end)
+  if ((phases & 2) && blocks > 0) {
+    if (ncoef <= 1)
+      DGS_GB_LAUNCH(1);
+    else if (ncoef <= 4)
+      DGS_GB_LAUNCH(4);
+    else if (ncoef <= 9)
+      DGS_GB_LAUNCH(9);
+    else
+      DGS_GB_LAUNCH(16);
+  }
 #undef DGS_GB_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(pose_grad_reduce_kernel, dim3(v.K), dim3(256), 0, s, v.K, blocks, partials, io.dL_dviewmatrix,
-                     io.dL_dprojmatrix);
+  if (phases & 4)
+    hipLaunchKernelGGL(pose_grad_reduce_kernel, dim3(v.K), dim3(256), 0, s, v.K, all_blocks, partials, io.dL_dviewmatrix,
+                       io.dL_dprojmatrix);
   return hipGetLastError();
 }

@@ -63,6 +63,7 @@ class FusedStep:
         self._keep = None           # buffers of the last step (the skip flag lives in its geometry blob)
         self.last_capacity = None
         self._sel_cache = {}
+        self._side = None           # side stream of the chunked gradient all-reduce
         self._drops_dev = None      # device word: forwards that overflowed so far (DgsForwardOut.drop_counter)
         self._graphs = {}           # captured steps by what they bake in (replay)
         self._pool = None           # one memory pool for all of them: replays never overlap
@@ -113,7 +114,8 @@ class FusedStep:
             return h
         return torch.zeros(8, dtype=torch.int32).pin_memory()
 
-    def _empty_slice(self, gt, lambda_t, K_total, P, H, W, ct_all, cr_all, nu_raw, need_blur, lambda_depth_tv=0.0):
+    def _empty_slice(self, gt, lambda_t, K_total, P, H, W, ct_all, cr_all, nu_raw, need_blur, lambda_depth_tv=0.0,
+                     ar=None):
         """"subframes" sharding with more ranks than subframes: this rank rasterises nothing but takes part in the loss
         block's exchanges; all its gradients are zero."""
         from . import sharding
@@ -123,8 +125,26 @@ class FusedStep:
         color = torch.zeros((0, 3, H, W), **f32)
         _, l1, sm = sharding.subframe_sharded_loss_grad(color, gt.to(dev, torch.float32).contiguous(), K_total,
                                                         float(lambda_t))
-        for p in cloud.hot_parameters():
-            p.grad = torch.zeros_like(p)
+        if ar is None:
+            for p in cloud.hot_parameters():
+                p.grad = torch.zeros_like(p)
+        else:      # take part in the other ranks' (chunked) reduction of the gradient bucket with a bucket of zeros
+            hot = list(cloud.hot_parameters())
+            sizes = [p.numel() for p in hot]
+            offs = [0]
+            for n in sizes:
+                offs.append(offs[-1] + (n + 3) // 4 * 4)
+            flat = torch.zeros(offs[-1], **f32)
+            for i, p in enumerate(hot):
+                p.grad = flat[offs[i]:offs[i] + sizes[i]].view(p.shape)
+            if int(ar.get("chunks", 1)) <= 1 or P < 512:
+                if P > 0:
+                    sharding._allreduce(flat, bool(ar.get("average", False)), ar.get("group"))
+            else:
+                widths = [n // max(P, 1) for n in sizes]
+                for b0, b1 in sharding.chunk_bounds(P, int(ar["chunks"])):
+                    sharding.allreduce_slices([flat[offs[i] + b0 * c:offs[i] + b1 * c] for i, c in enumerate(widths)],
+                                              bool(ar.get("average", False)), ar.get("group"))
         if m.is_optimizing():
             m._trans._control_points.grad, m._rot._control_points.grad = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
             if nu_raw.numel() > 0:
@@ -156,7 +176,8 @@ class FusedStep:
     def _hyper_words(self, f):
         return max(self.HYPER_FLOATS, 48 + f)
 
-    def replay(self, cam_idx, lambda_t, gt, subframe_indice, optimizer, tail, signature=(), background=None):
+    def replay(self, cam_idx, lambda_t, gt, subframe_indice, optimizer, tail, signature=(), background=None,
+               uniform=None):
         """One training iteration as ONE hipGraph launch (SURVEY 8f / DESIGN 2b): alignment -> cameras -> dgs_forward
         (capacity sized ahead) -> loss -> dgs_backward -> camera gradients -> `tail` (densification statistics + the
         optimiser launch).  At DeblurGS's real scene sizes a step is ~60 kernels of a few microseconds each; replayed
@@ -180,10 +201,12 @@ class FusedStep:
         cap = self._capacity(ckey) if self.speculative else None
         if cap is None or isinstance(subframe_indice, (list, tuple)) or torch.is_tensor(subframe_indice):
             return None
-        cap = -(-cap // (1 << 18)) << 18      # quantised: small count drifts do not force a re-capture
+        q = 1 << max(cap.bit_length() - 5, 10)      # quantised to ~3-6 %: small count drifts do not force a re-capture
+        cap = -(-cap // q) * q
         hot = list(cloud.hot_parameters())
+        cull = dgr.TILE_CULL if self.tile_cull is None else bool(self.tile_cull)
         gkey = (int(cam_idx), subframe_indice, int(cloud.active_sh_degree), bool(m.is_optimizing()),
-                bool(m.curve_random_sample), cap, self._generation, gt.data_ptr(),
+                bool(m.curve_random_sample), cap, self._generation, gt.data_ptr(), bool(cull), bool(dgr.WIDE_RECORDS),
                 tuple(p.data_ptr() for p in hot), tuple(signature))
         ent = self._graphs.get(gkey)
         if ent is None:
@@ -201,8 +224,8 @@ class FusedStep:
         hv = hbuf.numpy()
         hv[0] = float(lambda_t)
         hv[1:4] = (torch.rand(3) if background is None else background.detach().float().cpu()).numpy()   # motion.py:112-113
-        if m.curve_random_sample and f > 2:
-            hv[48:48 + f - 2] = torch.rand(f - 2).numpy()                 # scene/motion.py:213-214
+        if m.curve_random_sample and f > 2:                               # scene/motion.py:213-214
+            hv[48:48 + f - 2] = (torch.rand(f - 2) if uniform is None else uniform.detach().float().cpu()).numpy()
         for p, g in ent["grads"]:              # the step's gradients live in the graph's buffers
             p.grad = g
         optimizer.skip_flag_ptr = ent["result"]["skip_flag_ptr"]
@@ -254,7 +277,7 @@ class FusedStep:
     # ------------------------------------------------------------------------------------------------- the step
     @torch.no_grad()
     def run(self, cam_idx, lambda_t, gt, background, subframe_indice="all", need_blur=False, uniform=None,
-            lambda_depth_tv=0.0, shard=None, exact=False, need_depth=False, _cap=None):
+            lambda_depth_tv=0.0, shard=None, exact=False, need_depth=False, _cap=None, ar=None):
         """gt: [3,H,W] ground truth of view cam_idx (already tone-mapped / noised by the caller); background: [3].
         lambda_depth_tv > 0 adds the reference's optional depth-smoothness term (train.py:150-153,
         utils/loss_utils.py:66-78): its gradient on the K depth images is formed with a few torch ops and handed to the
@@ -266,6 +289,10 @@ class FusedStep:
         only); 'radii' / 'viewspace_grad' / 'subframes' hold the local slice, 'K' the view's subframe count.
         exact=True forces the two-phase forward (one host read) whatever has been learnt.
         need_depth=True renders the K depth images too ('depths'; implied by lambda_depth_tv > 0), else 'depths' is None.
+        ar = {"chunks": G, "average": bool, "group": ...}: a sharded run's all-reduce of the per-Gaussian gradient bucket,
+        overlapped with the backward's tail: the per-Gaussian half of the backward runs in G Gaussian-index
+        chunks (dgs_backward_geometry) and chunk i is reduced on a side stream while chunk i + 1 computes; the caller must
+        then NOT reduce the bucket again (the trajectory gradients remain its job).
         _cap: internal, set by replay() while the step is being CAPTURED into a hipGraph -- the capacity, the pinned count
         words, the device words lambda_t is read from and the tail (statistics + optimiser launch) to enqueue; no host
         bookkeeping happens then.
@@ -327,7 +354,8 @@ class FusedStep:
         P = cloud._xyz.shape[0]
         H, W = int(m.ref_cam.image_height), int(m.ref_cam.image_width)
         if K == 0:
-            return self._empty_slice(gt, lambda_t, K_total, P, H, W, ct_all, cr_all, nu_raw, need_blur, lambda_depth_tv)
+            return self._empty_slice(gt, lambda_t, K_total, P, H, W, ct_all, cr_all, nu_raw, need_blur, lambda_depth_tv,
+                                     ar)
         rest = cloud._features_rest if cloud._features_rest.shape[1] > 0 else None
         Mr = 0 if rest is None else rest.shape[1]
         color = torch.empty((K, 3, H, W), **f32)
@@ -447,7 +475,32 @@ class FusedStep:
         io.dL_dcov3D, io.dL_dviewmatrix, io.dL_dprojmatrix = _ptr(g_cov3D), _ptr(g_view), _ptr(g_proj)
         # sharded: the ranks' gradients are summed, so the hinge term is added by one of them only
         io.opacity_hinge_scale = self.lambda_hinge / max(P, 1) if (shard is None or int(shard[0]) == 0) else 0.0
-        _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward")
+        if ar is None or int(ar.get("chunks", 1)) <= 1 or P < 512:
+            _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward")
+            if ar is not None and P > 0:
+                from . import sharding
+                sharding._allreduce(flat, bool(ar.get("average", False)), ar.get("group"))
+        else:
+            from . import sharding
+            _lib.check(L.dgs_backward_composite(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_composite")
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
+            flat.record_stream(side)
+            widths = [3, 3, 3 * Mr, 1, 3, 4]
+            for b0, b1 in sharding.chunk_bounds(P, int(ar["chunks"])):
+                _lib.check(L.dgs_backward_geometry(ctypes.byref(prob), ctypes.byref(io), b0, b1, stream),
+                           "dgs_backward_geometry")
+                ev = torch.cuda.Event()
+                ev.record(stream_obj)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    sharding.allreduce_slices([flat[offs[i] + b0 * c:offs[i] + b1 * c] for i, c in enumerate(widths)],
+                                              bool(ar.get("average", False)), ar.get("group"))
+            _lib.check(L.dgs_backward_pose(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_pose")
+            done = torch.cuda.Event()
+            done.record(side)
+            stream_obj.wait_event(done)
         if P == 0:
             flat.zero_()
             g_means2D.zero_()

@@ -123,6 +123,30 @@ def _allreduce(flat, average, group):
             flat /= dist.get_world_size(group)
 
 
+def allreduce_slices(tensors, average=False, group=None):
+    """One fused collective over several contiguous fp32 tensors (the six row ranges of one Gaussian-index chunk of the
+    gradient bucket): RCCL gets them as one group call (coalescing manager), other backends one all-reduce each."""
+    tensors = [t for t in tensors if t.numel() > 0]
+    if not tensors:
+        return
+    if dist.get_backend(group) == "nccl" and hasattr(dist, "_coalescing_manager"):
+        op = dist.ReduceOp.AVG if average else dist.ReduceOp.SUM
+        with dist._coalescing_manager(group=group, device=tensors[0].device, async_ops=False):
+            for t in tensors:
+                dist.all_reduce(t, op=op, group=group)
+        return
+    for t in tensors:
+        _allreduce(t, average, group)
+
+
+def chunk_bounds(P, chunks, align=256):
+    """Gaussian-index chunk boundaries for dgs_backward_geometry: `chunks` ranges, each starting on a multiple of `align`."""
+    per = -(-P // max(int(chunks), 1))
+    per = -(-per // align) * align
+    b = list(range(0, P, per)) + [P] if P > 0 else [0, 0]
+    return list(zip(b[:-1], b[1:]))
+
+
 def allreduce_small_grads(params, average=False, group=None, force=False):
     """The trajectory parameters (curve control points, alignment) are replicated like the cloud; their gradients are a
     few KB, packed into one small buffer and reduced next to the per-Gaussian bucket.  A parameter without a gradient on

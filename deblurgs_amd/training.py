@@ -28,7 +28,8 @@ def default_optimization_params(**overrides):
 
 class TrainingLoop:
     def __init__(self, gaussians, cam_motion_module, opt, cameras_extent, white_background=False, spatial_lr_scale=None,
-                 distributed=False, tone_mapping=None, fused_step="auto", speculative=True, log_losses=True, graph="auto"):
+                 distributed=False, tone_mapping=None, fused_step="auto", speculative=True, log_losses=True, graph="auto",
+                 ar_chunks=1):
         """distributed = "views" (or True): every rank steps on its own view (the caller passes each rank its cam_idx);
         the per-Gaussian AND trajectory gradients are averaged over ranks (one flat all-reduce + one few-KB one) before
         the Adam step and the densification statistics are combined before every densify_and_prune, so the replicas
@@ -44,6 +45,9 @@ class TrainingLoop:
         autograd graph, no host synchronisation; `speculative` sizes the duplicate arrays ahead, see that module) whenever
         the cloud allows it (fused activations), and falls
         back to the autograd path (CameraMotionModule.query + losses) otherwise; False forces the autograd path.
+        ar_chunks > 1 (sharded runs on the fused step): the all-reduce of the per-Gaussian gradient bucket is issued in
+        that many Gaussian-index chunks on a side stream, each as soon as the backward has produced it, instead of one
+        collective after the backward (FusedStep.run, `ar`).
         graph: "auto" (default) replays the fused iteration -- including the densification statistics and the optimiser
         launch -- as ONE captured hipGraph per (view, subframe selection, SH degree, ...) whenever that is possible
         (single process, no depth-smoothness term, no ground-truth noise, not an iteration that densifies or resets
@@ -76,7 +80,9 @@ class TrainingLoop:
         cam_motion_module.alternate_optimization()      # train.py:102, unconditional: curve gradients off at the start
         self.log_losses = log_losses
         self.graph = bool(graph)
+        self.ar_chunks = int(ar_chunks)
         self.fixed_background = None    # a [3] tensor here replaces the random background (scene/motion.py:112-113)
+        self.split_noise_fn = None      # f(iteration, m) -> [2 m, 3] standard normals for densify_and_split (tests)
         self.retried = 0            # dropped fused steps that were re-run through the exact path
         self._fused = None
         if fused_step:
@@ -140,14 +146,16 @@ class TrainingLoop:
         self._tail(iteration, r, densification_threshold)
         return {"loss": loss.detach(), "l1": Ll1, "smooth": L_t, "hinge": L_hinge, "num_points": g._xyz.shape[0]}
 
-    def _shared_draws(self, bg):
+    def _shared_draws(self, bg, uniform=None):
         """"subframes" sharding: the ranks rasterise slices of ONE view, so the random background (scene/motion.py:112-113)
         and the alignment jitter (scene/motion.py:213-214, curve_random_sample) must be the same draw on all of them:
         rank 0's, sent in one small broadcast.  Returns (bg [3], uniform [f-2] or None)."""
         import torch.distributed as dist
         m = self.motion
         n = m._nu.shape[1] if (m.curve_random_sample and m._nu.ndim == 2) else 0
-        buf = torch.cat([bg.reshape(3).float(), torch.rand(n, device=bg.device)])
+        if n > 0 and uniform is None:
+            uniform = torch.rand(n).to(bg.device)
+        buf = torch.cat([bg.reshape(3).float()] + ([uniform.reshape(n).float()] if n > 0 else []))
         dist.broadcast(buf, src=0)
         return buf[:3].contiguous(), (buf[3:].contiguous() if n > 0 else None)
 
@@ -156,19 +164,28 @@ class TrainingLoop:
         g = self.gaussians
         dev = g._xyz.device
         gt = self._ground_truth(cam_idx, self.motion.get_gt_image(cam_idx), iteration)
+        # The step's random numbers -- background (scene/motion.py:112-113) and alignment jitter (:213-214) -- are drawn
+        # from the HOST generator, so that the eager and the captured step consume the same stream
+        bg_host = torch.rand(3) if self.fixed_background is None else self.fixed_background.detach().float().cpu()
+        m = self.motion
+        n_jit = m._nu.shape[1] if (m.curve_random_sample and m._nu.ndim == 2) else 0
+        uni_host = torch.rand(n_jit) if n_jit > 0 else None
         if self.graph and not exact and self._graphable(iteration):
-            out = self._step_graph(iteration, cam_idx, subframe_indice, lambda_t_smooth, gt)
+            out = self._step_graph(iteration, cam_idx, subframe_indice, lambda_t_smooth, gt, bg_host, uni_host)
             if out is not None:
                 return out
-        bg = (torch.rand(3, device=dev) if self.fixed_background is None          # scene/motion.py:112-113
-              else self.fixed_background.to(dev, torch.float32))
-        shard, uniform = None, None
+        bg = bg_host.to(dev)
+        uniform = None if uni_host is None else uni_host.to(dev)
+        shard = None
         if self.mode == "subframes":
             import torch.distributed as dist
             shard = (dist.get_rank(), dist.get_world_size())
-            bg, uniform = self._shared_draws(bg)
+            bg, uniform = self._shared_draws(bg, uniform)
+        ar = None
+        if self.distributed and self.ar_chunks > 1:      # the bucket is reduced inside run(), chunk by chunk
+            ar = {"chunks": self.ar_chunks, "average": self.mode != "subframes"}
         fr = self._fused.run(cam_idx, lambda_t_smooth, gt, bg, subframe_indice, uniform=uniform,
-                             lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0), shard=shard, exact=exact)
+                             lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0), shard=shard, exact=exact, ar=ar)
         skip = fr["skip_flag_ptr"]
         if self.distributed:
             from . import sharding
@@ -185,8 +202,11 @@ class TrainingLoop:
                 self._flag_keep = flag
                 skip = flag.data_ptr()
             # "views": a mini-batch of views, gradients averaged; "subframes": partial sums of one view's gradient
-            sharding.flat_allreduce_grads(g.hot_parameters(), average=self.mode != "subframes",
-                                          extra=[p for p in self.motion.parameters() if p.requires_grad])
+            extra = [p for p in self.motion.parameters() if p.requires_grad]
+            if ar is not None:         # (the bucket was reduced inside run(), also by a rank without subframes)
+                sharding.allreduce_small_grads(extra, average=self.mode != "subframes")
+            else:
+                sharding.flat_allreduce_grads(g.hot_parameters(), average=self.mode != "subframes", extra=extra)
         g.optimizer.skip_flag_ptr = skip
         r = {"viewspace_points_all": fr["viewspace_grad"], "radii_all": fr["radii"], "K_total": fr["K"],
              "skip_flag_ptr": skip}
@@ -224,7 +244,7 @@ class TrainingLoop:
                 return False
         return True
 
-    def _step_graph(self, iteration, cam_idx, subframe_indice, lambda_t_smooth, gt):
+    def _step_graph(self, iteration, cam_idx, subframe_indice, lambda_t_smooth, gt, bg_host, uni_host):
         g, opt = self.gaussians, self.opt
         stats_on = iteration < opt.densify_until_iter
 
@@ -238,7 +258,7 @@ class TrainingLoop:
         sig = (stats_on, g.max_radii2D.data_ptr(), g.xyz_gradient_accum.data_ptr(), g.denom.data_ptr(),
                float(self._fused.lambda_hinge), float(g.optimizer.clip_value))
         fr = self._fused.replay(cam_idx, lambda_t_smooth, gt, subframe_indice, g.optimizer, tail, signature=sig,
-                                background=self.fixed_background)
+                                background=bg_host, uniform=uni_host)
         if fr is None:
             return None
         g.optimizer.skip_flag_ptr = None
@@ -261,7 +281,8 @@ class TrainingLoop:
         g, opt = self.gaussians, self.opt
         rank, world = dist.get_rank(), dist.get_world_size()
         # one view, one background, one alignment jitter: every rank uses rank 0's draws (the fused path does the same)
-        bg, uniform = self._shared_draws(torch.rand(3, device=g._xyz.device))
+        bg, uniform = self._shared_draws((torch.rand(3) if self.fixed_background is None
+                                          else self.fixed_background.detach().float().cpu()).to(g._xyz.device))
         r = self.motion.query(cam_idx=cam_idx, subframe_indice=subframe_indice, compute_blurred=False,
                               shard=(rank, world), background=bg, uniform=uniform)
         gt = self._ground_truth(cam_idx, r["gt"], iteration)
@@ -321,7 +342,9 @@ class TrainingLoop:
                     if self.distributed:                # the split's normal draws must be the same on every rank
                         gen = torch.Generator(device=g._xyz.device)
                         gen.manual_seed(1_000_003 * int(iteration) + 17)
-                    g.densify_and_prune(densification_threshold, self.extent, generator=gen)
+                    g.densify_and_prune(densification_threshold, self.extent, generator=gen,
+                                        noise=None if self.split_noise_fn is None else
+                                        (lambda m_sel, _it=iteration: self.split_noise_fn(_it, m_sel)))
                     if self._fused is not None:      # the cloud changed size: learn the duplicate counts afresh
                         self._fused.invalidate()
                 if not makeup and (iteration % opt.opacity_reset_interval == 0 or

@@ -215,6 +215,16 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t n
 int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream);
 /* Replaces Rasterizer::backward (rasterizer_impl.cu:350-463). */
 int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream);
+/* dgs_backward in three parts, for callers that overlap the gradient all-reduce of a sharded run with the backward's
+ * tail: dgs_backward_composite (compositing backward + per-(subframe, Gaussian) totals), then dgs_backward_geometry for
+ * consecutive Gaussian-index chunks [g_begin, g_end) (g_begin a multiple of 256; each call writes exactly those rows of
+ * the per-Gaussian outputs, so chunk i can be all-reduced on another stream while chunk i + 1 runs), then
+ * dgs_backward_pose (dL_dviewmatrix / dL_dprojmatrix from the partial sums all chunks left).  Bit-identical to
+ * dgs_backward for any chunking. */
+int dgs_backward_composite(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream);
+int dgs_backward_geometry(const DgsProblem* p, const DgsBackwardIO* io, int32_t g_begin, int32_t g_end,
+                          dgs_stream_t stream);
+int dgs_backward_pose(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream);
 /* Replaces Rasterizer::markVisible (rasterizer_impl.cu:141-153); present is bool[P] as bytes. */
 int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, dgs_stream_t stream);

@@ -55,7 +55,7 @@ def quat_to_rotmat(q):
 
 def preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, sh=None,
                colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, sh_degree=0,
-               scale_modifier=1.0, use_sigmoid=False):
+               scale_modifier=1.0, use_sigmoid=False, pix_offset=None):
     dt = means3D.dtype
     P = means3D.shape[0]
     V = viewmatrix.reshape(4, 4)   # row-vector convention: p_view = [p,1] @ V
@@ -98,6 +98,8 @@ def preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx
     disc = torch.sqrt(torch.clamp(mid * mid - det, min=0.1))
     radius = torch.ceil(3.0 * torch.sqrt(torch.maximum(mid + disc, mid - disc))).detach()
     pix = torch.stack([((p_proj[:, 0] + 1.0) * W - 1.0) * 0.5, ((p_proj[:, 1] + 1.0) * H - 1.0) * 0.5], 1)
+    if pix_offset is not None:     # a zero [P,2] leaf: its .grad is dL/d(pixel-space mean), the reference's means2D carrier
+        pix = pix + pix_offset     # before the 0.5 W / 0.5 H NDC scaling of backward.cu:535-536
     gx, gy = (W + 15) // 16, (H + 15) // 16
     pd, rd = pix.detach(), radius
     minx = torch.clamp(torch.trunc((pd[:, 0] - rd) / 16), 0, gx)

@@ -384,7 +384,7 @@ ILL_ROW = 1e-3         # a Gaussian is ill-conditioned for a chain output when t
                        # (fp32 vs double accumulation; FMA contraction on vs off) differ by more than this on its row
 ILL_FRAC = 5e-4        # at most this fraction of the Gaussians that receive a gradient may be ill-conditioned (+ ILL_MIN)
 ILL_MIN = 2
-POSE_NOISE_MULT = 2.0  # dL_dviewmatrix sums the chain over ALL Gaussians, the ill-conditioned ones included
+POSE_NOISE_MULT = 4.0  # dL_dviewmatrix sums the chain over ALL Gaussians, the ill-conditioned ones included
 
 
 def row_errors(a, b, floor=ROW_FLOOR):
@@ -399,9 +399,9 @@ def row_errors(a, b, floor=ROW_FLOOR):
     return dn.max(axis=1) / np.maximum(bn.max(axis=1), floor), dn.max(axis=1), colmax
 
 
-WELL_ROW = 1e-4        # end to end, a chain output is held to the flat bars on the Gaussians whose row two correct fp32 builds
+WELL_ROW = 5e-5        # end to end, a chain output is held to the flat bars on the Gaussians whose row two correct fp32 builds
                        # of the reference (fp32 vs double accumulation, FMA contraction on vs off) move by less than this
-WELL_FRAC = 0.97       # ... and those must be (at least) this fraction of the Gaussians that receive a gradient
+WELL_FRAC = 0.99       # ... and those must be (at least) this fraction of the Gaussians that receive a gradient
 REPORT_ONLY = os.environ.get("DGS_PARITY_REPORT", "0") == "1"
 
 
@@ -414,7 +414,7 @@ def _check(cond, msg, failures):
 
 
 def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, floor=ROW_FLOOR, report=None, row_tol=ROW_TOL, ill_frac=ILL_FRAC,
-                       ill_min=ILL_MIN):
+                       ill_min=ILL_MIN, well_frac=WELL_FRAC):
     """hip[key] against ora["double"][key] with FLAT bars: every gradient component (column) within `tol` = 1e-4 of its
     own largest magnitude, every Gaussian (row) within `row_tol` = 1e-3 of its own gradient (floored at `floor` x the
     column scale); pose matrices per [4,4] matrix relative to its largest entry.
@@ -483,7 +483,7 @@ def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, floor=ROW_FLOOR, report=Non
         _check(ill.sum() <= ill_min + ill_frac * active,
                f"{key}: {int(ill.sum())} of {active} Gaussians are ill-conditioned (two fp32 builds of the reference differ "
                f"by more than {ILL_ROW} on their row)", failures)
-        _check(rep["well_frac"] >= WELL_FRAC, f"{key}: only {rep['well_frac']:.4f} of the Gaussians are well-conditioned", failures)
+        _check(rep["well_frac"] >= well_frac, f"{key}: only {rep['well_frac']:.4f} of the Gaussians are well-conditioned", failures)
         _check(col <= tol, f"{key} col on well-conditioned rows: {col:.2e} > {tol:.0e}", failures)
         _check(row <= row_tol, f"{key} row on well-conditioned rows: {row:.2e} > {row_tol:.0e}", failures)
     if REPORT_ONLY and failures:

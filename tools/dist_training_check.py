@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--same-seed", action="store_true",
                     help="seed every rank identically per iteration (only for comparing a 1-rank with an N-rank run)")
     ap.add_argument("--random-sample", action="store_true", help="curve_random_sample on (alignment jitter)")
+    ap.add_argument("--ar-chunks", type=int, default=1,
+                    help="all-reduce the gradient bucket in this many Gaussian-index chunks, overlapped with the backward")
     return ap.parse_args()
 
 
@@ -80,7 +82,8 @@ def main():
         iterations=args.iters + 10, curve_start_iter=args.curve_start, densify_from_iter=far if args.no_densify else 5,
         densification_interval=6, densify_until_iter=args.iters - 3, densify_grad_threshold_init=2e-5,
         densify_grad_threshold_final=1e-5, opacity_reset_interval=1000, curve_alignment_lr=1e-3, curve_alignment_start=4)
-    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=args.mode if world > 1 else False)
+    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=args.mode if world > 1 else False,
+                        ar_chunks=args.ar_chunks)
     inplace = []
     _orig = sharding.flat_allreduce_grads
 

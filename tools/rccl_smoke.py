@@ -16,7 +16,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 
 
-def train(mode, iters=12):
+def train(mode, iters=12, ar_chunks=1):
     import torch
     from deblurgs_amd import synthetic
     from deblurgs_amd.cloud import GaussianCloud
@@ -38,7 +38,7 @@ def train(mode, iters=12):
                                       densify_grad_threshold_init=2e-5, densify_grad_threshold_final=1e-5,
                                       opacity_reset_interval=1000, curve_alignment_lr=1e-3, curve_alignment_start=4,
                                       lambda_depth_tv=0.01)
-    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=mode)
+    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=mode, ar_chunks=ar_chunks)
     for it in range(1, iters + 1):
         torch.manual_seed(it)
         loop.step(it, it % 2)
@@ -78,6 +78,11 @@ def main():
             assert a.shape == b.shape and torch.equal(a, b), f"mode {mode}: parameter {i} changed by a one-rank collective"
         print(f"rccl smoke: mode {mode}: {len(got)} parameter tensors bit-identical with and without the collectives",
               flush=True)
+        # the chunked, overlapped reduction of the gradient bucket (coalesced RCCL group calls on a side stream)
+        got = train(mode, ar_chunks=4)
+        for i, (a, b) in enumerate(zip(base, got)):
+            assert a.shape == b.shape and torch.equal(a, b), f"mode {mode}, 4 chunks: parameter {i} changed"
+        print(f"rccl smoke: mode {mode}: 4-chunk overlapped all-reduce bit-identical too", flush=True)
     dist.barrier()
     dist.destroy_process_group()
     print("rccl smoke ok: backend nccl, world 1", flush=True)
