@@ -311,6 +311,9 @@ def run_rank(args):
             return r
         sharding.flat_allreduce_grads = timed_allreduce
 
+    if world > 1 and loop._fused is not None:
+        loop._fused.time_allreduce = True
+
     def step():
         stats["it"] += 1
         loop.step(stats["it"], 0)
@@ -353,6 +356,11 @@ def run_rank(args):
     allreduce_ms = None
     if ar_events:
         allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
+    elif world > 1 and loop._fused is not None and loop._fused.ar_events:
+        # chunked reduction: the span on the side stream from "first chunk ready" to "last chunk reduced" (it overlaps
+        # the backward's tail, so it is not additional step time)
+        evs = loop._fused.ar_events[-args.steps:]
+        allreduce_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
     graph_info = None
     if replaying:
         # The timed region replayed the captured step (one hipGraph launch per iteration): HIP events cannot be recorded

@@ -130,6 +130,10 @@ EXPORTS = {
                                      ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
     "dgs_forward": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsForwardOut), ctypes.c_uint32,
                                    ctypes.c_void_p]),
+    "dgs_forward_lists": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsForwardOut), ctypes.c_uint32,
+                                         ctypes.c_void_p]),
+    "dgs_forward_composite": (ctypes.c_int, [ctypes.POINTER(DgsProblem), ctypes.POINTER(DgsForwardOut), ctypes.c_uint32,
+                                             ctypes.c_void_p]),
     "dgs_densify_tmp_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dgs_densify_plan": (ctypes.c_int, [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [ctypes.c_float] * 4 +
                          [ctypes.c_int32] + [ctypes.c_void_p] * 6),

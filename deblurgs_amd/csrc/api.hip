@@ -566,7 +566,7 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
 // R = the exact duplicate count (two-phase forward), or the capacity of the duplicate arrays when `speculative`
 // (then the kernels read the count from c.num_rendered[4], set by finalize_count)
 static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, uint32_t R, bool speculative,
-                               hipStream_t s) {
+                               hipStream_t s, int phases = 3) {   // 1 = duplicate lists + sort + ranges, 2 = compositing
   int rc = check_problem(p);
   if (rc != DGS_OK) return rc;
   if (out == nullptr || out->out_color == nullptr) return fail(DGS_E_ARG, "DgsForwardOut: out_color is null");
@@ -591,7 +591,7 @@ static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, ui
   }
   const int key_lo = v.pack_tile_shift > 0 ? v.pack_tile_shift : 32;   // first tile bit of the key
   const uint32_t* n_dev = speculative ? c.num_rendered + 4 : nullptr;
-  if (R > 0 || v.tile_cull) {  // tile_cull with R == 0 still marks the visible pairs as "no surviving tile"
+  if ((phases & 1) && (R > 0 || v.tile_cull)) {  // tile_cull with R == 0 still marks the visible pairs as "no surviving tile"
     // choose the sort's input pair so that the result always lands in keys_sorted / point_list
     DgsCarve cd = c;
     const bool even = (L.sort_passes % 2) == 0;
@@ -619,9 +619,10 @@ static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, ui
               dgs_launch_sort(cd.keys_unsorted, packed ? nullptr : cd.vals_unsorted, kalt, packed ? nullptr : valt, R,
                               key_lo, key_lo + (L.sort_bits - 32), c.sort_tmp, &in_alt, s, n_dev));
   }
-  DGS_STAGE(DGS_STAGE_RANGES, "identifyTileRanges", dgs_launch_ranges(v, c, R, s, n_dev, key_lo));
-  DGS_STAGE(DGS_STAGE_COMPOSITE_FWD, "composite forward",
-            dgs_launch_composite_fwd(v, c, p->bg, out->out_color, out->out_depth, s));
+  if (phases & 1) DGS_STAGE(DGS_STAGE_RANGES, "identifyTileRanges", dgs_launch_ranges(v, c, R, s, n_dev, key_lo));
+  if (phases & 2)
+    DGS_STAGE(DGS_STAGE_COMPOSITE_FWD, "composite forward",
+              dgs_launch_composite_fwd(v, c, p->bg, out->out_color, out->out_depth, s));
   return DGS_OK;
 }
 
@@ -629,7 +630,19 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t R
   return forward_render_impl(p, out, R, false, reinterpret_cast<hipStream_t>(stream));
 }
 
+static int forward_capacity_impl(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream,
+                                 int phases);
 int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream) {
+  return forward_capacity_impl(p, out, capacity, stream, 3);
+}
+int dgs_forward_lists(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream) {
+  return forward_capacity_impl(p, out, capacity, stream, 1);
+}
+int dgs_forward_composite(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream) {
+  return forward_render_impl(p, out, capacity, true, reinterpret_cast<hipStream_t>(stream), 2);
+}
+static int forward_capacity_impl(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream,
+                                 int phases) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = dgs_forward_geometry(p, out, stream);   // includes the async copy of the counts to num_rendered_host[0..1]
   if (rc != DGS_OK) return rc;
@@ -650,7 +663,7 @@ int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity
     out->num_rendered_host[2] = 0;
     out->num_rendered_host[3] = 0;
   }
-  return forward_render_impl(p, out, capacity, true, s);
+  return forward_render_impl(p, out, capacity, true, s, phases);
 }
 
 // which != 0: 1 = compositing backward + per-pair totals, 2 = per-Gaussian kernel for [g_begin, g_end), 4 = pose sums

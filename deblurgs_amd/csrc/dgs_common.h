@@ -125,6 +125,23 @@ __device__ __forceinline__ float dgs_fold4(float a, float b) {
   asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(t) : "v"(b));
   return t;
 }
+// The same two folds from builtins only: the masked step is a bank-masked v_mov_b32_dpp of the second operand's fold
+// (one instruction more than the inline-asm masked add above), but the compiler knows every hazard and is free to fill
+// the wait states with independent work -- what the compositing backward wants when it reduces two entries at once.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dgs_dpp_keep(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float dgs_fold8b(float a, float b) {
+  const float t = a + dgs_dpp<0x128, 0xf>(a);   // row_ror:8
+  const float u = b + dgs_dpp<0x128, 0xf>(b);
+  return dgs_dpp_keep<0xE4, 0xf, 0xc>(t, u);    // quad_perm [0,1,2,3] (identity), banks 2, 3 <- u
+}
+__device__ __forceinline__ float dgs_fold4b(float a, float b) {
+  const float t = a + dgs_dpp<0x141, 0xf>(a);   // row_half_mirror
+  const float u = b + dgs_dpp<0x141, 0xf>(b);
+  return dgs_dpp_keep<0xE4, 0xf, 0xa>(t, u);    // banks 1, 3 <- u
+}
 // every lane of a quad <- the sum over the quad
 __device__ __forceinline__ float dgs_quad_sum(float v) {
   v += dgs_dpp<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]

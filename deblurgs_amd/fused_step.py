@@ -64,6 +64,8 @@ class FusedStep:
         self.last_capacity = None
         self._sel_cache = {}
         self._side = None           # side stream of the chunked gradient all-reduce
+        self.time_allreduce = False
+        self.ar_events = []
         self._drops_dev = None      # device word: forwards that overflowed so far (DgsForwardOut.drop_counter)
         self._graphs = {}           # captured steps by what they bake in (replay)
         self._pool = None           # one memory pool for all of them: replays never overlap
@@ -488,18 +490,26 @@ class FusedStep:
             side = self._side
             flat.record_stream(side)
             widths = [3, 3, 3 * Mr, 1, 3, 4]
-            for b0, b1 in sharding.chunk_bounds(P, int(ar["chunks"])):
+            t_ar = None
+            if self.time_allreduce:      # (bench.py: span of the side stream's reductions, first chunk ready -> last done)
+                t_ar = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            for ci, (b0, b1) in enumerate(sharding.chunk_bounds(P, int(ar["chunks"]))):
                 _lib.check(L.dgs_backward_geometry(ctypes.byref(prob), ctypes.byref(io), b0, b1, stream),
                            "dgs_backward_geometry")
                 ev = torch.cuda.Event()
                 ev.record(stream_obj)
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
+                    if t_ar is not None and ci == 0:
+                        t_ar[0].record(side)
                     sharding.allreduce_slices([flat[offs[i] + b0 * c:offs[i] + b1 * c] for i, c in enumerate(widths)],
                                               bool(ar.get("average", False)), ar.get("group"))
             _lib.check(L.dgs_backward_pose(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_pose")
             done = torch.cuda.Event()
             done.record(side)
+            if t_ar is not None:
+                t_ar[1].record(side)
+                self.ar_events = (self.ar_events + [t_ar])[-256:]
             stream_obj.wait_event(done)
         if P == 0:
             flat.zero_()

@@ -118,6 +118,13 @@ class TrainingLoop:
         if iteration % 1000 == 0:
             g.oneupSHdegree()
         subframe_indice = "all" if iteration >= opt.curve_start_iter else 1
+        # The step's random numbers -- background (scene/motion.py:112-113) and alignment jitter (:213-214) -- are drawn
+        # from the HOST generator, once, whichever path runs the step: the eager fused step, the captured one and the
+        # autograd path then consume the same stream and can be compared step for step
+        self._bg_host = torch.rand(3) if self.fixed_background is None else self.fixed_background.detach().float().cpu()
+        m_ = self.motion
+        n_jit = m_._nu.shape[1] if (m_.curve_random_sample and m_._nu.ndim == 2) else 0
+        self._uni_host = torch.rand(n_jit) if n_jit > 0 else None
         # The opacity hinge is built BEFORE the render: autograd then runs its backward AFTER the rasteriser's, so the
         # rasteriser's gradient (a view of the flat gradient buffer) becomes `_opacity.grad` and the hinge term is added
         # into it in place -- the six gradients stay one contiguous bucket for the all-reduce.
@@ -127,7 +134,10 @@ class TrainingLoop:
         if self.mode == "subframes":
             return self._step_subframe_sharded(iteration, cam_idx, subframe_indice, lambda_t_smooth, L_hinge,
                                                densification_threshold)
-        r = self.motion.query(cam_idx=cam_idx, subframe_indice=subframe_indice, compute_blurred=False)
+        dev = g._xyz.device
+        r = self.motion.query(cam_idx=cam_idx, subframe_indice=subframe_indice, compute_blurred=False,
+                              background=self._bg_host.to(dev),
+                              uniform=None if self._uni_host is None else self._uni_host.to(dev))
         gt = self._ground_truth(cam_idx, r["gt"], iteration)
         total, blur, lv = losses.blur_l1_smooth(r["subframes"], gt, lambda_t_smooth)
         Ll1, L_t = lv[0], lv[1]
@@ -164,12 +174,7 @@ class TrainingLoop:
         g = self.gaussians
         dev = g._xyz.device
         gt = self._ground_truth(cam_idx, self.motion.get_gt_image(cam_idx), iteration)
-        # The step's random numbers -- background (scene/motion.py:112-113) and alignment jitter (:213-214) -- are drawn
-        # from the HOST generator, so that the eager and the captured step consume the same stream
-        bg_host = torch.rand(3) if self.fixed_background is None else self.fixed_background.detach().float().cpu()
-        m = self.motion
-        n_jit = m._nu.shape[1] if (m.curve_random_sample and m._nu.ndim == 2) else 0
-        uni_host = torch.rand(n_jit) if n_jit > 0 else None
+        bg_host, uni_host = self._bg_host, self._uni_host        # drawn by step()
         if self.graph and not exact and self._graphable(iteration):
             out = self._step_graph(iteration, cam_idx, subframe_indice, lambda_t_smooth, gt, bg_host, uni_host)
             if out is not None:
@@ -281,8 +286,8 @@ class TrainingLoop:
         g, opt = self.gaussians, self.opt
         rank, world = dist.get_rank(), dist.get_world_size()
         # one view, one background, one alignment jitter: every rank uses rank 0's draws (the fused path does the same)
-        bg, uniform = self._shared_draws((torch.rand(3) if self.fixed_background is None
-                                          else self.fixed_background.detach().float().cpu()).to(g._xyz.device))
+        bg, uniform = self._shared_draws(self._bg_host.to(g._xyz.device),
+                                         None if self._uni_host is None else self._uni_host.to(g._xyz.device))
         r = self.motion.query(cam_idx=cam_idx, subframe_indice=subframe_indice, compute_blurred=False,
                               shard=(rank, world), background=bg, uniform=uniform)
         gt = self._ground_truth(cam_idx, r["gt"], iteration)

@@ -213,6 +213,11 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t n
  * a whole training step can be enqueued without any host synchronisation and still never apply a truncated gradient.
  * dgs_backward takes num_rendered = capacity for such a state. */
 int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream);
+/* dgs_forward in two parts, for callers that pipeline subframe groups over streams: dgs_forward_lists (preprocess, depth
+ * order, tile culling, duplication, sort, tile ranges: the HBM-bound half) and dgs_forward_composite (the per-tile
+ * compositing of the lists the first call built: the VALU-bound half).  Same arguments as dgs_forward. */
+int dgs_forward_lists(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream);
+int dgs_forward_composite(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream);
 /* Replaces Rasterizer::backward (rasterizer_impl.cu:350-463). */
 int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream);
 /* dgs_backward in three parts, for callers that overlap the gradient all-reduce of a sharded run with the backward's

@@ -384,7 +384,7 @@ ILL_ROW = 1e-3         # a Gaussian is ill-conditioned for a chain output when t
                        # (fp32 vs double accumulation; FMA contraction on vs off) differ by more than this on its row
 ILL_FRAC = 5e-4        # at most this fraction of the Gaussians that receive a gradient may be ill-conditioned (+ ILL_MIN)
 ILL_MIN = 2
-POSE_NOISE_MULT = 4.0  # dL_dviewmatrix sums the chain over ALL Gaussians, the ill-conditioned ones included
+POSE_NOISE_MULT = 2.0  # dL_dviewmatrix sums the chain over ALL Gaussians, the ill-conditioned ones included
 
 
 def row_errors(a, b, floor=ROW_FLOOR):
@@ -428,18 +428,22 @@ def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, floor=ROW_FLOOR, report=Non
         well-conditioned Gaussians must be >= WELL_FRAC of those that receive a gradient; the Gaussians above ILL_ROW
         are counted against ill_min + ill_frac x active and reported by index; in between nothing is asserted but
         finiteness (their error is reported next to their noise).
-      * dL_dviewmatrix sums the chain over all Gaussians including the ill-conditioned ones: max(tol, POSE_NOISE_MULT x
-        the same noise for that matrix)."""
+      * dL_dviewmatrix is a sum of ~P signed per-Gaussian terms that cancel to a small total, the ill-conditioned Gaussians
+        included: max(tol, POSE_NOISE_MULT x the largest difference between two fp32 builds of the reference over the K
+        matrices of the problem).  (The HIP path adds these terms in double beyond the 64-lane wave sums.)"""
     failures = []
     for key in keys:
         b, n, f = ora["double"][key], ora["f32"][key], ora["fma"][key]
         a = np.asarray(hip[key], np.float64).reshape(b.shape)
         _check(np.isfinite(a).all(), f"{key}: not finite", failures)
         if key in ("dL_dviewmatrix", "dL_dprojmatrix"):
+            # one noise level for the K matrices of a problem: the largest difference between two fp32 builds of the
+            # reference over the subframes (the per-subframe values are single samples of the same rounding process)
+            en = max(max(relerr(n[k], b[k]), relerr(f[k], b[k])) for k in range(b.shape[0]))
             for k in range(b.shape[0]):
-                e, en = relerr(a[k], b[k]), max(relerr(n[k], b[k]), relerr(f[k], b[k]))
+                e = relerr(a[k], b[k])
                 if report is not None:
-                    report.append((key, k, {"vs_oracle": e, "oracle_noise": en}))
+                    report.append((key, k, {"vs_oracle": e, "oracle_noise_max_k": en}))
                 bar = tol if key == "dL_dprojmatrix" else max(tol, POSE_NOISE_MULT * en)
                 _check(e <= bar, f"{key}[{k}]: {e:.2e} (bar {bar:.2e}, oracle noise {en:.2e})", failures)
             continue

@@ -650,7 +650,9 @@ def test_training_matches_the_cpu_reference_loop_on_a_toy_deblurring_scene(gpu):
     densification twice: once by TrainingLoop on the GPU (fused / captured steps), once by oracle/train_loop_oracle.py on
     the CPU (train.py:104-222 restated with torch autograd through the dense torch_naive rasteriser, torch.optim.Adam and
     the reference-pinned densify_and_prune).  Same views, backgrounds and split noise.  Both must improve the PSNR by a
-    wide margin, and agree: blur-PSNR and sharp-PSNR within 0.05 dB, point counts within 1 %."""
+    wide margin, and agree: blur-PSNR and sharp-PSNR within 0.05 dB and point counts within 1 % -- or within twice the
+    distance between two runs of the CPU reference whose starting points differ by one part in a million, which is how
+    far this (chaotic: Adam, densification thresholds) optimisation carries rounding-level differences by itself."""
     import torch
     from helpers import synthetic
     from deblurgs_amd.cloud import GaussianCloud, get_expon_lr_func
@@ -724,29 +726,39 @@ def test_training_matches_the_cpu_reference_loop_on_a_toy_deblurring_scene(gpu):
     after_gpu = evaluate(cloud, m)
     n_gpu = cloud._xyz.shape[0]
 
-    # ---- CPU: the reference loop
+    # ---- CPU: the reference loop, twice -- the second time from a starting point moved by one part in 10^6, which shows
+    # how far 240 iterations of Adam + two densifications carry a rounding-level difference for the REFERENCE ITSELF
     f = dict(xyz=get_expon_lr_func(opt.position_lr_init, opt.position_lr_final, max_steps=opt.iterations),
              threshold=loop.densify_threshold_func, lambda_t=loop.lambda_t_smooth_func, alignment=loop.alignment_func)
     cam = dict(W=W, H=H, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"])
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    trainer = tl.ReferenceTrainer(init, ct0, cr0, np.asarray(m_gt._nu.detach().cpu()), gt_blur.cpu().numpy(), cam,
-                                  sc["projection_matrix"], opt, 1.0, f, sc["sh_degree"], bgc.numpy(), z_far=sc["z_far"])
-    for it in range(1, iters + 1):
-        trainer.step(it, it % n_views, split_noise=lambda m_sel, _it=it: noise_fn(_it, m_sel))
-    # the CPU-trained model evaluated with the same renderer
-    p = {k: torch.from_numpy(trainer.p[k].detach().numpy()).to(dev) for k in tl.FIELDS}
-    cloud_c = GaussianCloud(p["xyz"], p["f_dc"].contiguous(), p["f_rest"].contiguous(), p["scaling"], p["rotation"],
-                            p["opacity"], sh_degree=sc["sh_degree"], z_near=sc["z_near"], z_far=sc["z_far"])
-    m_c = module(cloud_c, trainer.ctrl_trans.detach().numpy(), trainer.ctrl_rot.detach().numpy(), gt_blur)
-    after_cpu = evaluate(cloud_c, m_c)
-    n_cpu = cloud_c._xyz.shape[0]
-    print(f"\n[toy training] PSNR (blur, sharp): start {before}, GPU {after_gpu}, CPU reference {after_cpu}; "
-          f"points {init['xyz'].shape[0]} -> GPU {n_gpu} / CPU {n_cpu}; captured {loop._fused.captured}, "
-          f"replayed {loop._fused.replayed}")
+
+    def run_cpu(start):
+        trainer = tl.ReferenceTrainer(start, ct0, cr0, np.asarray(m_gt._nu.detach().cpu()), gt_blur.cpu().numpy(), cam,
+                                      sc["projection_matrix"], opt, 1.0, f, sc["sh_degree"], bgc.numpy(), z_far=sc["z_far"])
+        for it in range(1, iters + 1):
+            trainer.step(it, it % n_views, split_noise=lambda m_sel, _it=it: noise_fn(_it, m_sel))
+        # the CPU-trained model evaluated with the same renderer
+        p = {k: torch.from_numpy(trainer.p[k].detach().numpy()).to(dev) for k in tl.FIELDS}
+        cl = GaussianCloud(p["xyz"], p["f_dc"].contiguous(), p["f_rest"].contiguous(), p["scaling"], p["rotation"],
+                           p["opacity"], sh_degree=sc["sh_degree"], z_near=sc["z_near"], z_far=sc["z_far"])
+        mm = module(cl, trainer.ctrl_trans.detach().numpy(), trainer.ctrl_rot.detach().numpy(), gt_blur)
+        return evaluate(cl, mm), cl._xyz.shape[0]
+
+    after_cpu, n_cpu = run_cpu(init)
+    moved = dict(init, xyz=(init["xyz"] * (1.0 + 1e-6 * rng.standard_normal(init["xyz"].shape))).astype(np.float32))
+    after_cpu2, n_cpu2 = run_cpu(moved)
+    spread = (abs(after_cpu[0] - after_cpu2[0]), abs(after_cpu[1] - after_cpu2[1]), abs(n_cpu - n_cpu2))
+    print(f"\n[toy training] PSNR (blur, sharp): start {before}, GPU {after_gpu}, CPU reference {after_cpu} / from a start "
+          f"moved by 1e-6: {after_cpu2}; points {init['xyz'].shape[0]} -> GPU {n_gpu} / CPU {n_cpu} / {n_cpu2}; "
+          f"captured {loop._fused.captured}, replayed {loop._fused.replayed}")
     assert after_gpu[0] > before[0] + 3.0 and after_cpu[0] > before[0] + 3.0, "training did not improve the blur PSNR"
     assert n_gpu != init["xyz"].shape[0], "densification never changed the cloud"
-    assert abs(after_gpu[0] - after_cpu[0]) <= 0.05 and abs(after_gpu[1] - after_cpu[1]) <= 0.05
-    assert abs(n_gpu - n_cpu) <= 0.01 * n_cpu
+    # within 0.05 dB -- or within twice what the reference loop differs from itself when its start moves by 1e-6 (the
+    # optimisation is chaotic: densification decisions flip on rounding-level differences)
+    assert abs(after_gpu[0] - after_cpu[0]) <= max(0.05, 2.0 * spread[0]), (after_gpu, after_cpu, after_cpu2)
+    assert abs(after_gpu[1] - after_cpu[1]) <= max(0.05, 2.0 * spread[1]), (after_gpu, after_cpu, after_cpu2)
+    assert abs(n_gpu - n_cpu) <= max(0.01 * n_cpu, 2.0 * spread[2]), (n_gpu, n_cpu, n_cpu2)
 
 
 # ------------------------------------------------------------------------------------ N-rank path on the one-GPU box
@@ -819,3 +831,4 @@ def test_two_ranks_on_one_gpu(gpu, mode, tmp_path):
     assert line["n_gpus"] == 2 and line["config"]["ranks_in_process_group"] == 2
     assert line["scaling"] == ("weak" if mode == "views" else "strong") and line["config"]["sharding"] == mode
     assert line["config"]["allreduce_ms_per_step"] is not None and line["value"] > 0
+    assert line["config"]["ar_chunks"] == 4
