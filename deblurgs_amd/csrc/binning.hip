@@ -162,6 +162,82 @@ scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, u
   }
 }
 
+// Small and medium inputs (up to SCAN_SELF_MAX blocks = 16.7 M elements): no top kernel -- every block of the apply
+// pass adds up the sums of the blocks before it by itself (a few KB from L2), the last block publishes the 64-bit grand
+// total.  One launch less per scan; at DeblurGS-sized scenes a scan is three few-microsecond kernels, so that is a third
+// of its cost.
+constexpr uint32_t SCAN_SELF_MAX = 4096;
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_apply_self_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
+                       const uint32_t* __restrict__ block_sums, uint32_t nb, uint32_t* __restrict__ total) {
+  __shared__ uint32_t lds[8];
+  __shared__ unsigned long long s_wide[SCAN_THREADS / 64];
+  __shared__ uint32_t s_base;
+  // exclusive offset of this block = sum of block_sums[0 .. blockIdx.x)
+  unsigned long long mine = 0;
+  const uint32_t upto = (blockIdx.x == nb - 1 && total != nullptr) ? nb : blockIdx.x;   // the last block also needs all
+  for (uint32_t i = threadIdx.x; i < upto; i += SCAN_THREADS) mine += block_sums[i];
+  for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor((long long)mine, d, 64);
+  if (dgs_lane() == 0) s_wide[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long all = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; w++) all += s_wide[w];
+    if (blockIdx.x == nb - 1 && total != nullptr) {
+      total[0] = (uint32_t)all;
+      total[1] = (uint32_t)(all >> 32);
+      all -= block_sums[nb - 1];
+    }
+    s_base = (uint32_t)all;
+  }
+  __syncthreads();
+  const uint32_t block_base = s_base;
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t vals[SCAN_ITEMS];
+  uint32_t s = 0;
+  if (base + SCAN_ITEMS <= n) {
+    const uint4* p = reinterpret_cast<const uint4*>(in + base);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS / 4; i++) {
+      uint4 q = p[i];
+      vals[4 * i] = q.x;
+      vals[4 * i + 1] = q.y;
+      vals[4 * i + 2] = q.z;
+      vals[4 * i + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) vals[i] = (base + i < n) ? in[base + i] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) s += vals[i];
+  uint32_t tot;
+  uint32_t pre = block_excl_scan(s, &tot, lds) + block_base;
+  if (base + SCAN_ITEMS <= n) {
+    uint4* p = reinterpret_cast<uint4*>(out + base);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS / 4; i++) {
+      uint4 q;
+      q.x = pre;
+      pre += vals[4 * i];
+      q.y = pre;
+      pre += vals[4 * i + 1];
+      q.z = pre;
+      pre += vals[4 * i + 2];
+      q.w = pre;
+      pre += vals[4 * i + 3];
+      p[i] = q;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+      if (base + i < n) out[base + i] = pre;
+      pre += vals[i];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ depth-ordered duplication
 // The duplicates only need a STABLE sort by (k, tile) if they are generated in (k, depth, index) order: the
 // low 32 key bits (depth) are then already in order inside every (k, tile) group, exactly as if the LSD passes
@@ -861,8 +937,12 @@ dsort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t P, uint32_t nb, in
 }
 
 // (segment, chunk): per digit, exclusive running count over the chunk's blocks (in place) and the chunk total
+// fuse_top (nch == 1, i.e. segments of up to DS_CHUNK * DS_TILE = 131072 pairs): the chunk total IS the digit's count in
+// the segment, so the digit bases are formed right here and the top kernel is not launched
 __global__ void __launch_bounds__(DS_BINS)
-dsort_colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nb, uint32_t nch, uint32_t* __restrict__ ctot) {
+dsort_colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nb, uint32_t nch, uint32_t* __restrict__ ctot,
+                           int fuse_top, uint32_t P) {
+  __shared__ uint32_t lds[8];
   const uint32_t k = blockIdx.x / nch, c = blockIdx.x - k * nch;
   const uint32_t t0 = c * DS_CHUNK, t1 = min(t0 + (uint32_t)DS_CHUNK, nb);
   uint32_t* base = table + ((size_t)k * nb) * DS_BINS + threadIdx.x;
@@ -877,6 +957,10 @@ dsort_colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nb, uint32_t n
       if (t + u < t1) base[(size_t)(t + u) * DS_BINS] = run;
       run += v[u];
     }
+  }
+  if (fuse_top) {
+    uint32_t tot;
+    run = block_excl_scan(run, &tot, lds) + k * P;   // (what dsort_colscan_top_kernel leaves for the only chunk)
   }
   ctot[(size_t)blockIdx.x * DS_BINS + threadIdx.x] = run;
 }
@@ -1030,6 +1114,11 @@ hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32
   }
   const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((uint32_t)nb), dim3(SCAN_THREADS), 0, s, in, n, tmp);
+  if (nb <= SCAN_SELF_MAX) {
+    hipLaunchKernelGGL(scan_apply_self_kernel, dim3((uint32_t)nb), dim3(SCAN_THREADS), 0, s, in, out, n, tmp, (uint32_t)nb,
+                       total);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, tmp, nb, total);
   hipLaunchKernelGGL(scan_apply_kernel, dim3((uint32_t)nb), dim3(SCAN_THREADS), 0, s, in, out, n, tmp);
   return hipGetLastError();
@@ -1215,8 +1304,8 @@ hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* o
   for (int pass = 0; pass < 4; pass++) {
     const int shift = 8 * pass;
     hipLaunchKernelGGL(dsort_hist_kernel, grid, dim3(DS_THREADS), 0, s, kin, P, nb, shift, table);
-    hipLaunchKernelGGL(dsort_colscan_chunk_kernel, cgrid, dim3(DS_BINS), 0, s, table, nb, nch, ctot);
-    hipLaunchKernelGGL(dsort_colscan_top_kernel, dim3((uint32_t)K), dim3(DS_BINS), 0, s, ctot, nch, P);
+    hipLaunchKernelGGL(dsort_colscan_chunk_kernel, cgrid, dim3(DS_BINS), 0, s, table, nb, nch, ctot, nch == 1 ? 1 : 0, P);
+    if (nch > 1) hipLaunchKernelGGL(dsort_colscan_top_kernel, dim3((uint32_t)K), dim3(DS_BINS), 0, s, ctot, nch, P);
     if (pass == 0)
       hipLaunchKernelGGL((dsort_scatter_kernel<true, false>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P, nb,
                          nch, shift, table, ctot, gather_src, gather_dst);

@@ -218,10 +218,16 @@ __device__ __forceinline__ float dgs_edge_min_y(const DgsCull& g, float e, float
 __device__ __forceinline__ bool dgs_cull_hit(const DgsCull& g, float dx_lo, float dx_hi, float dy_lo, float dy_hi) {
   if (g.always) return true;
   if (g.never) return false;
-  const bool inside = (dx_lo <= 0.0f) && (dx_hi >= 0.0f) && (dy_lo <= 0.0f) && (dy_hi >= 0.0f);
-  float qm = fminf(fminf(dgs_edge_min_x(g, dx_lo, dy_lo, dy_hi), dgs_edge_min_x(g, dx_hi, dy_lo, dy_hi)),
-                   fminf(dgs_edge_min_y(g, dy_lo, dx_lo, dx_hi), dgs_edge_min_y(g, dy_hi, dx_lo, dx_hi)));
-  qm = inside ? 0.0f : qm;
+  // q is convex with its minimum (0) at the origin: over a box that does not contain the origin, the minimum lies on a
+  // face that is VISIBLE from the origin (from the minimiser, q decreases along the segment towards the origin, so that
+  // segment leaves the box through the face the minimiser sits on).  At most one x-face and one y-face are visible:
+  // two clamped 1-D minimisations instead of four.
+  const bool x_out = (dx_lo > 0.0f) || (dx_hi < 0.0f), y_out = (dy_lo > 0.0f) || (dy_hi < 0.0f);
+  const float ex = (dx_lo > 0.0f) ? dx_lo : dx_hi, ey = (dy_lo > 0.0f) ? dy_lo : dy_hi;
+  const float qx = dgs_edge_min_x(g, ex, dy_lo, dy_hi), qy = dgs_edge_min_y(g, ey, dx_lo, dx_hi);
+  const float big = __int_as_float(0x7f800000);
+  float qm = fminf(x_out ? qx : big, y_out ? qy : big);
+  qm = (x_out || y_out) ? qm : 0.0f;     // origin inside the box
   return !(qm * 0.9999f > g.r2);  // NaN -> keep
 }
 

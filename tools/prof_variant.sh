@@ -11,7 +11,7 @@ mkdir -p $out
 if [ "$mode" == "pmc" ]; then
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE -d $out/pmc -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists > $out/pmc.log 2>&1
 else
-  rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-reference-lists > $out/trace.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-reference-lists $DGS_BENCH_EXTRA > $out/trace.log 2>&1
   f=$(find $out/trace -name "*kernel_stats.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv, sys
