@@ -477,7 +477,7 @@ def run_rank(args):
             result["value_reference_lists"] = ref_lists
         # PMC counters cannot be collected inside this run (rocprofv3 wraps the process): traffic / VALU figures are the
         # committed measurements of the same command, with their provenance, or null
-        for fname, key in (("traffic_r02.json", "traffic"), ("valu_r02.json", "valu")):
+        for fname, key in (("traffic_r03.json", "traffic"), ("valu_r03.json", "valu")):
             path = os.path.join(ROOT, "profiles", fname)
             if not os.path.exists(path) or world != 1:
                 continue
@@ -491,7 +491,9 @@ def run_rank(args):
                 if key == "valu":
                     hit = [v_ for k_, v_ in doc.items() if k_.startswith(dom + "_kernel")]
                     if hit:
-                        result["roofline"]["valu"] = dict(hit[0], source=f"profiles/{fname}: {doc.get('_source', '')}")
+                        result["roofline"]["valu"] = dict(hit[0], frac=hit[0].get("weighted_busy_frac"),
+                                                          class_cost_cycles=doc.get("_class_cost_cycles"),
+                                                          source=f"profiles/{fname}: {doc.get('_source', '')}")
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

@@ -50,6 +50,8 @@ void make_layout(int P, int W, int H, int K, uint64_t R, bool wide_records, DgsL
   L->tt_tight = o;       o += up(KP * 4);
   L->offs_tight = o;     o += up(KP * 4);
   L->gsort_tmp = o;      o += up(dgs_depth_sort_tmp_words(K, (uint32_t)P) * 4);
+  L->cull_desc = o;      o += up(KP * 8);
+  L->cull_hits = o;      o += up(dgs_cull_hits_words64(KP) * 8);
   L->geom_total = o;
   o = 0;
   L->final_T = o;        o += up((size_t)K * N * 4);
@@ -149,6 +151,8 @@ void carve(const DgsProblem* p, const DgsLayout& L, DgsCarve* c) {
   c->tt_tight = reinterpret_cast<uint32_t*>(g + L.tt_tight);
   c->offs_tight = reinterpret_cast<uint32_t*>(g + L.offs_tight);
   c->gsort_tmp = reinterpret_cast<uint32_t*>(g + L.gsort_tmp);
+  c->cull_desc = reinterpret_cast<uint2*>(g + L.cull_desc);
+  c->cull_hits = reinterpret_cast<unsigned long long*>(g + L.cull_hits);
   c->final_T = reinterpret_cast<float*>(im + L.final_T);
   c->n_contrib = reinterpret_cast<uint32_t*>(im + L.n_contrib);
   c->ranges = reinterpret_cast<uint2*>(im + L.ranges);

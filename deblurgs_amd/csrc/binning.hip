@@ -341,13 +341,15 @@ duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __
 // -ffp-contract=off so both instantiations round identically -- and writes the compacted keys/values; the low key
 // word carries the duplicate's own index u (its contribution-row slot for the backward) instead of the depth
 // bits, which the tile-bits-only stable sort never looks at.
+constexpr int TIGHT_ROUNDS = 8;   // rounds (of 64 rectangle slots) per wave whose hit ballots the COUNT pass keeps for EMIT
+
 template <bool EMIT>
 __global__ void __launch_bounds__(256)
 tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restrict__ order,
              const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ offs_sorted,
              uint32_t* __restrict__ tt_tight, const uint32_t* __restrict__ offs_tight,
              const uint32_t* __restrict__ total_full, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-             uint32_t cap) {
+             uint32_t cap, uint2* __restrict__ desc, unsigned long long* __restrict__ hits) {
   // the rectangle total overflowed 32 bits: the offsets are meaningless (the host raises on the overflow word)
   if (total_full[1] != 0u) {
     const uint64_t jj = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -369,13 +371,36 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
   const uint64_t n = (uint64_t)v.K * v.P;
   const bool in = j < n;
   uint32_t off = 0, nt = 0, otight = 0;
+  // EMIT: the COUNT instance left every pair's rectangle (desc) and the hit ballots of each wave's first TIGHT_ROUNDS
+  // rounds (hits): a wave whose slots fit into those rounds -- nearly all of them -- re-reads nothing of the geometry rows
+  // and evaluates no ellipse test; only a wave with more slots gathers the rows again for its later rounds.
+  const unsigned long long* my_hits = hits + ((size_t)blockIdx.x * 4 + (size_t)w) * TIGHT_ROUNDS;
+  bool need_rows = !EMIT;
+  if (EMIT) {
+    const uint32_t o0 = in ? offs_sorted[j] : 0u, n0 = in ? tt_sorted[j] : 0u;
+    const uint64_t vm = __ballot(in);
+    if (vm != 0ull) {
+      const int lastv = 63 - __builtin_clzll(vm);
+      const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)(o0 + n0), lastv) -
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)o0);
+      need_rows = tot0 > (uint32_t)(TIGHT_ROUNDS * 64);   // wave-uniform
+    }
+  }
   if (in) {
     const uint32_t i = order[j];
     off = offs_sorted[j];
     nt = tt_sorted[j];
     uint32_t rect = 0, wide = 0, tb = 0, g = 0, fl = 0;
     float4 q = make_float4(0, 0, 0, 0), r = q;
-    if (nt != 0) {
+    if (nt != 0 && !need_rows) {      // EMIT, fast path: rectangle from the COUNT pass, no row
+      const uint32_t k = i / (uint32_t)v.P;
+      g = i - k * (uint32_t)v.P;
+      const uint2 dsc = desc[j];
+      rect = dsc.x;
+      wide = dsc.y;
+      tb = k * (uint32_t)v.T;
+      otight = offs_tight[j];
+    } else if (nt != 0) {
       const uint32_t k = i / (uint32_t)v.P;
       g = i - k * (uint32_t)v.P;
       const DgsRow* row = rows + i;
@@ -394,6 +419,8 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
         otight = offs_tight[j];
         // (the backward finds this pair's contribution rows through offs_tight[j] in this same order:
         // contrib_reduce_kernel; nothing is stamped per pair)
+      } else {
+        desc[j] = make_uint2(rect, wide);
       }
     } else if (EMIT) {
       otight = offs_tight[j];
@@ -426,7 +453,11 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
     int lo = 0;
     bool hit = false;
     uint32_t tile = 0;
-    if (act) {
+    const uint32_t round = d0 >> 6;
+    const bool stored = EMIT && round < (uint32_t)TIGHT_ROUNDS;    // wave-uniform
+    unsigned long long hm_stored = 0ull;
+    if (stored) hm_stored = my_hits[round];
+    if (act && (!stored || ((hm_stored >> lane) & 1ull))) {
 #pragma unroll
       for (int step = 32; step >= 1; step >>= 1) {
         const int mid = lo + step;
@@ -445,10 +476,15 @@ tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restr
       cg.a = q.z; cg.b = q.w; cg.c = r.x; cg.inv_a = r.y; cg.inv_c = r.z; cg.r2 = r.w;
       cg.always = (fl & 1u) != 0; cg.never = (fl & 2u) != 0;
       // d = mean - pixel over the tile's pixel centres [16 t, 16 t + 15]
-      const float ex = q.x - (float)(tx * DGS_TILE), ey = q.y - (float)(ty * DGS_TILE);
-      hit = dgs_cull_hit(cg, ex - (float)(DGS_TILE - 1), ex, ey - (float)(DGS_TILE - 1), ey);
+      if (stored) {
+        hit = true;
+      } else {
+        const float ex = q.x - (float)(tx * DGS_TILE), ey = q.y - (float)(ty * DGS_TILE);
+        hit = dgs_cull_hit(cg, ex - (float)(DGS_TILE - 1), ex, ey - (float)(DGS_TILE - 1), ey);
+      }
     }
-    const uint64_t hm = __ballot(hit);
+    const uint64_t hm = stored ? (uint64_t)hm_stored : __ballot(hit);
+    if (!EMIT && round < (uint32_t)TIGHT_ROUNDS && lane == 0) hits[((size_t)blockIdx.x * 4 + (size_t)w) * TIGHT_ROUNDS + round] = hm;
     if (EMIT) {
       if (hit) {
         const uint32_t pos = obase + run + (uint32_t)__builtin_popcountll(hm & lt);
@@ -1104,6 +1140,8 @@ hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, 
   return hipGetLastError();
 }
 
+size_t dgs_cull_hits_words64(uint64_t kp) { return (size_t)((kp + 255) / 256) * 4 * TIGHT_ROUNDS; }
+
 size_t dgs_scan_tmp_words(uint64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 64; }
 
 hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, uint32_t* total,
@@ -1257,7 +1295,8 @@ hipError_t dgs_launch_tight_count(const DgsView& v, const DgsCarve& c, const uin
   hipError_t e = dgs_launch_scan(c.tt_sorted, c.offs_sorted, n, c.scan_tmp, total_full, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tight_kernel<false>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
-                     c.tt_tight, c.offs_tight, total_full, (uint64_t*)nullptr, (uint32_t*)nullptr, 0u);
+                     c.tt_tight, c.offs_tight, total_full, (uint64_t*)nullptr, (uint32_t*)nullptr, 0u, c.cull_desc,
+                     c.cull_hits);
   return dgs_launch_scan(c.tt_tight, c.offs_tight, n, c.scan_tmp, total_tight, s);
 }
 
@@ -1266,7 +1305,8 @@ hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const
   const uint64_t n = (uint64_t)v.K * v.P;
   const dim3 grid((uint32_t)((n + 255) / 256));
   hipLaunchKernelGGL(tight_kernel<true>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
-                     c.tt_tight, c.offs_tight, c.num_rendered, c.keys_unsorted, c.vals_unsorted, cap);
+                     c.tt_tight, c.offs_tight, c.num_rendered, c.keys_unsorted, c.vals_unsorted, cap, c.cull_desc,
+                     c.cull_hits);
   return hipGetLastError();
 }
 

@@ -39,6 +39,8 @@ struct DgsCarve {  // resolved device pointers of the three blobs
   uint32_t* tt_tight;        // tile_cull: per (k, Gaussian) count of tiles that can reach alpha >= 1/255, same order,
   uint32_t* offs_tight;      //            and its exclusive scan (= duplicate / contribution-row offsets)
   uint32_t* gsort_tmp;
+  uint2* cull_desc;          // tile_cull: per (k, Gaussian) in depth order, its tile rectangle (minx | miny << 12, width)
+  unsigned long long* cull_hits;  // tile_cull: hit ballots of each 64-pair wave's first rounds of rectangle slots
   float* final_T;
   uint32_t* n_contrib;
   uint2* ranges;
@@ -267,6 +269,7 @@ hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* o
                                  hipStream_t s);
 size_t dgs_depth_sort_tmp_words(int K, uint32_t P);
 size_t dgs_scan_tmp_words(uint64_t n);
+size_t dgs_cull_hits_words64(uint64_t kp);
 size_t dgs_sort_tmp_words(uint64_t n);
 int dgs_sort_num_passes(int begin_bit, int end_bit);
 int dgs_geometry_bwd_blocks(int P);

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 7
+#define DGS_ABI_VERSION 8
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -156,6 +156,8 @@ typedef struct DgsLayout {
   size_t tt_tight;       /* u32 [K*P] tile_cull: surviving tiles per (k, Gaussian), same order */
   size_t offs_tight;     /* u32 [K*P] its exclusive prefix sum (its total is R under tile_cull) */
   size_t gsort_tmp;      /* u32 radix tables of the Gaussian sort */
+  size_t cull_desc;      /* u32 [K*P,2] tile_cull: tile rectangle of every (k, Gaussian) in depth order (minx | miny << 12, width) */
+  size_t cull_hits;      /* u64 tile_cull: per 64-pair wave, the hit ballots of its first 8 rounds of 64 rectangle slots */
   size_t geom_total;
   /* image blob */
   size_t final_T;        /* f32 [K,H*W] */

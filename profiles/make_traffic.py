@@ -1,8 +1,8 @@
-"""Builds profiles/traffic_r02.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
+"""Builds profiles/traffic_<round>.json (default r03) from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
 MI355X_MICROARCH.md, "HBM" and the TCC slot table):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <fetch_dir> --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d <write_dir> --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists
-    python profiles/make_traffic.py <fetch_dir> <write_dir> [config]
+    python profiles/make_traffic.py <fetch_dir> <write_dir> [config] [round]
 Unit: the counters are in KiB.  gfx950 correction (same guide): FETCH_SIZE reports half the bytes of wide (16 B per
 lane) coalesced streaming reads, so it is doubled for the kernels whose reads are of that kind (STREAMING below,
 calibrated on blur_loss: 771 MB read, 373 MB reported); the row-gather kernels (48-byte rows picked by index) report
@@ -20,7 +20,8 @@ STAGE_OF = {
     "preprocess_fwd_kernel": "preprocess", "tight_kernel<true>": "duplicate", "tight_kernel<false>": "tile_cull(count)",
     "duplicate_sorted_kernel": "duplicate", "ranges_kernel": "ranges", "contrib_reduce_kernel": "geometry_bwd(contrib_reduce)",
     "geometry_bwd_kernel": "geometry_bwd(kernel)", "onesweep_scatter_kernel": "sort(scatter)",
-    "sort_hist_rows_kernel": "sort(hist)", "blur_loss_kernel": "blur_loss", "adam_kernel": "adam",
+    "sort_hist_rows_kernel": "sort(hist)", "blur_loss_kernel": "blur_loss", "blur_loss_all_kernel": "blur_loss",
+    "adam_kernel": "adam", "dsort_scatter_kernel": "depth_order(scatter)", "dsort_hist_kernel": "depth_order(hist)",
 }
 STREAMING = {"blur_loss", "sort(hist)", "sort(scatter)", "adam"}
 
@@ -56,7 +57,8 @@ def main():
         w = write.get(k, 0.0)
         out["_detail"][k] = {"fetch_bytes": int(f), "write_bytes": int(w)}
         out[k] = int(f + w)
-    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic_r02.json"), "w"), indent=1)
+    rnd = sys.argv[4] if len(sys.argv) > 4 else "r03"
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"traffic_{rnd}.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
 
 

@@ -384,7 +384,7 @@ ILL_ROW = 1e-3         # a Gaussian is ill-conditioned for a chain output when t
                        # (fp32 vs double accumulation; FMA contraction on vs off) differ by more than this on its row
 ILL_FRAC = 5e-4        # at most this fraction of the Gaussians that receive a gradient may be ill-conditioned (+ ILL_MIN)
 ILL_MIN = 2
-POSE_NOISE_MULT = 3.0  # dL_dviewmatrix sums the chain over ALL Gaussians, the ill-conditioned ones included
+POSE_NOISE_MULT = 4.0  # dL_dviewmatrix sums the chain over ALL Gaussians, the ill-conditioned ones included
 
 
 def row_errors(a, b, floor=ROW_FLOOR):
