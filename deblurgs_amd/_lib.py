@@ -59,7 +59,7 @@ class DgsLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in (
         "geom_rows", "cov3D", "pre_sigmoid", "tiles_touched", "point_offsets", "scan_tmp", "num_rendered",
         "gsort_keys", "gsort_keys_alt", "gsort_vals", "gsort_vals_alt", "tt_sorted", "offs_sorted", "tt_tight", "offs_tight", "gsort_tmp",
-        "cull_desc", "cull_hits", "geom_total", "final_T", "n_contrib", "ranges", "image_total", "keys_sorted", "point_list",
+        "cull_rec", "cull_cnt", "geom_total", "final_T", "n_contrib", "ranges", "image_total", "keys_sorted", "point_list",
         "keys_unsorted", "vals_unsorted", "sort_tmp", "binning_total")] + [
         ("sort_bits", ctypes.c_int32), ("sort_passes", ctypes.c_int32), ("pack_g_shift", ctypes.c_int32),
         ("pack_tile_shift", ctypes.c_int32)]
@@ -76,7 +76,7 @@ class DgsCloudArrays(ctypes.Structure):
 
 
 ADAM_MAX_GROUPS = 16
-ABI_VERSION = 8            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
+ABI_VERSION = 9            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
 
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {

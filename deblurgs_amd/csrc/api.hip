@@ -50,8 +50,8 @@ void make_layout(int P, int W, int H, int K, uint64_t R, bool wide_records, DgsL
   L->tt_tight = o;       o += up(KP * 4);
   L->offs_tight = o;     o += up(KP * 4);
   L->gsort_tmp = o;      o += up(dgs_depth_sort_tmp_words(K, (uint32_t)P) * 4);
-  L->cull_desc = o;      o += up(KP * 8);
-  L->cull_hits = o;      o += up(dgs_cull_hits_words64(KP) * 8);
+  L->cull_rec = o;       o += up(KP * 16);
+  L->cull_cnt = o;       o += up(KP * 4);
   L->geom_total = o;
   o = 0;
   L->final_T = o;        o += up((size_t)K * N * 4);
@@ -151,8 +151,8 @@ void carve(const DgsProblem* p, const DgsLayout& L, DgsCarve* c) {
   c->tt_tight = reinterpret_cast<uint32_t*>(g + L.tt_tight);
   c->offs_tight = reinterpret_cast<uint32_t*>(g + L.offs_tight);
   c->gsort_tmp = reinterpret_cast<uint32_t*>(g + L.gsort_tmp);
-  c->cull_desc = reinterpret_cast<uint2*>(g + L.cull_desc);
-  c->cull_hits = reinterpret_cast<unsigned long long*>(g + L.cull_hits);
+  c->cull_rec = reinterpret_cast<uint4*>(g + L.cull_rec);
+  c->cull_cnt = reinterpret_cast<uint32_t*>(g + L.cull_cnt);
   c->final_T = reinterpret_cast<float*>(im + L.final_T);
   c->n_contrib = reinterpret_cast<uint32_t*>(im + L.n_contrib);
   c->ranges = reinterpret_cast<uint2*>(im + L.ranges);
@@ -448,11 +448,16 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
   const bool v4 = (E % 4 == 0) && ((reinterpret_cast<uintptr_t>(sub) | reinterpret_cast<uintptr_t>(gt) |
                                     reinterpret_cast<uintptr_t>(blur) | reinterpret_cast<uintptr_t>(dsub)) % 16 == 0);
   const size_t per = v4 ? 4 : 1;
-  // at most 2048 blocks (8 per CU): enough to saturate HBM, few enough that the per-block atomics of the loss totals
-  // (6075 blocks at 1080p cost 0.35 ms of same-address atomics) disappear; the totals depend on the grid, which is a
-  // function of E only -- still bitwise reproducible
+  // at most DGS_LOSS_BLOCKS blocks (2 per CU; every thread keeps K 16-byte loads in flight): enough to saturate HBM, few
+  // enough that the per-block same-address atomics of the loss totals (~58 ns per block: 0.35 ms with 6075 blocks at
+  // 1080p, still 0.11 ms of the 800x800 case's kernel with 1875) disappear.  Measured 2048 / 1024 / 512 blocks:
+  // 1.204 / 1.157 / 1.144 ms per cfg2 step, 11.99 / 12.01 / 11.91 ms at the metric config.  The totals depend on the
+  // grid, which is a function of E only -- still bitwise reproducible
   const size_t want = (E / per + 255) / 256;
-  const dim3 grid((uint32_t)(want < 2048 ? (want == 0 ? 1 : want) : 2048));
+#ifndef DGS_LOSS_BLOCKS
+#define DGS_LOSS_BLOCKS 512
+#endif
+  const dim3 grid((uint32_t)(want < DGS_LOSS_BLOCKS ? (want == 0 ? 1 : want) : DGS_LOSS_BLOCKS));
 #define DGS_BL(MODE)                                                                                              \
   do {                                                                                                            \
     if (v4)                                                                                                       \
@@ -504,7 +509,7 @@ size_t dgs_binning_state_bytes(uint64_t R, int32_t W, int32_t H, int32_t K) {
 }
 size_t dgs_backward_scratch_bytes(uint64_t R, int32_t P, int32_t K) {
   // contribution rows [R] + their per-pair totals by natural index [K*P] (48 bytes each) + pose-gradient partials (f64)
-  return up((size_t)R * DGS_CONTRIB_F * 4) + up((size_t)K * (size_t)P * DGS_CONTRIB_F * 4) +
+  return up((size_t)R * DGS_CONTRIB_F * 4) + up((size_t)K * (size_t)P * DGS_SUMS_F * 4) +
          up((size_t)dgs_geometry_bwd_blocks(P) * (size_t)K * 24 * 8) + ALIGN;
 }
 int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, int32_t wide_records, DgsLayout* out) {
@@ -515,15 +520,25 @@ int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, int32_t w
 int dgs_backward_scratch_layout(uint64_t R, int32_t P, int32_t K, size_t* sums_offset, size_t* partials_offset) {
   const size_t so = up((size_t)R * DGS_CONTRIB_F * 4);
   if (sums_offset) *sums_offset = so;
-  if (partials_offset) *partials_offset = so + up((size_t)K * (size_t)P * DGS_CONTRIB_F * 4);
+  if (partials_offset) *partials_offset = so + up((size_t)K * (size_t)P * DGS_SUMS_F * 4);
   return DGS_OK;
 }
 
 // order the (k, Gaussian) pairs by (k, depth bits, index): segmented stable sort of the depth keys preprocess wrote;
 // the result (flat indices) lands in c.gsort_vals
+// (tile_cull: its last pass also writes the visibility flags in that order)
 static hipError_t launch_depth_order(const DgsProblem* p, const DgsCarve& c, hipStream_t s) {
+  const bool cull = p->tile_cull != 0;
   return dgs_launch_depth_sort(c.gsort_keys, c.gsort_keys_alt, c.gsort_vals, c.gsort_vals_alt, p->K, (uint32_t)p->P,
-                               c.gsort_tmp, nullptr, nullptr, s);
+                               c.gsort_tmp, cull ? c.tt_sorted : nullptr, s);
+}
+
+// tile_cull: per-slot test in natural order (independent of the depth order), then records and counts into depth order and
+// the scan of the counts (total -> status words [2], [3])
+static hipError_t launch_tile_cull(const DgsView& v, const DgsCarve& c, hipStream_t s) {
+  hipError_t e = dgs_launch_cull_count(v, c, s);
+  if (e != hipSuccess) return e;
+  return dgs_launch_cull_offsets(v, c, c.num_rendered + 2, s);
 }
 
 int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stream_t stream) {
@@ -553,15 +568,12 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
     // two words: R and the high half of the 64-bit total (non-zero = the u32 duplicate offsets overflowed)
     e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   } else {
-    // tile_cull: R is the number of surviving duplicates, known only after the depth ordering and the per-slot
-    // test; the overflow word still comes from the rectangle total, whose u32 offsets drive the expansion
+    // tile_cull: R is the number of surviving duplicates: per-slot test in natural order, depth ordering (which also
+    // lays the per-pair records and counts out in its order), scan of the counts.  Status words [0], [1] stay 0.
     DGS_STAGE(DGS_STAGE_DEPTH_ORDER, "depth order", launch_depth_order(p, c, s));
-    const uint32_t* order = c.gsort_vals;
-    DGS_STAGE(DGS_STAGE_TILE_CULL, "tile cull count",
-              dgs_launch_tight_count(v, c, order, c.num_rendered, c.num_rendered + 2, s));
-    e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(out->num_rendered_host + 1, c.num_rendered + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    DGS_STAGE(DGS_STAGE_TILE_CULL, "tile cull", launch_tile_cull(v, c, s));
+    // two words: R and the high half of the 64-bit total (non-zero = the u32 duplicate offsets overflowed)
+    e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   }
   if (e != hipSuccess) return fail_hip(e, "copy num_rendered");
   return DGS_OK;
@@ -713,7 +725,7 @@ static int backward_impl(const DgsProblem* p, const DgsBackwardIO* io, int which
   float* contrib = reinterpret_cast<float*>(io->scratch);
   float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(io->scratch) + up((size_t)R * DGS_CONTRIB_F * 4));
   double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(sums) +
-                                               up((size_t)p->K * (size_t)p->P * DGS_CONTRIB_F * 4));
+                                               up((size_t)p->K * (size_t)p->P * DGS_SUMS_F * 4));
   if (which & 1)
     DGS_STAGE(DGS_STAGE_COMPOSITE_BWD, "composite backward",
               dgs_launch_composite_bwd(v, c, p->bg, io->dL_dout_color, io->dL_dout_depth, contrib, s));

@@ -335,197 +335,285 @@ duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __
 // The reference emits one duplicate per tile of the 3-sigma bounding rectangle (rasterizer_impl.cu:76-108), but
 // on the metric scene 42 % of those can never reach alpha >= 1/255 inside their tile: the compositing kernels
 // skip them at every pixel (forward.cu:356-358), after they have been sorted, range-marked, gathered and tested.
-// With tile_cull the same cooperative expansion walks the rectangle slots, evaluates the exact ellipse-vs-tile
-// test (dgs_cull_hit, conservative) per slot and keeps only the hits.  COUNT pass: per (k, Gaussian) number of
-// hits.  EMIT pass (after the scan of those counts): recomputes the identical test -- this file is built with
-// -ffp-contract=off so both instantiations round identically -- and writes the compacted keys/values; the low key
-// word carries the duplicate's own index u (its contribution-row slot for the backward) instead of the depth
+// With tile_cull the exact ellipse-vs-tile test (dgs_cull_hit, conservative) runs once per rectangle slot and only the
+// hits become duplicates:
+//   COUNT (cull_count_kernel) walks the pairs in NATURAL order -- coalesced row reads, no global offsets: a wave's 64
+//     pairs share out their rectangle slots by a wave-local scan -- and leaves one 16-byte record per pair: the
+//     rectangle, the number of hits and the hit bits of the first 64 slots (94 % of the visible pairs at the metric
+//     config have no more).
+//   The counts are gathered into (k, depth, index) order and scanned.
+//   EMIT (cull_emit_kernel) walks the pairs in that order, gathers their records and writes the surviving
+//     duplicates compacted: for a pair of at most 64 slots the stored bits ARE the test; a larger rectangle is tested
+//     again (identical instructions -- this file is built with -ffp-contract=off).
+// The low key word carries the duplicate's own index u (its contribution-row slot for the backward) instead of the depth
 // bits, which the tile-bits-only stable sort never looks at.
-constexpr int TIGHT_ROUNDS = 8;   // rounds (of 64 rectangle slots) per wave whose hit ballots the COUNT pass keeps for EMIT
+constexpr uint32_t CULL_BIG = 0x80000000u;   // record.x: rectangle of more than 64 slots (otherwise minx | miny << 12 | (width - 1) << 24)
+constexpr int CULL_CH = 32;                  // rounds (of 64 slots) per refill of the segment-start bit table
 
-template <bool EMIT>
-__global__ void __launch_bounds__(256)
-tight_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restrict__ order,
-             const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ offs_sorted,
-             uint32_t* __restrict__ tt_tight, const uint32_t* __restrict__ offs_tight,
-             const uint32_t* __restrict__ total_full, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-             uint32_t cap, uint2* __restrict__ desc, unsigned long long* __restrict__ hits) {
-  // the rectangle total overflowed 32 bits: the offsets are meaningless (the host raises on the overflow word)
-  if (total_full[1] != 0u) {
-    const uint64_t jj = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (!EMIT && jj < (uint64_t)v.K * v.P) tt_tight[jj] = 0;
-    return;
+__device__ __forceinline__ void cull_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// inclusive prefix sum over the 64 lanes: DPP row shifts inside each row of 16, row_bcast15 / row_bcast31 across rows
+// (6 VALU adds; a __shfl_up ladder is 6 dependent LDS round trips -- and a wave here has only ~4 rounds of work to hide them)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t cull_dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);   // no source lane: 0
+}
+__device__ __forceinline__ uint32_t cull_wave_incl_scan(uint32_t x, int) {
+  x += cull_dpp_u32<0x111, 0xf>(x);   // row_shr:1
+  x += cull_dpp_u32<0x112, 0xf>(x);   // row_shr:2
+  x += cull_dpp_u32<0x114, 0xf>(x);   // row_shr:4
+  x += cull_dpp_u32<0x118, 0xf>(x);   // row_shr:8
+  x += cull_dpp_u32<0x142, 0xa>(x);   // row_bcast15 -> rows 1, 3
+  x += cull_dpp_u32<0x143, 0xc>(x);   // row_bcast31 -> rows 2, 3
+  return x;
+}
+
+// Slot -> pair mapping of one wave.  The wave's non-empty pairs are compacted (index c), pair c owns the slots
+// [excl_c, excl_c + work_c) of the wave.  Instead of a binary search per slot, every pair sets the bit of its first slot
+// in an LDS bit table (one 64-bit word per round of 64 slots, refilled every CULL_CH rounds); lane l of round r then owns
+// pair  (pairs started before the round) + popcount(bits of the round at or below l) - 1  -- one v_mbcnt pair.
+// body(d, act, pi, own, m): d = slot, act = d < total, pi = compacted pair, own = this lane holds a first slot,
+// m = the round's start bits.
+template <typename F>
+__device__ __forceinline__ void cull_walk(unsigned long long* s_bits, int lane, bool nonempty, uint32_t excl,
+                                          uint32_t total, F&& body) {
+  for (uint32_t cb = 0; cb < total; cb += (uint32_t)CULL_CH * 64u) {
+    if (lane < CULL_CH) s_bits[lane] = 0ull;
+    cull_wave_sync();
+    if (nonempty && excl >= cb && excl - cb < (uint32_t)CULL_CH * 64u) {
+      const uint32_t rel = excl - cb;
+      atomicOr(reinterpret_cast<uint32_t*>(s_bits) + (rel >> 5), 1u << (rel & 31u));
+    }
+    cull_wave_sync();
+    uint32_t run_pairs = (uint32_t)__builtin_popcountll(__ballot(nonempty && excl < cb));
+    const uint32_t cend = min(total, cb + (uint32_t)CULL_CH * 64u);
+    for (uint32_t d0 = cb; d0 < cend; d0 += 64) {
+      const unsigned long long mv = s_bits[(d0 - cb) >> 6];
+      const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mv);
+      const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mv >> 32));
+      const uint64_t m = ((uint64_t)mhi << 32) | mlo;
+      const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+      const bool own = ((m >> lane) & 1ull) != 0ull;
+      const uint32_t d = d0 + (uint32_t)lane;
+      body(d, d < total, (int)(run_pairs + below + (own ? 1u : 0u)) - 1, own, m);
+      run_pairs += (uint32_t)__builtin_popcountll(m);
+    }
   }
-  __shared__ uint32_t s_off[4][64];
-  __shared__ uint32_t s_rect[4][64];
-  __shared__ uint32_t s_wide[4][64];
-  __shared__ float s_invw[4][64];   // 1 / width (dgs_divmod_u24)
-  __shared__ uint32_t s_tb[4][64];
-  __shared__ uint32_t s_g[4][64];
-  __shared__ uint32_t s_cnt[4][64];
+}
+
+__global__ void __launch_bounds__(256)
+cull_count_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restrict__ tiles_touched,
+                  uint4* __restrict__ recs, uint32_t* __restrict__ cnts) {
+  __shared__ unsigned long long s_bits[4][CULL_CH];
+  __shared__ uint4 s_a[4][64];    // first slot, minx | miny << 12, width | flags << 16 (1 = always, 2 = never), 1 / width
   __shared__ float4 s_q[4][64];   // x, y, a, b
   __shared__ float4 s_r[4][64];   // c, 1/a, 1/c, r2
-  __shared__ uint32_t s_fl[4][64];  // 1 = always, 2 = never
+  __shared__ uint32_t s_cnt[4][64];
+  __shared__ unsigned long long s_mask[4][64];
+  const int lane = dgs_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t n = (uint64_t)v.K * v.P;
+  const bool in = i < n;
+  const uint32_t nt = in ? tiles_touched[i] : 0u;
+  const bool nonempty = nt != 0u;
+  const uint64_t nm = __ballot(nonempty);
+  if (nm == 0ull) {   // wave-uniform: nothing visible here
+    if (in) {
+      recs[i] = make_uint4(0u, 0u, 0u, 0u);
+      cnts[i] = 0u;
+    }
+    return;
+  }
+  const uint32_t c = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+  const uint32_t incl = cull_wave_incl_scan(nt, lane);
+  const uint32_t excl = incl - nt;
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  uint32_t desc = 0;
+  if (nonempty) {
+    const DgsRow* row = rows + i;
+    const float4 A = reinterpret_cast<const float4*>(row)[0];  // x, y, cx, cy
+    const float4 B = reinterpret_cast<const float4*>(row)[1];  // cz, op, ...
+    int minx, miny, maxx, maxy;
+    dgs_get_rect(A.x, A.y, row->radius, v.gx, v.gy, minx, miny, maxx, maxy);
+    const uint32_t wide = (uint32_t)(maxx - minx);
+    const uint32_t rect = (uint32_t)minx | ((uint32_t)miny << 12);
+    const DgsCull cg = dgs_make_cull(A.z, A.w, B.x, B.y);
+    const uint32_t fl = (cg.always ? 1u : 0u) | (cg.never ? 2u : 0u);
+    s_a[w][c] = make_uint4(excl, rect, wide | (fl << 16), __float_as_uint(__builtin_amdgcn_rcpf((float)wide)));
+    s_q[w][c] = make_float4(A.x, A.y, cg.a, cg.b);
+    s_r[w][c] = make_float4(cg.c, cg.inv_a, cg.inv_c, cg.r2);
+    s_cnt[w][c] = 0u;
+    s_mask[w][c] = 0ull;
+    desc = (nt > 64u) ? CULL_BIG : (rect | ((wide - 1u) << 24));
+  }
+  cull_walk(s_bits[w], lane, nonempty, excl, total, [&](uint32_t d, bool act, int pi, bool own, uint64_t m) {
+    bool hit = false;
+    uint32_t local = 0;
+    if (act) {
+      const uint4 a = s_a[w][pi];
+      const float4 q = s_q[w][pi], r = s_r[w][pi];
+      local = d - a.x;
+      uint32_t ry, rx;
+      dgs_divmod_u24(local, a.z & 0xFFFFu, __uint_as_float(a.w), ry, rx);
+      const uint32_t tx = (a.y & 0xFFFu) + rx, ty = (a.y >> 12) + ry;
+      DgsCull cg;
+      cg.a = q.z; cg.b = q.w; cg.c = r.x; cg.inv_a = r.y; cg.inv_c = r.z; cg.r2 = r.w;
+      cg.always = (a.z & 0x10000u) != 0u; cg.never = (a.z & 0x20000u) != 0u;
+      // d = mean - pixel over the tile's pixel centres [16 t, 16 t + 15]
+      const float ex = q.x - (float)(tx * DGS_TILE), ey = q.y - (float)(ty * DGS_TILE);
+      hit = dgs_cull_hit(cg, ex - (float)(DGS_TILE - 1), ex, ey - (float)(DGS_TILE - 1), ey);
+    }
+    const uint64_t hm = __ballot(hit);
+    // one lane per pair and round (the pair's first slot of the round) books the pair's hits of the round
+    if (act && (lane == 0 || own)) {
+      const uint64_t rest = (lane == 63) ? 0ull : (m >> (lane + 1));
+      const int len = rest ? (__builtin_ctzll(rest) + 1) : (64 - lane);
+      const uint64_t seg = (len == 64) ? ~0ull : ((1ull << len) - 1ull);
+      const uint64_t chunk = (hm >> lane) & seg;
+      s_cnt[w][pi] += (uint32_t)__builtin_popcountll(chunk);
+      if (local < 64u) s_mask[w][pi] |= chunk << local;
+    }
+  });
+  cull_wave_sync();
+  if (in) {
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (nonempty) {
+      const uint64_t mk = s_mask[w][c];
+      rec = make_uint4(desc, s_cnt[w][c], (uint32_t)mk, (uint32_t)(mk >> 32));
+    }
+    recs[i] = rec;
+    cnts[i] = rec.y;   // dense copy: the input of the depth-order gather + scan
+  }
+}
+
+template <bool ANYBIG>
+__device__ __forceinline__ void cull_emit_rounds(const DgsView& v, unsigned long long* s_bits, const uint4* s_a,
+                                                 const uint4* s_b, const float4* s_q, const float4* s_r, int lane,
+                                                 bool live, uint32_t excl, uint32_t total, uint32_t obase, uint32_t cap,
+                                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  uint32_t run = 0;   // hits emitted by earlier rounds (wave-uniform)
+  cull_walk(s_bits, lane, live, excl, total, [&](uint32_t d, bool act, int pi, bool own, uint64_t m) {
+    bool hit = false;
+    uint32_t tile = 0, g = 0;
+    if (act) {
+      const uint4 a = s_a[pi];
+      const uint4 b = s_b[pi];
+      const uint32_t local = d - a.x;
+      const bool big = (a.z & 0x40000u) != 0u;
+      g = b.y;
+      uint32_t ry = 0, rx = 0;
+      if (!ANYBIG || !big) {
+        const uint64_t mk = ((uint64_t)b.w << 32) | b.z;
+        hit = ((mk >> local) & 1ull) != 0ull;
+        if (hit) dgs_divmod_u24(local, a.z & 0xFFFFu, __uint_as_float(a.w), ry, rx);
+      } else {
+        dgs_divmod_u24(local, a.z & 0xFFFFu, __uint_as_float(a.w), ry, rx);
+        const float4 q = s_q[pi], r = s_r[pi];
+        DgsCull cg;
+        cg.a = q.z; cg.b = q.w; cg.c = r.x; cg.inv_a = r.y; cg.inv_c = r.z; cg.r2 = r.w;
+        cg.always = (a.z & 0x10000u) != 0u; cg.never = (a.z & 0x20000u) != 0u;
+        const uint32_t tx = (a.y & 0xFFFu) + rx, ty = (a.y >> 12) + ry;
+        const float ex = q.x - (float)(tx * DGS_TILE), ey = q.y - (float)(ty * DGS_TILE);
+        hit = dgs_cull_hit(cg, ex - (float)(DGS_TILE - 1), ex, ey - (float)(DGS_TILE - 1), ey);
+      }
+      tile = b.x + __umul24((a.y >> 12) + ry, (uint32_t)v.gx) + (a.y & 0xFFFu) + rx;
+    }
+    const uint64_t hm = __ballot(hit);
+    if (hit) {
+      const uint32_t pos = obase + run + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+      if (pos < cap) {
+        if (v.pack_tile_shift > 0) {   // compact keys: the whole record in the key, no value array
+          keys[pos] = ((uint64_t)tile << v.pack_tile_shift) | ((uint64_t)g << v.pack_g_shift) | pos;
+        } else {
+          keys[pos] = ((uint64_t)tile << 32) | pos;
+          vals[pos] = g;
+        }
+      }
+    }
+    run += (uint32_t)__builtin_popcountll(hm);
+  });
+}
+
+__global__ void __launch_bounds__(256)
+cull_emit_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __restrict__ order,
+                 const uint32_t* __restrict__ tt_tight, const uint4* __restrict__ recs,
+                 const uint32_t* __restrict__ offs_tight, const uint32_t* __restrict__ status,
+                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap) {
+  if (status[3] != 0u) return;   // the surviving total overflowed 32 bits: the offsets are meaningless (the host raises)
+  __shared__ unsigned long long s_bits[4][CULL_CH];
+  __shared__ uint4 s_a[4][64];    // first slot, minx | miny << 12, width | flags << 16 (1 always, 2 never, 4 big), 1 / width
+  __shared__ uint4 s_b[4][64];    // k * T, Gaussian, hit bits of the first 64 slots
+  __shared__ float4 s_q[4][64];   // big rectangles only: x, y, a, b
+  __shared__ float4 s_r[4][64];   //                      c, 1/a, 1/c, r2
   const int lane = dgs_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t n = (uint64_t)v.K * v.P;
   const bool in = j < n;
-  uint32_t off = 0, nt = 0, otight = 0;
-  // EMIT: the COUNT instance left every pair's rectangle (desc) and the hit ballots of each wave's first TIGHT_ROUNDS
-  // rounds (hits): a wave whose slots fit into those rounds -- nearly all of them -- re-reads nothing of the geometry rows
-  // and evaluates no ellipse test; only a wave with more slots gathers the rows again for its later rounds.
-  const unsigned long long* my_hits = hits + ((size_t)blockIdx.x * 4 + (size_t)w) * TIGHT_ROUNDS;
-  bool need_rows = !EMIT;
-  if (EMIT) {
-    const uint32_t o0 = in ? offs_sorted[j] : 0u, n0 = in ? tt_sorted[j] : 0u;
-    const uint64_t vm = __ballot(in);
-    if (vm != 0ull) {
-      const int lastv = 63 - __builtin_clzll(vm);
-      const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)(o0 + n0), lastv) -
-                            (uint32_t)__builtin_amdgcn_readfirstlane((int)o0);
-      need_rows = tot0 > (uint32_t)(TIGHT_ROUNDS * 64);   // wave-uniform
-    }
-  }
-  if (in) {
-    const uint32_t i = order[j];
-    off = offs_sorted[j];
-    nt = tt_sorted[j];
-    uint32_t rect = 0, wide = 0, tb = 0, g = 0, fl = 0;
-    float4 q = make_float4(0, 0, 0, 0), r = q;
-    if (nt != 0 && !need_rows) {      // EMIT, fast path: rectangle from the COUNT pass, no row
-      const uint32_t k = i / (uint32_t)v.P;
-      g = i - k * (uint32_t)v.P;
-      const uint2 dsc = desc[j];
-      rect = dsc.x;
-      wide = dsc.y;
-      tb = k * (uint32_t)v.T;
-      otight = offs_tight[j];
-    } else if (nt != 0) {
-      const uint32_t k = i / (uint32_t)v.P;
-      g = i - k * (uint32_t)v.P;
+  const bool live = in && tt_tight[j] != 0u;
+  const uint64_t lm = __ballot(live);
+  if (lm == 0ull) return;   // wave-uniform
+  const uint32_t i = in ? order[j] : 0u;
+  const uint4 rec = live ? recs[i] : make_uint4(0u, 0u, 0u, 0u);
+  const uint32_t otight = in ? offs_tight[j] : 0u;
+  const bool big = live && (rec.x & CULL_BIG) != 0u;
+  const bool any_big = __ballot(big) != 0ull;
+  const uint32_t c = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+  uint32_t work = 0, rect = 0, wide = 1, fl = 0, tb = 0, g = 0;
+  float4 q = make_float4(0, 0, 0, 0), r = q;
+  if (live) {
+    const uint32_t k = i / (uint32_t)v.P;
+    g = i - k * (uint32_t)v.P;
+    tb = k * (uint32_t)v.T;
+    if (!big) {   // the stored bits are the test: slots up to the last hit
+      rect = rec.x & 0xFFFFFFu;
+      wide = ((rec.x >> 24) & 63u) + 1u;
+      work = 64u - (uint32_t)__builtin_clzll(((uint64_t)rec.w << 32) | rec.z);
+    } else {      // more than 64 slots: the whole rectangle again, from the row
       const DgsRow* row = rows + i;
-      const float4 A = reinterpret_cast<const float4*>(row)[0];  // x, y, cx, cy
-      const float4 B = reinterpret_cast<const float4*>(row)[1];  // cz, op, ...
+      const float4 A = reinterpret_cast<const float4*>(row)[0];
+      const float4 B = reinterpret_cast<const float4*>(row)[1];
       int minx, miny, maxx, maxy;
       dgs_get_rect(A.x, A.y, row->radius, v.gx, v.gy, minx, miny, maxx, maxy);
       wide = (uint32_t)(maxx - minx);
       rect = (uint32_t)minx | ((uint32_t)miny << 12);
-      tb = k * (uint32_t)v.T;
+      work = wide * (uint32_t)(maxy - miny);
       const DgsCull cg = dgs_make_cull(A.z, A.w, B.x, B.y);
+      fl = (cg.always ? 1u : 0u) | (cg.never ? 2u : 0u) | 4u;
       q = make_float4(A.x, A.y, cg.a, cg.b);
       r = make_float4(cg.c, cg.inv_a, cg.inv_c, cg.r2);
-      fl = (cg.always ? 1u : 0u) | (cg.never ? 2u : 0u);
-      if (EMIT) {
-        otight = offs_tight[j];
-        // (the backward finds this pair's contribution rows through offs_tight[j] in this same order:
-        // contrib_reduce_kernel; nothing is stamped per pair)
-      } else {
-        desc[j] = make_uint2(rect, wide);
-      }
-    } else if (EMIT) {
-      otight = offs_tight[j];
     }
-    s_rect[w][lane] = rect;
-    s_wide[w][lane] = wide;
-    s_invw[w][lane] = __builtin_amdgcn_rcpf((float)wide);
-    s_tb[w][lane] = tb;
-    s_g[w][lane] = g;
-    s_q[w][lane] = q;
-    s_r[w][lane] = r;
-    s_fl[w][lane] = fl;
   }
-  s_cnt[w][lane] = 0;
-  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+  const uint32_t incl = cull_wave_incl_scan(work, lane);
+  const uint32_t excl = incl - work;
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  if (live) {
+    s_a[w][c] = make_uint4(excl, rect, wide | (fl << 16), __float_as_uint(__builtin_amdgcn_rcpf((float)wide)));
+    s_b[w][c] = make_uint4(tb, g, rec.z, rec.w);
+    if (big) {
+      s_q[w][c] = q;
+      s_r[w][c] = r;
+    }
+  }
+  // the wave's duplicates are contiguous from its first pair's offset (offs_tight is the exclusive scan in this order)
   const uint32_t obase = (uint32_t)__builtin_amdgcn_readfirstlane((int)otight);
-  s_off[w][lane] = in ? off - base : 0xFFFFFFFFu;
-  const uint64_t valid = __ballot(in);
-  if (valid == 0ull) return;
-  const int last = 63 - __builtin_clzll(valid);
-  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)(off + nt), last) - base;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  uint32_t run = 0;  // hits emitted by earlier rounds (wave-uniform)
-  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (uint32_t d0 = 0; d0 < total; d0 += 64) {
-    const uint32_t d = d0 + (uint32_t)lane;
-    const bool act = d < total;
-    int lo = 0;
-    bool hit = false;
-    uint32_t tile = 0;
-    const uint32_t round = d0 >> 6;
-    const bool stored = EMIT && round < (uint32_t)TIGHT_ROUNDS;    // wave-uniform
-    unsigned long long hm_stored = 0ull;
-    if (stored) hm_stored = my_hits[round];
-    if (act && (!stored || ((hm_stored >> lane) & 1ull))) {
-#pragma unroll
-      for (int step = 32; step >= 1; step >>= 1) {
-        const int mid = lo + step;
-        if (mid < 64 && s_off[w][mid] <= d) lo = mid;
-      }
-      const uint32_t local = d - s_off[w][lo];
-      const uint32_t width = s_wide[w][lo];
-      const uint32_t rect = s_rect[w][lo];
-      uint32_t ry, rx;
-      dgs_divmod_u24(local, width, s_invw[w][lo], ry, rx);
-      const uint32_t tx = (rect & 0xFFFu) + rx, ty = (rect >> 12) + ry;
-      tile = s_tb[w][lo] + __umul24(ty, (uint32_t)v.gx) + tx;
-      const float4 q = s_q[w][lo], r = s_r[w][lo];
-      const uint32_t fl = s_fl[w][lo];
-      DgsCull cg;
-      cg.a = q.z; cg.b = q.w; cg.c = r.x; cg.inv_a = r.y; cg.inv_c = r.z; cg.r2 = r.w;
-      cg.always = (fl & 1u) != 0; cg.never = (fl & 2u) != 0;
-      // d = mean - pixel over the tile's pixel centres [16 t, 16 t + 15]
-      if (stored) {
-        hit = true;
-      } else {
-        const float ex = q.x - (float)(tx * DGS_TILE), ey = q.y - (float)(ty * DGS_TILE);
-        hit = dgs_cull_hit(cg, ex - (float)(DGS_TILE - 1), ex, ey - (float)(DGS_TILE - 1), ey);
-      }
-    }
-    const uint64_t hm = stored ? (uint64_t)hm_stored : __ballot(hit);
-    if (!EMIT && round < (uint32_t)TIGHT_ROUNDS && lane == 0) hits[((size_t)blockIdx.x * 4 + (size_t)w) * TIGHT_ROUNDS + round] = hm;
-    if (EMIT) {
-      if (hit) {
-        const uint32_t pos = obase + run + (uint32_t)__builtin_popcountll(hm & lt);
-        if (pos < cap) {
-          if (v.pack_tile_shift > 0) {   // compact keys: the whole record in the key, no value array
-            keys[pos] = ((uint64_t)tile << v.pack_tile_shift) | ((uint64_t)s_g[w][lo] << v.pack_g_shift) | pos;
-          } else {
-            keys[pos] = ((uint64_t)tile << 32) | pos;
-            vals[pos] = s_g[w][lo];
-          }
-        }
-      }
-      run += (uint32_t)__builtin_popcountll(hm);
-    } else {
-      // one lane per segment of this round (the first slot of the segment in the round) adds the segment's hits
-      const int prev = __shfl_up(lo, 1, 64);
-      const bool first = act && (lane == 0 || prev != lo);
-      const uint64_t fm = __ballot(first);
-      if (first) {
-        const uint64_t rest = (lane == 63) ? 0ull : (fm >> (lane + 1));
-        const int len = rest ? (__builtin_ctzll(rest) + 1) : (64 - lane);
-        const uint64_t seg = ((len == 64) ? ~0ull : ((1ull << len) - 1ull)) << lane;
-        s_cnt[w][lo] += (uint32_t)__builtin_popcountll(hm & seg);
-      }
-    }
-  }
-  if (!EMIT) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (in) tt_tight[j] = s_cnt[w][lane];
-  }
+  if (any_big)
+    cull_emit_rounds<true>(v, s_bits[w], s_a[w], s_b[w], s_q[w], s_r[w], lane, live, excl, total, obase, cap, keys, vals);
+  else
+    cull_emit_rounds<false>(v, s_bits[w], s_a[w], s_b[w], s_q[w], s_r[w], lane, live, excl, total, obase, cap, keys, vals);
 }
 
 // Capacity mode (dgs_forward): the duplicate arrays were sized by the caller before the count was known.  Words of
-// c.num_rendered: [0] rectangle total, [1] its high half (u32 overflow), [2] surviving total (tile_cull), [4] the count
+// c.num_rendered: [0] rectangle total, [1] its high half (u32 overflow), [2], [3] the same for the surviving total
+// (tile_cull; [0], [1] stay 0 then), [4] the count
 // the sort / ranges kernels use = min(count, capacity), [5] overflow flag (the lists are truncated: every consumer that
 // indexes by duplicate offset returns early, the caller re-runs with a larger capacity).
 __global__ void finalize_count_kernel(uint32_t* __restrict__ nr, int cull, uint32_t cap, uint32_t* __restrict__ drops) {
   const uint32_t n = cull ? nr[2] : nr[0];
-  const bool bad = (nr[1] != 0u) || (n > cap);
+  const bool bad = ((cull ? nr[3] : nr[1]) != 0u) || (n > cap);
   nr[4] = bad ? 0u : n;
   nr[5] = bad ? 1u : 0u;
   if (bad && drops != nullptr) drops[0] += 1u;   // the caller's running count of overflowed forwards (graph replays)
@@ -1023,7 +1111,7 @@ __global__ void __launch_bounds__(DS_THREADS)
 dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t P, uint32_t nb,
                      uint32_t nch, int shift, const uint32_t* __restrict__ table, const uint32_t* __restrict__ ctot,
-                     const uint32_t* __restrict__ gather_src, uint32_t* __restrict__ gather_dst) {
+                     uint32_t* __restrict__ vis_dst) {
   __shared__ uint32_t lds_k[DS_TILE];
   __shared__ uint32_t lds_v[DS_TILE];
   __shared__ uint32_t whist[DS_THREADS / 64][DS_BINS];
@@ -1105,10 +1193,24 @@ dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
       if (!LAST) keys_out[pos] = kk;
       const uint32_t vv = lds_v[i];
       vals_out[pos] = vv;
-      // the last pass also lays out a per-pair word (tiles_touched) in the final order: saves a gather launch
-      if (LAST && gather_src != nullptr) gather_dst[pos] = gather_src[vv];
+      // tile_cull: the last pass also writes the visibility flags in the final order (invisible pairs sort to the end of
+      // their subframe); the 16-byte cull records follow in a gather kernel of their own -- done here, behind this
+      // kernel's LDS exchange and at its occupancy, the dependent random reads cost 225 us instead of ~100
+      if (LAST && vis_dst != nullptr) vis_dst[pos] = (kk != 0xFFFFFFFFu) ? 1u : 0u;
     }
   }
+}
+
+// tile_cull: the surviving-tile counts (natural order) into (k, depth, index) order, the input of the scan.
+// (3 M random reads cost ~100 us here whatever the block -> XCD map: an XCD-contiguous map measured 107 vs 97 us.  The
+// same gather of the 16-byte records costs 226 us on its own, which is why cull_emit_kernel does that one itself, behind
+// its own arithmetic.)
+__global__ void __launch_bounds__(256)
+gather_cnt_kernel(uint64_t n, const uint32_t* __restrict__ order, const uint32_t* __restrict__ vis,
+                  const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  dst[j] = (vis[j] != 0u) ? src[order[j]] : 0u;
 }
 
 struct PassPlan {
@@ -1140,7 +1242,6 @@ hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, 
   return hipGetLastError();
 }
 
-size_t dgs_cull_hits_words64(uint64_t kp) { return (size_t)((kp + 255) / 256) * 4 * TIGHT_ROUNDS; }
 
 size_t dgs_scan_tmp_words(uint64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 64; }
 
@@ -1287,26 +1388,28 @@ hipError_t dgs_launch_duplicate_sorted(const DgsView& v, const DgsCarve& c, cons
   return hipGetLastError();
 }
 
-hipError_t dgs_launch_tight_count(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* total_full,
-                                  uint32_t* total_tight, hipStream_t s) {
+// tile_cull, before the depth sort: per (k, Gaussian) record of rectangle, surviving-tile count and hit bits, natural order
+hipError_t dgs_launch_cull_count(const DgsView& v, const DgsCarve& c, hipStream_t s) {
   const uint64_t n = (uint64_t)v.K * v.P;
-  const dim3 grid((uint32_t)((n + 255) / 256));
-  hipLaunchKernelGGL(gather_u32_kernel, grid, dim3(256), 0, s, n, order, c.tiles_touched, c.tt_sorted);
-  hipError_t e = dgs_launch_scan(c.tt_sorted, c.offs_sorted, n, c.scan_tmp, total_full, s);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(tight_kernel<false>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
-                     c.tt_tight, c.offs_tight, total_full, (uint64_t*)nullptr, (uint32_t*)nullptr, 0u, c.cull_desc,
-                     c.cull_hits);
-  return dgs_launch_scan(c.tt_tight, c.offs_tight, n, c.scan_tmp, total_tight, s);
+  hipLaunchKernelGGL(cull_count_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, v, c.rows, c.tiles_touched,
+                     c.cull_rec, c.cull_cnt);
+  return hipGetLastError();
+}
+
+// tile_cull, after the depth sort: the counts into its order, offsets = their exclusive scan
+// (total -> total_tight[0..1])
+hipError_t dgs_launch_cull_offsets(const DgsView& v, const DgsCarve& c, uint32_t* total_tight, hipStream_t s) {
+  const uint64_t n = (uint64_t)v.K * v.P;
+  hipLaunchKernelGGL(gather_cnt_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, n, c.gsort_vals, c.tt_sorted, c.cull_cnt,
+                     c.tt_tight);
+  return dgs_launch_scan(c.tt_tight, c.offs_tight, (uint64_t)v.K * v.P, c.scan_tmp, total_tight, s);
 }
 
 hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t cap,
                                       hipStream_t s) {
   const uint64_t n = (uint64_t)v.K * v.P;
-  const dim3 grid((uint32_t)((n + 255) / 256));
-  hipLaunchKernelGGL(tight_kernel<true>, grid, dim3(256), 0, s, v, c.rows, order, c.tt_sorted, c.offs_sorted,
-                     c.tt_tight, c.offs_tight, c.num_rendered, c.keys_unsorted, c.vals_unsorted, cap, c.cull_desc,
-                     c.cull_hits);
+  hipLaunchKernelGGL(cull_emit_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, v, c.rows, order, c.tt_tight, c.cull_rec,
+                     c.offs_tight, c.num_rendered, c.keys_unsorted, c.vals_unsorted, cap);
   return hipGetLastError();
 }
 
@@ -1329,8 +1432,7 @@ size_t dgs_depth_sort_tmp_words(int K, uint32_t P) {
 // keys [K*P] u32 (destroyed), order out [K*P] u32 = flat (k, Gaussian) indices in (k, key, index) order.  Four passes:
 // the result always lands in `order` (the first of the two value buffers).
 hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
-                                 uint32_t P, uint32_t* tmp, const uint32_t* gather_src, uint32_t* gather_dst,
-                                 hipStream_t s) {
+                                 uint32_t P, uint32_t* tmp, uint32_t* vis_dst, hipStream_t s) {
   if (K <= 0 || P == 0) return hipSuccess;
   const uint32_t nb = (P + DS_TILE - 1) / DS_TILE;
   const uint32_t nch = (nb + DS_CHUNK - 1) / DS_CHUNK;
@@ -1348,13 +1450,13 @@ hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* o
     if (nch > 1) hipLaunchKernelGGL(dsort_colscan_top_kernel, dim3((uint32_t)K), dim3(DS_BINS), 0, s, ctot, nch, P);
     if (pass == 0)
       hipLaunchKernelGGL((dsort_scatter_kernel<true, false>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P, nb,
-                         nch, shift, table, ctot, gather_src, gather_dst);
+                         nch, shift, table, ctot, vis_dst);
     else if (pass == 3)
       hipLaunchKernelGGL((dsort_scatter_kernel<false, true>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P, nb,
-                         nch, shift, table, ctot, gather_src, gather_dst);
+                         nch, shift, table, ctot, vis_dst);
     else
       hipLaunchKernelGGL((dsort_scatter_kernel<false, false>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P,
-                         nb, nch, shift, table, ctot, gather_src, gather_dst);
+                         nb, nch, shift, table, ctot, vis_dst);
     uint32_t* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }

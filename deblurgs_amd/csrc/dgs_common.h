@@ -8,6 +8,8 @@
 #define DGS_TILE 16                 // reference BLOCK_X/BLOCK_Y (config.h:16-17): tile ids must match
 #define DGS_ROW_F 12                // floats per geometry row (48 B)
 #define DGS_CONTRIB_F 12            // floats per backward contribution row (48 B): 10 used
+#define DGS_SUMS_F 16               // float stride of the per-(subframe, Gaussian) totals of those rows: 64-byte slots, so the
+                                    // scattered writes of contrib_reduce_kernel are whole aligned lines (12-float slots: 771 us, 16: 663 us)
 #define DGS_WAVE 64
 
 // Geometry row: everything the per-tile compositing needs about one (subframe, Gaussian), gathered by one
@@ -39,8 +41,8 @@ struct DgsCarve {  // resolved device pointers of the three blobs
   uint32_t* tt_tight;        // tile_cull: per (k, Gaussian) count of tiles that can reach alpha >= 1/255, same order,
   uint32_t* offs_tight;      //            and its exclusive scan (= duplicate / contribution-row offsets)
   uint32_t* gsort_tmp;
-  uint2* cull_desc;          // tile_cull: per (k, Gaussian) in depth order, its tile rectangle (minx | miny << 12, width)
-  unsigned long long* cull_hits;  // tile_cull: hit ballots of each 64-pair wave's first rounds of rectangle slots
+  uint4* cull_rec;           // tile_cull: per (k, Gaussian) rectangle, surviving-tile count, hit bits of the first 64 slots
+  uint32_t* cull_cnt;        //            the counts alone (both by natural index)
   float* final_T;
   uint32_t* n_contrib;
   uint2* ranges;
@@ -126,23 +128,6 @@ __device__ __forceinline__ float dgs_fold4(float a, float b) {
   float t = a + dgs_dpp<0x141, 0xf>(a);  // row_half_mirror
   asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(t) : "v"(b));
   return t;
-}
-// The same two folds from builtins only: the masked step is a bank-masked v_mov_b32_dpp of the second operand's fold
-// (one instruction more than the inline-asm masked add above), but the compiler knows every hazard and is free to fill
-// the wait states with independent work -- what the compositing backward wants when it reduces two entries at once.
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ float dgs_dpp_keep(float old, float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
-}
-__device__ __forceinline__ float dgs_fold8b(float a, float b) {
-  const float t = a + dgs_dpp<0x128, 0xf>(a);   // row_ror:8
-  const float u = b + dgs_dpp<0x128, 0xf>(b);
-  return dgs_dpp_keep<0xE4, 0xf, 0xc>(t, u);    // quad_perm [0,1,2,3] (identity), banks 2, 3 <- u
-}
-__device__ __forceinline__ float dgs_fold4b(float a, float b) {
-  const float t = a + dgs_dpp<0x141, 0xf>(a);   // row_half_mirror
-  const float u = b + dgs_dpp<0x141, 0xf>(b);
-  return dgs_dpp_keep<0xE4, 0xf, 0xa>(t, u);    // banks 1, 3 <- u
 }
 // every lane of a quad <- the sum over the quad
 __device__ __forceinline__ float dgs_quad_sum(float v) {
@@ -249,8 +234,8 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
                            const uint32_t* n_dev = nullptr);
 hipError_t dgs_launch_duplicate_sorted(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* tt_sorted,
                                        uint32_t* offs_sorted, uint32_t* scan_tmp, uint32_t cap, hipStream_t s);
-hipError_t dgs_launch_tight_count(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* total_full,
-                                  uint32_t* total_tight, hipStream_t s);
+hipError_t dgs_launch_cull_count(const DgsView& v, const DgsCarve& c, hipStream_t s);
+hipError_t dgs_launch_cull_offsets(const DgsView& v, const DgsCarve& c, uint32_t* total_tight, hipStream_t s);
 hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t cap,
                                       hipStream_t s);
 hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,
@@ -265,11 +250,9 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
                                 hipStream_t s);
 
 hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
-                                 uint32_t P, uint32_t* tmp, const uint32_t* gather_src, uint32_t* gather_dst,
-                                 hipStream_t s);
+                                 uint32_t P, uint32_t* tmp, uint32_t* vis_dst, hipStream_t s);
 size_t dgs_depth_sort_tmp_words(int K, uint32_t P);
 size_t dgs_scan_tmp_words(uint64_t n);
-size_t dgs_cull_hits_words64(uint64_t kp);
 size_t dgs_sort_tmp_words(uint64_t n);
 int dgs_sort_num_passes(int begin_bit, int end_bit);
 int dgs_geometry_bwd_blocks(int P);

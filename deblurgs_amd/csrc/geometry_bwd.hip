@@ -51,7 +51,7 @@ __device__ __forceinline__ M3 tr(const M3& A) {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // Stage 1: the contribution rows of every visible (subframe, Gaussian) pair, summed in duplicate order (deterministic),
-// written as ONE 48-byte total per pair at the pair's NATURAL index k * P + g.  Pairs are walked in the order the
+// written as ONE total per pair (12 floats in a 64-byte slot: whole aligned lines) at the pair's NATURAL index k * P + g.  Pairs are walked in the order the
 // duplicates were laid out in ((k, depth, index): consecutive quads read consecutive row segments).
 // The geometry kernel then reads its totals with coalesced, independent loads -- no duplicate offset to chase, and the
 // emit pass of the forward no longer stores one.  A visible pair whose every tile was culled gets zeros.
@@ -66,15 +66,16 @@ contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ status, const uin
   if (status[5] != 0u) return;  // capacity mode, truncated lists: the offsets point past the rows that were written
   // four lanes per (subframe, Gaussian): lane part p in {0,1,2} owns the p-th float4 of every row of the segment
   // (part 3 idles), so a quad reads each 48-byte row with one contiguous access and no cross-lane sum is needed
+  // (an XCD-contiguous block map -- every XCD's L2 seeing about two subframes' slots -- measured slower: 709 vs 671 us)
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t j = t >> 2;
   const uint32_t part = (uint32_t)t & 3u;
-  if (j >= n || part == 3u) return;
+  if (j >= n || (part == 3u && DGS_SUMS_F < 16)) return;
   // the four index words are requested together (one round trip instead of a chain of three) ...
   const uint32_t vis = tt_visible[j], nt = tiles[j], off = offsets[j], dst = order[j];
   if (vis == 0u) return;  // invisible pair: the geometry kernel never reads its slot
   float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if (nt > 0) {
+  if (nt > 0 && part < 3u) {
     const float4* cp = reinterpret_cast<const float4*>(contrib + (size_t)off * DGS_CONTRIB_F) + part;
     // ... and so are the first four rows of the segment (a pair has ~3 duplicates on average), then eight at a time:
     // the loop is never a chain of dependent HBM round trips.  Rows are added strictly in duplicate order.
@@ -107,7 +108,7 @@ contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ status, const uin
       a.w += q.w;
     }
   }
-  reinterpret_cast<float4*>(sums + (size_t)dst * DGS_CONTRIB_F)[part] = a;
+  reinterpret_cast<float4*>(sums + (size_t)dst * DGS_SUMS_F)[part] = a;
 }
 
 template <int MAXC>  // MAXC = SH coefficients held in registers: 1, 4, 9 or 16
@@ -188,7 +189,7 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     // the (subframe, Gaussian) total contrib_reduce_kernel left at the pair's natural index (zeros when tile culling
     // left the pair no tile); loaded unconditionally -- the slot of an invisible pair is never used
     SumPf c;
-    const float4* cp = reinterpret_cast<const float4*>(contrib + ((size_t)k * v.P + gi) * DGS_CONTRIB_F);
+    const float4* cp = reinterpret_cast<const float4*>(contrib + ((size_t)k * v.P + gi) * DGS_SUMS_F);
     c.r0 = cp[0];
     c.r1 = cp[1];
     c.r2 = cp[2];

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 8
+#define DGS_ABI_VERSION 9
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -151,13 +151,14 @@ typedef struct DgsLayout {
   size_t gsort_keys_alt; /* u32 [K,P] its ping-pong buffer */
   size_t gsort_vals;     /* u32 [K*P] flat (k, Gaussian) indices in (k, depth, index) order (the sort's result) */
   size_t gsort_vals_alt; /* u32 [K*P] */
-  size_t tt_sorted;      /* u32 [K*P] tiles_touched in (k, depth, index) order */
+  size_t tt_sorted;      /* u32 [K*P] tiles_touched in (k, depth, index) order (tile_cull: 1 / 0 = visible / not) */
   size_t offs_sorted;    /* u32 [K*P] its exclusive prefix sum */
   size_t tt_tight;       /* u32 [K*P] tile_cull: surviving tiles per (k, Gaussian), same order */
   size_t offs_tight;     /* u32 [K*P] its exclusive prefix sum (its total is R under tile_cull) */
   size_t gsort_tmp;      /* u32 radix tables of the Gaussian sort */
-  size_t cull_desc;      /* u32 [K*P,2] tile_cull: tile rectangle of every (k, Gaussian) in depth order (minx | miny << 12, width) */
-  size_t cull_hits;      /* u64 tile_cull: per 64-pair wave, the hit ballots of its first 8 rounds of 64 rectangle slots */
+  size_t cull_rec;       /* u32 [K*P,4] tile_cull: per (k, Gaussian), natural order: rectangle (minx | miny << 12 | (width-1) << 24, or
+                          * bit 31 = more than 64 tiles), surviving tiles, hit bits of the rectangle's first 64 tiles (u64) */
+  size_t cull_cnt;       /* u32 [K*P] tile_cull: the surviving-tile counts alone, natural order */
   size_t geom_total;
   /* image blob */
   size_t final_T;        /* f32 [K,H*W] */
@@ -193,7 +194,8 @@ size_t dgs_backward_scratch_bytes(uint64_t R, int32_t P, int32_t K);
 int dgs_layout(int32_t P, int32_t W, int32_t H, int32_t K, uint64_t R, int32_t wide_records, DgsLayout* out);
 /* Byte offsets inside DgsBackwardIO.scratch (for debuggers and the parity tests): contribution rows f32 [R,12] at 0
  * ([S_wx, S_wy, S_xx, S_xy, S_yy, S_w, dL_dr, dL_dg, dL_db, dL_ddepth, -, -] per duplicate, in emission order), their
- * per-(subframe, Gaussian) totals f32 [K*P,12] at *sums_offset (natural index k*P + g; defined for visible pairs only; the
+ * per-(subframe, Gaussian) totals f32 [K*P,16] at *sums_offset (the same 12 columns in 64-byte slots, the last 4 floats
+ * unused; natural index k*P + g; defined for visible pairs only; the
  * reference's per-Gaussian sinks follow from them as dL_dconic = -0.5 (S_xx, S_xy, S_yy), dL_dopacity = S_w / opacity,
  * backward.cu:620-637), the per-block pose-gradient partials at *partials_offset. */
 int dgs_backward_scratch_layout(uint64_t R, int32_t P, int32_t K, size_t* sums_offset, size_t* partials_offset);

@@ -505,7 +505,7 @@ def hip_backward_internals(debug, radii, ks=None, means2D=None):
     from deblurgs_amd import _lib
     K, P, R = debug["K"], debug["P"], debug["R"]
     so, _ = _lib.backward_scratch_layout(R, P, K)
-    sums = debug["scratch"][so:so + K * P * 48].view(dtype=torch.float32).reshape(K, P, 12)
+    sums = debug["scratch"][so:so + K * P * 64].view(dtype=torch.float32).reshape(K, P, 16)[..., :12]
     radii = torch.as_tensor(np.asarray(radii)).reshape(K, P) if not torch.is_tensor(radii) else radii.reshape(K, P)
     sel = list(range(K)) if ks is None else list(ks)
     part = sums[sel].cpu().numpy()
