@@ -162,9 +162,9 @@ def stage_bytes(P, Pv_tot, R_tot, N, K, s):
         "composite_bwd": 44 * R_tot + 24 * N * K + 2 * 48 * Pv_tot,
         "geometry_bwd": Pv_tot * (100 + 12 * s + 48) + P * (40 + 12 * s),
         "depth_order": 24 * P * K,   # ideal one-read-one-write sort of the K*P (key, index) pairs
-        # tile_cull: gather + two scans + the per-slot test (order/count/offset words per pair, 32 B of each
-        # visible pair's row, the surviving-tile count out)
-        "tile_cull": 32 * P * K + 32 * Pv_tot,
+        # tile_cull: the per-slot test in natural order (tiles_touched in, 16-byte record + count out per pair, 36 B of
+        # each visible pair's row), the counts gathered into depth order (order, flag, count in, count out) and their scan
+        "tile_cull": (4 + 20) * P * K + 36 * Pv_tot + 16 * P * K + 8 * P * K,
     }
 
 

@@ -52,6 +52,8 @@ class DgsBackwardIO(ctypes.Structure):
         ("dL_dcolors", ctypes.c_void_p), ("dL_dopacity", ctypes.c_void_p), ("dL_dscales", ctypes.c_void_p),
         ("dL_drotations", ctypes.c_void_p), ("dL_dcov3D", ctypes.c_void_p), ("dL_dviewmatrix", ctypes.c_void_p),
         ("dL_dprojmatrix", ctypes.c_void_p), ("opacity_hinge_scale", ctypes.c_float),
+        ("stats_max_radii2D", ctypes.c_void_p), ("stats_grad_accum", ctypes.c_void_p), ("stats_denom", ctypes.c_void_p),
+        ("stats_K_total", ctypes.c_int32),
     ]
 
 

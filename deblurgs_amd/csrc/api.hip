@@ -697,7 +697,8 @@ static int backward_impl(const DgsProblem* p, const DgsBackwardIO* io, int which
     return e == hipSuccess ? DGS_OK : fail_hip(e, "memset grads");
   }
   if (io->dL_dout_color == nullptr || io->radii == nullptr || io->dL_dmeans3D == nullptr ||
-      io->dL_dmeans2D == nullptr || io->dL_dcolors == nullptr || io->dL_dopacity == nullptr ||
+      (io->dL_dmeans2D == nullptr && io->stats_max_radii2D == nullptr) || io->dL_dcolors == nullptr ||
+      io->dL_dopacity == nullptr ||
       io->dL_dcov3D == nullptr)
     return fail(DGS_E_ARG, "DgsBackwardIO: a required pointer is null");
   if (p->shs != nullptr && io->dL_dsh == nullptr) return fail(DGS_E_ARG, "dL_dsh is null");

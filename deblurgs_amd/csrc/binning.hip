@@ -770,13 +770,28 @@ colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nblocks, const uint3
   if (t0 >= nblocks) return;
   const uint32_t t1 = min(t0 + CS_CHUNK, nblocks);
   uint32_t run0 = 0, run1 = 0;
-  for (uint32_t t = t0; t < t1; t++) {
-    uint32_t* row = table + (size_t)t * SORT_MAX_BINS;
-    const uint32_t a = row[threadIdx.x], b = row[threadIdx.x + 256];
-    row[threadIdx.x] = run0;
-    row[threadIdx.x + 256] = run1;
-    run0 += a;
-    run1 += b;
+  // the rows are fetched eight at a time before the serial prefix is applied (the loads do not depend on the running
+  // sums; one dependent row per iteration left the 142 blocks of the metric config latency-bound: 30 us per pass)
+  constexpr int U = 8;
+  for (uint32_t t = t0; t < t1; t += U) {
+    uint32_t a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const bool ok = t + u < t1;
+      const uint32_t* row = table + (size_t)(ok ? t + u : t) * SORT_MAX_BINS;
+      a[u] = ok ? row[threadIdx.x] : 0u;
+      b[u] = ok ? row[threadIdx.x + 256] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (t + u < t1) {
+        uint32_t* row = table + (size_t)(t + u) * SORT_MAX_BINS;
+        row[threadIdx.x] = run0;
+        row[threadIdx.x + 256] = run1;
+      }
+      run0 += a[u];
+      run1 += b[u];
+    }
   }
   ctot[(size_t)blockIdx.x * SORT_MAX_BINS + threadIdx.x] = run0;
   ctot[(size_t)blockIdx.x * SORT_MAX_BINS + threadIdx.x + 256] = run1;
@@ -784,7 +799,7 @@ colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nblocks, const uint3
 
 // one block: chunk totals -> exclusive chunk bases per digit, plus the exclusive base of each digit.
 // The chunk loop is latency-bound (one block, dependent only through the running sums), so rows are fetched
-// eight at a time before the serial prefix is applied.
+// 32 at a time before the serial prefix is applied.
 __global__ void __launch_bounds__(256)
 colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nchunks, const uint32_t* __restrict__ n_dev) {
   if (n_dev != nullptr) {
@@ -792,7 +807,7 @@ colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nchunks, const uint32_t
     nchunks = min(nchunks, (nb + CS_CHUNK - 1) / CS_CHUNK);
   }
   __shared__ uint32_t lds[8];
-  constexpr int U = 8;
+  constexpr int U = 32;
   uint32_t run0 = 0, run1 = 0;
   for (uint32_t c0 = 0; c0 < nchunks; c0 += U) {
     uint32_t a[U], b[U];
@@ -1272,18 +1287,12 @@ size_t dgs_sort_tmp_words(uint64_t n) {
   return (size_t)(table + dgs_scan_tmp_words(table) + OS_MAX_PASSES * SORT_MAX_BINS + chunks * SORT_MAX_BINS + 256);
 }
 
-// DGS_SORT = classic | reorder | onesweep (A/B switch for the sort benchmark; default below)
-static int sort_mode() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DGS_SORT");
-    v = 1;
-    if (e != nullptr && strcmp(e, "classic") == 0) v = 0;
-    if (e != nullptr && strcmp(e, "reorder") == 0) v = 1;
-    if (e != nullptr && strcmp(e, "onesweep") == 0) v = 2;
-  }
-  return v;
-}
+// DGS_SORT_MODE = 0 classic | 1 reorder (default) | 2 onesweep: compile-time A/B switch for the sort benchmark
+// (tools/build_flag_variant.sh <name> -DDGS_SORT_MODE=2); the library reads no environment variable
+#ifndef DGS_SORT_MODE
+#define DGS_SORT_MODE 1
+#endif
+static constexpr int sort_mode() { return DGS_SORT_MODE; }
 
 // n_dev (optional): device word holding the actual pair count (<= n); every launch is then sized by the capacity n and
 // the kernels read the count themselves (no host read of num_rendered between duplication and sort)

@@ -126,7 +126,9 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
                     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dsh, float* __restrict__ dL_dsh_rest,
                     float* __restrict__ dL_dcolors,
                     float* __restrict__ dL_dopacity, float* __restrict__ dL_dscales, float* __restrict__ dL_drots,
-                    float* __restrict__ dL_dcov3D_out, double* __restrict__ partials, int g_begin, int g_end) {
+                    float* __restrict__ dL_dcov3D_out, double* __restrict__ partials, int g_begin, int g_end,
+                    const int32_t* __restrict__ radii, float* __restrict__ st_max_radii, float* __restrict__ st_accum,
+                    float* __restrict__ st_denom, float st_inc) {
   extern __shared__ __attribute__((aligned(16))) float s_part[];  // [waves][K][NMAT]
   if (status[5] != 0u) return;  // capacity mode, truncated lists (see contrib_reduce_kernel); the caller discards the step
   // Gaussians [g_begin, g_end) (g_begin a multiple of the block size): a caller may run the per-Gaussian half in index
@@ -171,13 +173,25 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
   // waves per SIMD, so they are issued ahead: row of k+2 and contribution row of k+1 are in flight while k computes.
   struct RowPf {
     uint32_t nt;
+    int32_t rad;    // fused densification statistics only
     float4 ga, gb;  // x, y, cx, cy | cz, op, r, g
   };
+  // densification statistics (train.py:188-193, scene/gaussian_model.py:456-458; DgsBackwardIO.stats_*): the thread has
+  // every subframe's screen gradient of its Gaussian in hand, in subframe order -- the separate statistics launch re-read
+  // the [K,P,3] gradient this kernel had just written (56 us and 0.4 GB per metric step)
+  const bool stats = st_max_radii != nullptr;
+  float st_mr = 0.0f, st_ac = 0.0f, st_dn = 0.0f;
+  if (stats && valid) {
+    st_mr = st_max_radii[gi];
+    st_ac = st_accum[gi];
+    st_dn = st_denom[gi];
+  }
   auto load_row = [&](int k) {
     RowPf r;
     const size_t o = (size_t)k * v.P + gi;
     const float4* rowp = reinterpret_cast<const float4*>(rows + o);
     r.nt = valid ? tiles_touched[o] : 0u;
+    r.rad = (stats && valid) ? radii[o] : 0;
     r.ga = rowp[0];   // unconditional (no dependent hop); rows of invisible pairs are never used
     r.gb = rowp[1];
     return r;
@@ -416,11 +430,16 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
       mat[19] = (float)(0.5 * g2y * v.H * m_w);
       mat[20] = (float)(-0.5 * lastcol);
     }
-    if (valid) {
+    if (valid && dL_dmeans2D != nullptr) {
       float* d2 = dL_dmeans2D + 3 * o;
       d2[0] = g2x;
       d2[1] = g2y;
       d2[2] = 0.0f;
+    }
+    if (stats && cur.rad > 0) {   // dgs_densify_stats' update of this subframe, same operations in the same order
+      st_mr = fmaxf(st_mr, (float)cur.rad);
+      st_ac += sqrtf(g2x * g2x + g2y * g2y);
+      st_dn += st_inc;
     }
     // ---- per-subframe pose gradients: wave sum (skipped when no lane of the wave is visible in k)
     if (__ballot(ntiles > 0) != 0ull) {
@@ -434,6 +453,11 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     }
   }
 
+  if (valid && stats) {
+    st_max_radii[gi] = st_mr;
+    st_accum[gi] = st_ac;
+    st_denom[gi] = st_dn;
+  }
   if (valid) {
     dL_dmeans3D[3 * idx + 0] = a_mean[0];
     dL_dmeans3D[3 * idx + 1] = a_mean[1];
@@ -647,7 +671,8 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
                      io.dL_dmeans2D, io.dL_dsh,                                                                       \
                      io.dL_dsh_rest,                                                                                 \
                      io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations, io.dL_dcov3D, partials, g_begin, \
-                     g_end)
+                     g_end, io.radii, io.stats_max_radii2D, io.stats_grad_accum, io.stats_denom,                      \
+                     (float)(1.0 / (double)(io.stats_K_total > 0 ? io.stats_K_total : v.K)))
   if ((phases & 2) && blocks > 0) {
     if (ncoef <= 1)
       DGS_GB_LAUNCH(1);

@@ -179,7 +179,7 @@ class FusedStep:
         return max(self.HYPER_FLOATS, 48 + f)
 
     def replay(self, cam_idx, lambda_t, gt, subframe_indice, optimizer, tail, signature=(), background=None,
-               uniform=None):
+               uniform=None, stats=None):
         """One training iteration as ONE hipGraph launch (SURVEY 8f / DESIGN 2b): alignment -> cameras -> dgs_forward
         (capacity sized ahead) -> loss -> dgs_backward -> camera gradients -> `tail` (densification statistics + the
         optimiser launch).  At DeblurGS's real scene sizes a step is ~60 kernels of a few microseconds each; replayed
@@ -209,10 +209,11 @@ class FusedStep:
         cull = dgr.TILE_CULL if self.tile_cull is None else bool(self.tile_cull)
         gkey = (int(cam_idx), subframe_indice, int(cloud.active_sh_degree), bool(m.is_optimizing()),
                 bool(m.curve_random_sample), cap, self._generation, gt.data_ptr(), bool(cull), bool(dgr.WIDE_RECORDS),
-                tuple(p.data_ptr() for p in hot), tuple(signature))
+                tuple(p.data_ptr() for p in hot), tuple(signature),
+                tuple(t.data_ptr() for t in stats) if stats is not None else ())
         ent = self._graphs.get(gkey)
         if ent is None:
-            ent = self._capture(gkey, cam_idx, gt, subframe_indice, cap, optimizer, tail)
+            ent = self._capture(gkey, cam_idx, gt, subframe_indice, cap, optimizer, tail, stats)
         # ---- this step's scalars: host block -> device block (the ring keeps a block alive until its copy has run)
         slot = self._ring[self._ring_pos % len(self._ring)] if self._ring else None
         if slot is None or slot[0].numel() != ent["hyper"].numel():
@@ -246,7 +247,7 @@ class FusedStep:
         self.replayed += 1
         return ent["result"]
 
-    def _capture(self, gkey, cam_idx, gt, subframe_indice, cap, optimizer, tail):
+    def _capture(self, gkey, cam_idx, gt, subframe_indice, cap, optimizer, tail, stats=None):
         cloud, m = self.cloud, self.motion
         dev = cloud._xyz.device
         f = m.n_subframes
@@ -269,7 +270,7 @@ class FusedStep:
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
-            fr = self.run(cam_idx, 0.0, gt, bg, subframe_indice, uniform=uniform, _cap=cap_args)
+            fr = self.run(cam_idx, 0.0, gt, bg, subframe_indice, uniform=uniform, _cap=cap_args, stats=stats)
         ent["graph"], ent["result"] = graph, fr
         ent["grads"] = [(p, p.grad) for p in params if p.grad is not None]
         self._graphs[gkey] = ent
@@ -279,7 +280,7 @@ class FusedStep:
     # ------------------------------------------------------------------------------------------------- the step
     @torch.no_grad()
     def run(self, cam_idx, lambda_t, gt, background, subframe_indice="all", need_blur=False, uniform=None,
-            lambda_depth_tv=0.0, shard=None, exact=False, need_depth=False, _cap=None, ar=None):
+            lambda_depth_tv=0.0, shard=None, exact=False, need_depth=False, _cap=None, ar=None, stats=None):
         """gt: [3,H,W] ground truth of view cam_idx (already tone-mapped / noised by the caller); background: [3].
         lambda_depth_tv > 0 adds the reference's optional depth-smoothness term (train.py:150-153,
         utils/loss_utils.py:66-78): its gradient on the K depth images is formed with a few torch ops and handed to the
@@ -295,6 +296,9 @@ class FusedStep:
         overlapped with the backward's tail: the per-Gaussian half of the backward runs in G Gaussian-index
         chunks (dgs_backward_geometry) and chunk i is reduced on a side stream while chunk i + 1 computes; the caller must
         then NOT reduce the bucket again (the trajectory gradients remain its job).
+        stats = (max_radii2D, xyz_gradient_accum, denom): the cloud's densification accumulators ([P] float32); the
+        backward then updates them itself (DgsBackwardIO.stats_*, exactly densify_stats.add_densification_stats_subframes
+        on this step's screen gradients) and 'viewspace_grad' comes back None -- the [K,P,3] gradient is never stored.
         _cap: internal, set by replay() while the step is being CAPTURED into a hipGraph -- the capacity, the pinned count
         words, the device words lambda_t is read from and the tail (statistics + optimiser launch) to enqueue; no host
         bookkeeping happens then.
@@ -448,7 +452,7 @@ class FusedStep:
         g_xyz, g_dc, g_op, g_sc, g_rot = (seg(0, (P, 3)), seg(1, cloud._features_dc.shape), seg(3, cloud._opacity.shape),
                                           seg(4, (P, 3)), seg(5, (P, 4)))
         g_rest = seg(2, cloud._features_rest.shape)
-        g_means2D = torch.empty((K, P, 3), **f32)
+        g_means2D = None if stats is not None else torch.empty((K, P, 3), **f32)
         g_colors = torch.empty((P, 3), **f32)
         g_cov3D = torch.empty((P, 6), **f32)
         g_view, g_proj = torch.empty((K, 4, 4), **f32), torch.empty((K, 4, 4), **f32)
@@ -477,6 +481,9 @@ class FusedStep:
         io.dL_dcov3D, io.dL_dviewmatrix, io.dL_dprojmatrix = _ptr(g_cov3D), _ptr(g_view), _ptr(g_proj)
         # sharded: the ranks' gradients are summed, so the hinge term is added by one of them only
         io.opacity_hinge_scale = self.lambda_hinge / max(P, 1) if (shard is None or int(shard[0]) == 0) else 0.0
+        if stats is not None:
+            io.stats_max_radii2D, io.stats_grad_accum, io.stats_denom = (_ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]))
+            io.stats_K_total = int(K_total)
         if ar is None or int(ar.get("chunks", 1)) <= 1 or P < 512:
             _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward")
             if ar is not None and P > 0:
@@ -513,7 +520,8 @@ class FusedStep:
             stream_obj.wait_event(done)
         if P == 0:
             flat.zero_()
-            g_means2D.zero_()
+            if g_means2D is not None:
+                g_means2D.zero_()
         cloud._xyz.grad, cloud._features_dc.grad, cloud._features_rest.grad = g_xyz, g_dc, g_rest
         cloud._opacity.grad, cloud._scaling.grad, cloud._rotation.grad = g_op, g_sc, g_rot
 

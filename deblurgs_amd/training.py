@@ -189,8 +189,14 @@ class TrainingLoop:
         ar = None
         if self.distributed and self.ar_chunks > 1:      # the bucket is reduced inside run(), chunk by chunk
             ar = {"chunks": self.ar_chunks, "average": self.mode != "subframes"}
+        # single process: the backward updates the densification statistics itself (no [K,P,3] screen gradient stored);
+        # sharded runs keep the separate launch (the statistics are snapshotted before it for their all-reduce)
+        stats = None
+        if iteration < self.opt.densify_until_iter and not self.distributed:
+            stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom)
         fr = self._fused.run(cam_idx, lambda_t_smooth, gt, bg, subframe_indice, uniform=uniform,
-                             lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0), shard=shard, exact=exact, ar=ar)
+                             lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0), shard=shard, exact=exact, ar=ar,
+                             stats=stats)
         skip = fr["skip_flag_ptr"]
         if self.distributed:
             from . import sharding
@@ -253,17 +259,16 @@ class TrainingLoop:
         g, opt = self.gaussians, self.opt
         stats_on = iteration < opt.densify_until_iter
 
-        def tail(fr, dev_scalars_ptr):         # recorded into the graph right after the backward (train.py:186-208)
-            if stats_on:
-                add_densification_stats_subframes(fr["viewspace_grad"], fr["radii"], g.max_radii2D, g.xyz_gradient_accum,
-                                                  g.denom, K_total=fr["K"], skip_flag_ptr=fr["skip_flag_ptr"])
-            g.optimizer.skip_flag_ptr = fr["skip_flag_ptr"]
+        stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if stats_on else None
+
+        def tail(fr, dev_scalars_ptr):         # recorded into the graph right after the backward (train.py:186-208);
+            g.optimizer.skip_flag_ptr = fr["skip_flag_ptr"]       # the statistics are updated by the backward itself
             g.optimizer.step_enqueue(dev_scalars_ptr)
 
         sig = (stats_on, g.max_radii2D.data_ptr(), g.xyz_gradient_accum.data_ptr(), g.denom.data_ptr(),
                float(self._fused.lambda_hinge), float(g.optimizer.clip_value))
         fr = self._fused.replay(cam_idx, lambda_t_smooth, gt, subframe_indice, g.optimizer, tail, signature=sig,
-                                background=bg_host, uniform=uni_host)
+                                background=bg_host, uniform=uni_host, stats=stats)
         if fr is None:
             return None
         g.optimizer.skip_flag_ptr = None
@@ -333,7 +338,7 @@ class TrainingLoop:
             if iteration < opt.densify_until_iter:
                 if self.distributed and self._stat_prev is None:
                     self._stat_prev = (g.xyz_gradient_accum.clone(), g.denom.clone())
-                if r["radii_all"].shape[0] > 0:
+                if r["radii_all"].shape[0] > 0 and r["viewspace_points_all"] is not None:   # (else: done by the backward)
                     add_densification_stats_subframes(r["viewspace_points_all"], r["radii_all"], g.max_radii2D,
                                                       g.xyz_gradient_accum, g.denom, K_total=r["K_total"],
                                                       skip_flag_ptr=r.get("skip_flag_ptr"))

@@ -116,7 +116,7 @@ typedef struct DgsBackwardIO {
    * subframes; the screen-space and pose grads stay per subframe because densification and the trajectory
    * consume them per subframe (train.py:188-193, scene/motion.py:248-294). */
   float* dL_dmeans3D;  /* [P,3] */
-  float* dL_dmeans2D;  /* [K,P,3] NDC-scaled screen gradient, .z = 0 (backward.cu:628-629) */
+  float* dL_dmeans2D;  /* [K,P,3] NDC-scaled screen gradient, .z = 0 (backward.cu:628-629); NULL allowed with stats_* */
   float* dL_dsh;       /* [P,M,3]  (NULL when colors_precomp was used); [P,1,3] with raw_params */
   float* dL_dsh_rest;  /* raw_params = 1 only: [P,M-1,3] */
   float* dL_dcolors;   /* [P,3]    (written always; the grad of colors_precomp when that was used) */
@@ -130,6 +130,16 @@ typedef struct DgsBackwardIO {
    * training loss's lambda_hinge * hinge_l2(_opacity) (utils/loss_utils.py:96-104, train.py:156-163) with
    * opacity_hinge_scale = lambda_hinge / P; 0 = off.  Saves the caller a dozen elementwise launches per step. */
   float opacity_hinge_scale;
+  /* Optional fused densification statistics (train.py:188-193, scene/gaussian_model.py:456-458): when
+   * stats_max_radii2D is non-NULL the per-Gaussian kernel updates the three [P] accumulators in place exactly as
+   * dgs_densify_stats(dL_dmeans2D, radii, K, stats_K_total, ...) would right after this backward (same operations,
+   * subframe order; nothing is touched when the forward's overflow flag is set), and dL_dmeans2D may then be NULL:
+   * the [K,P,3] screen gradient is neither written nor re-read.  stats_K_total: len(render_pkgs) of the whole view
+   * (0 = K). */
+  float* stats_max_radii2D;
+  float* stats_grad_accum;
+  float* stats_denom;
+  int32_t stats_K_total;
 } DgsBackwardIO;
 
 /* Byte offsets of the sub-arrays inside the three blobs (for debuggers and the parity tests).

@@ -17,7 +17,8 @@ import sys
 
 STAGE_OF = {
     "composite_bwd_kernel": "composite_bwd", "composite_fwd_kernel": "composite_fwd",
-    "preprocess_fwd_kernel": "preprocess", "tight_kernel<true>": "duplicate", "tight_kernel<false>": "tile_cull(count)",
+    "preprocess_fwd_kernel": "preprocess", "cull_emit_kernel": "duplicate", "cull_count_kernel": "tile_cull(count)",
+    "gather_cnt_kernel": "tile_cull(gather)",
     "duplicate_sorted_kernel": "duplicate", "ranges_kernel": "ranges", "contrib_reduce_kernel": "geometry_bwd(contrib_reduce)",
     "geometry_bwd_kernel": "geometry_bwd(kernel)", "onesweep_scatter_kernel": "sort(scatter)",
     "sort_hist_rows_kernel": "sort(hist)", "blur_loss_kernel": "blur_loss", "blur_loss_all_kernel": "blur_loss",

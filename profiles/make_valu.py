@@ -53,7 +53,7 @@ out = {"_config": sys.argv[2] if len(sys.argv) > 2 else "metric",
                 "GRBM_GUI_ACTIVE / 8); weighted_busy_frac = sum_class(dynamic count * measured issue cost) / (1024 SIMDs * cycles)",
        "_class_cost_cycles": {k: round(v, 2) for k, v in cost.items()}}
 for k, c in agg.items():
-    if not any(x in k for x in ("composite", "geometry_bwd_kernel", "preprocess", "contrib", "tight_kernel")):
+    if not any(x in k for x in ("composite", "geometry_bwd_kernel", "preprocess", "contrib", "cull_count_kernel", "cull_emit_kernel")):
         continue
     v = {n: sum(x) / len(x) for n, x in c.items()}
     cyc = v["GRBM_GUI_ACTIVE"] / 8

@@ -522,6 +522,46 @@ def test_fused_step_speculative_capacity_and_overflow(gpu):
     assert fs._seen == {} and fs.run(0, 1e-3, m.get_gt_image(0), bg)["skip_flag_ptr"] is None
 
 
+def test_backward_updates_densification_statistics_itself(gpu):
+    """DgsBackwardIO.stats_*: the per-Gaussian backward kernel updates max_radii2D / xyz_gradient_accum / denom exactly
+    as the separate statistics launch does from the stored screen gradient (train.py:188-193), bit for bit, over
+    several steps, for all subframes and for a subset; no [K,P,3] gradient comes back; an overflowed step leaves the
+    accumulators untouched."""
+    import torch
+    from deblurgs_amd.densify_stats import add_densification_stats_subframes
+    from deblurgs_amd.fused_step import FusedStep
+    from deblurgs_amd.training import default_optimization_params
+    sc, cloud, m = _fused_fixture(seed=6)
+    cloud.training_setup(default_optimization_params(), spatial_lr_scale=1.0)
+    bg = torch.tensor([0.1, 0.4, 0.2], device="cuda")
+    fs = FusedStep(cloud, m, lambda_hinge=0.1, speculative=True)
+    ref = [cloud.max_radii2D.clone(), cloud.xyz_gradient_accum.clone(), cloud.denom.clone()]
+    fused = [t.clone() for t in ref]
+    for it, sub in enumerate(("all", 1, "all", 3)):
+        a = fs.run(it % 2, 1e-3, m.get_gt_image(it % 2), bg, subframe_indice=sub)
+        add_densification_stats_subframes(a["viewspace_grad"], a["radii"], ref[0], ref[1], ref[2], K_total=a["K"],
+                                          skip_flag_ptr=a["skip_flag_ptr"])
+        ga = [p.grad.clone() for p in cloud.hot_parameters()]
+        b = fs.run(it % 2, 1e-3, m.get_gt_image(it % 2), bg, subframe_indice=sub, stats=tuple(fused))
+        assert b["viewspace_grad"] is None and torch.equal(a["radii"], b["radii"])
+        for x, y in zip(ga, [p.grad for p in cloud.hot_parameters()]):
+            assert torch.equal(x, y)
+        for x, y in zip(ref, fused):
+            assert torch.equal(x, y)
+        fs._poll(block=True)
+    assert float(ref[2].sum()) > 0 and float(ref[1].sum()) > 0
+    # ---- overflow: nothing is touched
+    key = (0, 5, 0)
+    fs._seen[key] = [fs._seen[key][-1] // 3]
+    before = [t.clone() for t in fused]
+    c = fs.run(0, 1e-3, m.get_gt_image(0), bg, stats=tuple(fused))
+    torch.cuda.synchronize()
+    fs._poll(block=True)
+    assert fs.dropped == 1 and c["skip_flag_ptr"] is not None
+    for x, y in zip(before, fused):
+        assert torch.equal(x, y)
+
+
 def test_training_loop_makes_up_for_dropped_steps_and_views_differ(gpu):
     """Views with very different duplicate counts, the 1 -> all subframes switch at curve_start_iter and a densification:
     none of them may drop a step (counts are learnt per view and subframe count, forgotten when the cloud changes); a

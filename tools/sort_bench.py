@@ -1,4 +1,4 @@
-"""Micro-benchmark of dgs_sort_pairs (A/B of DGS_SORT modes): python tools/sort_bench.py [n] [bits]"""
+"""Micro-benchmark of dgs_sort_pairs (A/B of sort modes: build variants with tools/build_flag_variant.sh <name> -DDGS_SORT_MODE=0|1|2 and select one with DGS_LIB_PATH): python tools/sort_bench.py [n] [bits]"""
 import ctypes, sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,4 +23,4 @@ def run():
 ts = [run() for _ in range(6)]
 ko = k1 if alt.value else k0
 ok = bool((ko[1:] >= ko[:-1]).all().item())
-print(f"DGS_SORT={os.environ.get('DGS_SORT','default')} n={n} bits={bits} ms={min(ts[1:]):.3f} sorted={ok}")
+print(f"lib={os.environ.get('DGS_LIB_PATH','default')} n={n} bits={bits} ms={min(ts[1:]):.3f} sorted={ok}")
