@@ -141,7 +141,7 @@ class ReferenceTrainer:
                 self._densify(threshold, split_noise)
         if iteration < o.iterations:
             self.optim.step()
-        return {"l1": float(l1), "smooth": float(sm), "num_points": self.p["xyz"].shape[0]}
+        return {"l1": float(l1.detach()), "smooth": float(sm.detach()), "num_points": self.p["xyz"].shape[0]}
 
     def _densify(self, threshold, split_noise):
         st = self.optim.state
