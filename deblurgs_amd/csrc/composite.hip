@@ -23,6 +23,14 @@ namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // lowers to v_pk_{mul,add,fma}_f32 on gfx950
 
+// Backward: how the ten per-lane sums of a list entry become one contribution row.  1 (default): through LDS -- ten
+// conflict-free 4-byte stores per lane, 40 lanes read 16 values each and add them, the totals go straight to the row in
+// global memory (one 40-byte store per entry).  0: the round-2 reduce-scatter on the VALU (v_permlane*_swap + DPP) with the
+// batch's rows staged in LDS.  Same box, metric config: 5.40 ms against 5.81 ms per launch (and 83 instead of 86 VGPRs,
+// 23 instead of 24.5 KB of LDS per block); tools/build_flag_variant.sh <name> -DDGS_BWD_LDS_REDUCE=0 rebuilds the other one.
+#ifndef DGS_BWD_LDS_REDUCE
+#define DGS_BWD_LDS_REDUCE 1
+#endif
 constexpr int CW = 4;  // waves (= tiles) per 256-thread block; the waves never synchronise with each other
 
 struct TileCtx {
@@ -238,7 +246,14 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
                      const float* __restrict__ dL_ddepth, const uint32_t* __restrict__ dup_off,
                      float* __restrict__ contrib) {
   __shared__ float4 s_row[CW][64 * 3];  // (x, y, A, B | C, op, r, g | b, depth, -, -) per list entry
+#if !DGS_BWD_LDS_REDUCE
   __shared__ float4 s_acc[CW][64][3];  // per-duplicate gradient rows of the current batch
+#endif
+#if DGS_BWD_LDS_REDUCE
+  // the ten per-lane sums of a list entry, value-major (row stride 68 floats: the 16-byte column reads of the rows start
+  // in different banks)
+  __shared__ __attribute__((aligned(16))) float s_part[CW][10][68];
+#endif
   TileCtx t;
   if (!load_tile_ctx(v, ranges, per_xcd, t)) return;
   const int lane = dgs_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -250,6 +265,13 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   // contribution-row slot this lane stores after the per-duplicate reduce-scatter (-1: none); slots are
   // [S_wx, S_wy, S_xx, S_xy, S_yy, S_w, r, g, b, depth]
+#if DGS_BWD_LDS_REDUCE
+  // reduction through LDS: lane (row = lane >> 2, quarter = lane & 3), row < 10 (9 without a depth gradient), sums 16 lanes'
+  // values of sum `row`; the quad's four partial sums are combined with two DPP adds and lane quarter 0 stores the total
+  const int rrow = lane >> 2, rq = lane & 3;
+  const bool rlane = rrow < (HASDEPTH ? 10 : 9);
+#endif
+#if !DGS_BWD_LDS_REDUCE
   int wslot = -1;
   if ((lane & 3) == 0) {
     const int rr = lane >> 4, bank = (lane & 15) >> 2;
@@ -258,6 +280,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     if (bank == 1 && rr == 0) wslot = 8;
     if (bank == 1 && rr == 2) wslot = 9;
   }
+#endif
   
 
   // per-pixel channel state kept as (r,g) and (b,depth) pairs so the channel arithmetic issues as packed fp32
@@ -347,9 +370,20 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       s_row[w][3 * lane + 2] = make_float4(Cc.x, Cc.y, 0.0f, 0.0f);
     }
     const float4 z4 = make_float4(0, 0, 0, 0);
+#if !DGS_BWD_LDS_REDUCE
     s_acc[w][lane][0] = z4;
     s_acc[w][lane][1] = z4;
     s_acc[w][lane][2] = z4;
+#else
+    // totals go straight to the contribution rows (one 40-byte store per entry); an entry that no pixel of the tile
+    // reaches any more is never walked: its row is zero-filled here
+    if (has && (((m[0] | m[1] | m[2] | m[3]) >> lane) & 1ull) == 0ull) {
+      float4* dst = reinterpret_cast<float4*>(contrib + (size_t)u * DGS_CONTRIB_F);
+      dst[0] = z4;
+      dst[1] = z4;
+      dst[2] = z4;
+    }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -371,6 +405,8 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       // backward.cu:620-637 is a per-Gaussian linear map of {sum w, sum w*dx, sum w*dy, sum w*dx*dx, sum w*dx*dy,
       // sum w*dy*dy}; that map (conic / opacity / 0.5*W factors) is applied once per (subframe, Gaussian) in
       // geometry_bwd.hip instead of once per pixel here.
+      // (starting the accumulators from three 16-byte LDS reads of zeros instead of v_mov measured slower: the compiler
+      // already starts them with the first executed pass when quadrant 0 is hit)
       float S_w = 0, S_wx = 0, S_wy = 0, S_xx = 0, S_xy = 0, S_yy = 0;
       v2f sA = {0.0f, 0.0f}, sB = {0.0f, 0.0f};  // (dL_dr, dL_dg), (dL_db, dL_ddepth)
       const v2f colA = {b.z, b.w}, colB = {c.x, c.y};
@@ -415,6 +451,47 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           S_yy = fmaf(wy, dy, S_yy);
         }
       }
+#if DGS_BWD_LDS_REDUCE
+      {
+        // 10 wave sums through LDS instead of the VALU (which this kernel saturates): ten conflict-free 4-byte stores per
+        // lane, then 40 lanes read 16 values each (four 16-byte loads) and add them; the cross-lane instructions of the
+        // reduce-scatter below (8 v_permlane*_swap at 5.4 issue cycles, 7 DPP adds at 4.4) become 15 plain adds and 2 DPP
+        // adds, and the LDS pipe -- nearly idle here -- does the data movement.  Fixed order of additions: deterministic.
+        float* pw = &s_part[w][0][lane];
+        pw[0 * 68] = S_wx;
+        pw[1 * 68] = S_wy;
+        pw[2 * 68] = S_xx;
+        pw[3 * 68] = S_xy;
+        pw[4 * 68] = S_yy;
+        pw[5 * 68] = S_w;
+        pw[6 * 68] = sA.x;
+        pw[7 * 68] = sA.y;
+        pw[8 * 68] = sB.x;
+        if (HASDEPTH) pw[9 * 68] = sB.y;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float tot = 0.0f;
+        if (rlane) {
+          const float4* pr = reinterpret_cast<const float4*>(&s_part[w][rrow][16 * rq]);
+          const float4 x0 = pr[0], x1 = pr[1], x2 = pr[2], x3 = pr[3];
+          tot = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
+                (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
+        }
+        tot = dgs_quad_sum(tot);
+        asm volatile("" : "+v"(tot));
+        {
+          // (the row address is one quarter-rate v_mad_u64_u32 per entry; forming it on the scalar unit -- readlane, two
+          // multiplies, add with carry, global_store with a scalar base -- measured slower: 5.57 vs 5.40 ms.)  Without a
+          // depth gradient the lanes of column 9 read nothing and store the 0 they started from; columns 10 and 11 of a
+          // row are never read as values.
+          const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
+          float* crow = contrib + (size_t)uj * DGS_CONTRIB_F;
+          if (rrow < 10 && rq == 0) crow[rrow] = tot;
+        }
+        __builtin_amdgcn_wave_barrier();   // the next entry's stores follow this entry's loads (LDS runs a wave's ops in order)
+      }
+#else
       {  // (every dup that reaches here passed the quadrant test for >= 1 quadrant; 98 % of those passes contribute)
         // 10 wave sums as a reduce-scatter: every fold level halves the number of live registers -- v_permlane32_swap
         // (half waves), v_permlane16_swap (rows), then bank-masked DPP adds inside the rows (8 lanes, 4 lanes) and a
@@ -432,6 +509,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         // (32-bit LDS index: the generic float* arithmetic compiled to a quarter-rate v_mad_u64_u32)
         if (wslot >= 0) reinterpret_cast<float*>(&s_acc[w][0][0])[j * DGS_CONTRIB_F + wslot] = tot;
       }
+#endif
     }
     };
     if ((~pdm & mu_all) == 0ull)
@@ -441,12 +519,14 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if !DGS_BWD_LDS_REDUCE
     if (has) {
       float4* dst = reinterpret_cast<float4*>(contrib + (size_t)u * DGS_CONTRIB_F);
       dst[0] = s_acc[w][lane][0];
       dst[1] = s_acc[w][lane][1];
       dst[2] = s_acc[w][lane][2];
     }
+#endif
     __builtin_amdgcn_wave_barrier();
   }
 }
