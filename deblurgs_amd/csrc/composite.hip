@@ -26,7 +26,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // lowers to v_pk_{mul,a
 // Backward: how the ten per-lane sums of a list entry become one contribution row.  1 (default): through LDS -- ten
 // conflict-free 4-byte stores per lane, 40 lanes read 16 values each and add them, the totals go straight to the row in
 // global memory (one 40-byte store per entry).  0: the round-2 reduce-scatter on the VALU (v_permlane*_swap + DPP) with the
-// batch's rows staged in LDS.  Same box, metric config: 5.40 ms against 5.81 ms per launch (and 83 instead of 86 VGPRs,
+// batch's rows staged in LDS.  Same box, metric config: 5.41 ms against 5.70-5.77 ms per launch (and 83 instead of 86 VGPRs,
 // 23 instead of 24.5 KB of LDS per block); tools/build_flag_variant.sh <name> -DDGS_BWD_LDS_REDUCE=0 rebuilds the other one.
 #ifndef DGS_BWD_LDS_REDUCE
 #define DGS_BWD_LDS_REDUCE 1
@@ -475,6 +475,8 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         if (rlane) {
           const float4* pr = reinterpret_cast<const float4*>(&s_part[w][rrow][16 * rq]);
           const float4 x0 = pr[0], x1 = pr[1], x2 = pr[2], x3 = pr[3];
+          // (a packed tree -- the 16-byte loads deliver aligned register pairs, 8 v_pk_add_f32 / v_add instead of 15
+          // v_add, no moves -- measured slower on the same box: 5.47-5.52 against 5.41 ms)
           tot = (((x0.x + x0.y) + (x0.z + x0.w)) + ((x1.x + x1.y) + (x1.z + x1.w))) +
                 (((x2.x + x2.y) + (x2.z + x2.w)) + ((x3.x + x3.y) + (x3.z + x3.w)));
         }
@@ -482,7 +484,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         asm volatile("" : "+v"(tot));
         {
           // (the row address is one quarter-rate v_mad_u64_u32 per entry; forming it on the scalar unit -- readlane, two
-          // multiplies, add with carry, global_store with a scalar base -- measured slower: 5.57 vs 5.40 ms.)  Without a
+          // multiplies, add with carry, global_store with a scalar base -- measured the same: 5.41 / 5.45 ms.)  Without a
           // depth gradient the lanes of column 9 read nothing and store the 0 they started from; columns 10 and 11 of a
           // row are never read as values.
           const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
