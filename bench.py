@@ -28,6 +28,7 @@ Prints ONE JSON line on rank 0 (metric contract + "roofline" for the dominant ke
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -157,7 +158,9 @@ def stage_bytes(P, Pv_tot, R_tot, N, K, s):
         "scan": 8 * P * K,
         "duplicate": 20 * P * K + 12 * R_tot,
         "sort": 24 * R_tot,
-        "ranges": 8 * R_tot,
+        # tile ranges by binary search over the sorted keys: per tile (N / 256 of them per subframe) one 8-byte result
+        # and ~log2(R) 8-byte probes; the reference's one-thread-per-key sweep reads 8 R bytes (DGS_RANGES_SWEEP)
+        "ranges": (N * K / 256.0) * (8 + 8 * max(math.log2(max(R_tot, 2)), 1.0)),
         "composite_fwd": (28 + 16) * R_tot + 24 * N * K,
         "composite_bwd": 44 * R_tot + 24 * N * K + 2 * 48 * Pv_tot,
         "geometry_bwd": Pv_tot * (100 + 12 * s + 48) + P * (40 + 12 * s),
