@@ -829,11 +829,12 @@ colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nblocks, const uint3
   ctot[(size_t)blockIdx.x * SORT_MAX_BINS + threadIdx.x + 256] = run1;
 }
 
-// one block: chunk totals -> exclusive chunk bases per digit, plus the exclusive base of each digit.
+// one block: chunk totals -> exclusive chunk bases per digit (in place), plus the exclusive base of each digit (dbase).
 // The chunk loop is latency-bound (one block, dependent only through the running sums), so rows are fetched
 // 32 at a time before the serial prefix is applied.
 __global__ void __launch_bounds__(256)
-colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nchunks, const uint32_t* __restrict__ n_dev) {
+colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nchunks, const uint32_t* __restrict__ n_dev,
+                   uint32_t* __restrict__ dbase) {
   if (n_dev != nullptr) {
     const uint32_t nb = (uint32_t)(((uint64_t)n_dev[0] + SORT_TILE - 1) / SORT_TILE);
     nchunks = min(nchunks, (nb + CS_CHUNK - 1) / CS_CHUNK);
@@ -861,28 +862,13 @@ colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nchunks, const uint32_t
       run1 += b[u];
     }
   }
-  // digit order is 0..255 (run0 of thread t) then 256..511 (run1 of thread t)
+  // digit order is 0..255 (run0 of thread t) then 256..511 (run1 of thread t).  The digit bases go to a row of their own
+  // (dbase) that the scatter adds itself: a second sweep over the chunk rows to fold them in doubled this kernel's time.
   uint32_t tot0, tot1;
   const uint32_t pre0 = block_excl_scan(run0, &tot0, lds);
   const uint32_t pre1 = block_excl_scan(run1, &tot1, lds) + tot0;
-  for (uint32_t c0 = 0; c0 < nchunks; c0 += U) {
-    uint32_t a[U], b[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const bool ok = c0 + u < nchunks;
-      const uint32_t* row = ctot + (size_t)(ok ? c0 + u : c0) * SORT_MAX_BINS;
-      a[u] = row[threadIdx.x];
-      b[u] = row[threadIdx.x + 256];
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (c0 + u < nchunks) {
-        uint32_t* row = ctot + (size_t)(c0 + u) * SORT_MAX_BINS;
-        row[threadIdx.x] = a[u] + pre0;
-        row[threadIdx.x + 256] = b[u] + pre1;
-      }
-    }
-  }
+  dbase[threadIdx.x] = pre0;
+  dbase[threadIdx.x + 256] = pre1;
 }
 
 // ------------------------------------------------------------------------------------ onesweep radix sort
@@ -1016,9 +1002,10 @@ onesweep_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __
     uint32_t* mine = status + (size_t)tile * SORT_MAX_BINS + d;
     uint32_t excl = 0;
     if (!LOOKBACK) {
-      // gbase = tile-major table of in-chunk exclusive counts, status = chunk bases (incl. digit bases)
-      gb[d] = gbase[(size_t)tile * SORT_MAX_BINS + d] + status[(size_t)(tile / CS_CHUNK) * SORT_MAX_BINS + d] -
-              (e == 0 ? pre2 : pre2 + cnt[0]);
+      // gbase = tile-major table of in-chunk exclusive counts, status = chunk bases, followed by the row of digit bases
+      const uint32_t cap_chunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
+      gb[d] = gbase[(size_t)tile * SORT_MAX_BINS + d] + status[(size_t)(tile / CS_CHUNK) * SORT_MAX_BINS + d] +
+              status[(size_t)cap_chunks * SORT_MAX_BINS + d] - (e == 0 ? pre2 : pre2 + cnt[0]);
       continue;
     }
     if (tile == 0) {
@@ -1316,7 +1303,7 @@ size_t dgs_sort_tmp_words(uint64_t n) {
   const uint64_t nblocks = (n + SORT_TILE - 1) / SORT_TILE;
   const uint64_t table = nblocks * SORT_MAX_BINS;  // classic: histogram table; onesweep: look-back status words
   const uint64_t chunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
-  return (size_t)(table + dgs_scan_tmp_words(table) + OS_MAX_PASSES * SORT_MAX_BINS + chunks * SORT_MAX_BINS + 256);
+  return (size_t)(table + dgs_scan_tmp_words(table) + OS_MAX_PASSES * SORT_MAX_BINS + (chunks + 1) * SORT_MAX_BINS + 256);
 }
 
 // DGS_SORT_MODE = 0 classic | 1 reorder (default) | 2 onesweep: compile-time A/B switch for the sort benchmark
@@ -1385,7 +1372,8 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
       hipLaunchKernelGGL(sort_hist_rows_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, n_dev, plan.shift[p],
                          plan.rb[p], table);
       hipLaunchKernelGGL(colscan_chunk_kernel, dim3(nchunks), dim3(256), 0, s, table, nblocks, n_dev, ctot);
-      hipLaunchKernelGGL(colscan_top_kernel, dim3(1), dim3(256), 0, s, ctot, nchunks, n_dev);
+      hipLaunchKernelGGL(colscan_top_kernel, dim3(1), dim3(256), 0, s, ctot, nchunks, n_dev,
+                         ctot + (size_t)nchunks * SORT_MAX_BINS);
       hipLaunchKernelGGL(onesweep_scatter_kernel<false>, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout,
                          n, plan.shift[p], plan.rb[p], table, ctot, nullptr, nblocks, n_dev);
       uint64_t* tk = kin;
