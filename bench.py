@@ -291,7 +291,7 @@ def run_rank(args):
     mode = False if world == 1 else args.shard
     loop = TrainingLoop(cloud, motion, opt, cameras_extent=1.0, spatial_lr_scale=1.0, distributed=mode,
                         fused_step=False if args.autograd_path else "auto", log_losses=False,
-                        graph=False if args.no_graph else "auto", ar_chunks=args.ar_chunks)
+                        graph=False if args.no_graph else "always", ar_chunks=args.ar_chunks)
     # The ground truth is noise, so real learning rates would pull the cloud away from the configured workload within
     # the timed region (opacities collapse and the step gets ~5 % cheaper).  The Adam kernel does the same work for
     # any learning rate; scale the rates down so that every timed step renders the workload BASELINE.json names.

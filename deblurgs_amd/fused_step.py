@@ -69,6 +69,7 @@ class FusedStep:
         self._drops_dev = None      # device word: forwards that overflowed so far (DgsForwardOut.drop_counter)
         self._graphs = {}           # captured steps by what they bake in (replay)
         self._pool = None           # one memory pool for all of them: replays never overlap
+        self._release_pool = False  # a dropped pool's blocks go back to the driver before the next capture
         self._ring, self._ring_pos = [], 0
         self.max_graphs = 256
         self.captured = 0
@@ -107,7 +108,14 @@ class FusedStep:
         on their way back -- so that every view takes the exact path once."""
         self._generation += 1
         self._seen = {}
-        self._graphs = {}
+        if self._graphs or self._pool is not None:
+            # the captured steps die with the cloud they were captured for, and their memory pool with them: a pool only
+            # ever grows (a block freed by one capture is re-used by the next only if it is large enough), so a cloud that
+            # grows a little at every densification would otherwise leave one full set of step buffers behind per
+            # generation (soak run, 100 k -> 3.4 M Gaussians: 159 GiB instead of 25)
+            self._graphs = {}
+            self._pool = None
+            self._release_pool = True
 
     def _host_words(self):
         if self._free_hosts:
@@ -256,6 +264,11 @@ class FusedStep:
         hyper = torch.zeros(self._hyper_words(f), dtype=torch.float32, device=dev)
         host = torch.zeros(8, dtype=torch.int32).pin_memory()
         self._drop_counter(dev)
+        if self._release_pool:
+            self._release_pool = False
+            self._keep = None
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
         ent = {"hyper": hyper, "host": host}
@@ -271,8 +284,17 @@ class FusedStep:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
             fr = self.run(cam_idx, 0.0, gt, bg, subframe_indice, uniform=uniform, _cap=cap_args, stats=stats)
-        ent["graph"], ent["result"] = graph, fr
+        # What a replay leaves behind for the host is the two loss values, the count words (pinned) and the gradients of
+        # the parameters; everything else the step allocated is released to the pool here, so that the captures of the
+        # other views re-use the same blocks (every replay is a complete step: nothing of one replay is read after the
+        # next has started) -- the pool holds ONE step's buffers plus a gradient bucket per graph, not one full set of
+        # buffers per view.  (`losses` of a replay must therefore be read before the next replay is launched.)
+        ent["graph"] = graph
+        ent["result"] = {"losses": fr["losses"], "K": fr["K"], "skip_flag_ptr": fr["skip_flag_ptr"], "blur": None,
+                         "radii": None, "viewspace_grad": None, "subframes": None, "depths": None, "depth_tv": None}
         ent["grads"] = [(p, p.grad) for p in params if p.grad is not None]
+        del fr
+        self._keep = None
         self._graphs[gkey] = ent
         self.captured += 1
         return ent

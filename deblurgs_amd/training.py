@@ -29,7 +29,7 @@ def default_optimization_params(**overrides):
 class TrainingLoop:
     def __init__(self, gaussians, cam_motion_module, opt, cameras_extent, white_background=False, spatial_lr_scale=None,
                  distributed=False, tone_mapping=None, fused_step="auto", speculative=True, log_losses=True, graph="auto",
-                 ar_chunks=1):
+                 ar_chunks=1, graph_min_reuse=8):
         """distributed = "views" (or True): every rank steps on its own view (the caller passes each rank its cam_idx);
         the per-Gaussian AND trajectory gradients are averaged over ranks (one flat all-reduce + one few-KB one) before
         the Adam step and the densification statistics are combined before every densify_and_prune, so the replicas
@@ -51,7 +51,12 @@ class TrainingLoop:
         graph: "auto" (default) replays the fused iteration -- including the densification statistics and the optimiser
         launch -- as ONE captured hipGraph per (view, subframe selection, SH degree, ...) whenever that is possible
         (single process, no depth-smoothness term, no ground-truth noise, not an iteration that densifies or resets
-        opacities), falling back to the eager fused step otherwise; False never captures.  FusedStep.replay has the details.
+        opacities), falling back to the eager fused step otherwise; False never captures; "always" captures whenever
+        possible.  FusedStep.replay has the details.
+        A capture costs tens of milliseconds (more for large clouds) and every densification invalidates all of them, so
+        while the cloud is still being densified "auto" only captures when a view can expect to be replayed often enough
+        before the next densification: densification_interval / number of views >= graph_min_reuse (the reference's
+        defaults, 100 iterations and tens of views, stay eager until densify_until_iter and replay afterwards).
         log_losses=False skips forming the scalar "loss" entry of step()'s result (two tiny launches).
         Not carried over from train.py: logging / visualiser / checkpoint-saving calls and `args.flag`."""
         self.gaussians, self.motion, self.opt, self.extent = gaussians, cam_motion_module, opt, cameras_extent
@@ -80,6 +85,8 @@ class TrainingLoop:
         cam_motion_module.alternate_optimization()      # train.py:102, unconditional: curve gradients off at the start
         self.log_losses = log_losses
         self.graph = bool(graph)
+        self._graph_always = graph == "always"      # capture whenever possible, whatever the expected re-use
+        self.graph_min_reuse = int(graph_min_reuse)
         self.ar_chunks = int(ar_chunks)
         self.fixed_background = None    # a [3] tensor here replaces the random background (scene/motion.py:112-113)
         self.split_noise_fn = None      # f(iteration, m) -> [2 m, 3] standard normals for densify_and_split (tests)
@@ -249,6 +256,9 @@ class TrainingLoop:
             return False
         if iteration < opt.densify_until_iter:      # densify_and_prune / reset_opacity go BETWEEN statistics and step
             if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+                return False
+            n_views = int(self.motion.gt_images.shape[0])       # captures die with every densification: see __init__
+            if not self._graph_always and opt.densification_interval < self.graph_min_reuse * max(n_views, 1):
                 return False
             if iteration % opt.opacity_reset_interval == 0 or (self.white_background and
                                                                iteration == opt.densify_from_iter):

@@ -654,7 +654,7 @@ def test_graph_replay_equals_eager_fused_step(gpu):
                                           densify_grad_threshold_init=2e-5, densify_grad_threshold_final=1e-5,
                                           opacity_reset_interval=1000, curve_alignment_lr=1e-3, curve_alignment_start=8,
                                           lambda_t_smooth_init=1e-2, lambda_t_smooth_final=1e-4)
-        loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, graph="auto" if use_graph else False)
+        loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, graph="always" if use_graph else False)
         loop.fixed_background = torch.tensor([0.25, 0.5, 0.125])
         hist = []
         for it in range(1, 41):
@@ -675,6 +675,16 @@ def test_graph_replay_equals_eager_fused_step(gpu):
                           [st[p]["exp_avg"].clone() for p in cloud.hot_parameters()],
                           [float(st[p]["step"]) for p in cloud.hot_parameters()],
                           [cloud.max_radii2D.clone(), cloud.xyz_gradient_accum.clone(), cloud.denom.clone()], hist)
+    # graph="auto": a capture dies with every densification, so while the cloud is being densified steps are only
+    # captured when densification_interval / views promises enough replays (12 / 3 views < 8 here); afterwards always
+    sc, cloud, m = _fused_fixture(seed=9, K=5, P=3000)
+    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0)
+    for it in range(1, 41):
+        loop.step(it, it % 3)
+        if it == 29:
+            assert loop._fused.captured == 0 and loop._fused.replayed == 0
+    torch.cuda.synchronize()
+    assert loop._fused.captured >= 1 and loop._fused.replayed >= 4, (loop._fused.captured, loop._fused.replayed)
     a, b = res[True], res[False]
     assert a[2] == b[2], (a[2], b[2])
     assert a[4] == b[4], "loss history"
