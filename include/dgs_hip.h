@@ -156,13 +156,14 @@ typedef struct DgsLayout {
                           * index) order; undefined for invisible pairs).  With tile culling the backward uses
                           * offs_tight (same order as tt_tight) and the emission index in the low key word. */
   size_t scan_tmp;       /* u32 scan block sums */
-  size_t num_rendered;   /* u32 [4] device copy of R (+ spare) */
+  size_t num_rendered;   /* u32 [8] status words: [0],[1] rectangle total lo/hi (tile_cull = 0), [2],[3] surviving total lo/hi
+                          * (tile_cull = 1), [4] the count the lists were built with, [5] overflow flag (capacity mode) */
   size_t gsort_keys;     /* u32 [K,P] depth bits (0xFFFFFFFF = invisible): keys of the segmented depth sort */
   size_t gsort_keys_alt; /* u32 [K,P] its ping-pong buffer */
   size_t gsort_vals;     /* u32 [K*P] flat (k, Gaussian) indices in (k, depth, index) order (the sort's result) */
   size_t gsort_vals_alt; /* u32 [K*P] */
   size_t tt_sorted;      /* u32 [K*P] tiles_touched in (k, depth, index) order (tile_cull: 1 / 0 = visible / not) */
-  size_t offs_sorted;    /* u32 [K*P] its exclusive prefix sum */
+  size_t offs_sorted;    /* u32 [K*P] its exclusive prefix sum (tile_cull = 0 only) */
   size_t tt_tight;       /* u32 [K*P] tile_cull: surviving tiles per (k, Gaussian), same order */
   size_t offs_tight;     /* u32 [K*P] its exclusive prefix sum (its total is R under tile_cull) */
   size_t gsort_tmp;      /* u32 radix tables of the Gaussian sort */
