@@ -169,6 +169,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m deblurgs_amd.build` (hipcc, gfx950). "
                 "deblurgs_amd has no CPU fallback.")
+        # torch first: it brings its own copy of the HIP runtime, and the device memory and streams this library is handed
+        # come from that copy -- loaded before torch, the library would bind to the system's libamdhip64 instead and its
+        # first call on a torch stream would fail with "no ROCm-capable device is detected"
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)
