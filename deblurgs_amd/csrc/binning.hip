@@ -1085,10 +1085,22 @@ dsort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t P, uint32_t nb, in
   __syncthreads();
   const uint32_t k = blockIdx.x / nb, b = blockIdx.x - k * nb;
   const uint32_t* seg = keys + (size_t)k * P;
+  const int lane = dgs_lane();
 #pragma unroll 4
   for (int r = 0; r < DS_ITEMS; r++) {
     const uint32_t i = b * DS_TILE + (uint32_t)r * DS_THREADS + threadIdx.x;
-    if (i < P) atomicAdd(&h[(seg[i] >> shift) & 255u], 1u);
+    const bool valid = i < P;
+    const uint32_t d = valid ? (seg[i] >> shift) & 255u : 0u;
+    // the upper digits of depth keys take a handful of values (exponent bits), and after the earlier passes a wave's 64
+    // keys often share theirs: one add of the wave's count instead of 64 same-address LDS atomics
+    const uint64_t vm = __ballot(valid);
+    if (vm == 0ull) continue;
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, __builtin_ctzll(vm));
+    if (__ballot(valid && d != d0) == 0ull) {
+      if (lane == __builtin_ctzll(vm)) atomicAdd(&h[d0], (uint32_t)__builtin_popcountll(vm));
+    } else if (valid) {
+      atomicAdd(&h[d], 1u);
+    }
   }
   __syncthreads();
   table[(size_t)blockIdx.x * DS_BINS + threadIdx.x] = h[threadIdx.x];
