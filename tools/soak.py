@@ -8,6 +8,7 @@ from deblurgs_amd.cloud import GaussianCloud
 from deblurgs_amd.motion import CameraMotionModule, RefCamera
 from deblurgs_amd.training import TrainingLoop, default_optimization_params
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+GRAPH = sys.argv[2] if len(sys.argv) > 2 else "auto"      # "always": capture whenever possible (stresses re-capture + pool release)
 dev = torch.device("cuda", 0)
 sc = synthetic.make_scene(100_000, 800, 800, K=9, curve_order=5, seed=3, sigma_px=2.0)
 ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device=dev)
@@ -26,7 +27,7 @@ m = CameraMotionModule(ref, gts, curve_order=5, num_subframes=9, device=dev)
 opt = default_optimization_params(iterations=N + 1, curve_start_iter=20, densify_from_iter=30, densification_interval=20,
                                   densify_until_iter=N, opacity_reset_interval=150, densify_grad_threshold_init=1e-5,
                                   densify_grad_threshold_final=5e-6)
-loop = TrainingLoop(cloud, m, opt, cameras_extent=2.0)
+loop = TrainingLoop(cloud, m, opt, cameras_extent=2.0, graph=GRAPH)
 t0 = time.time()
 first = None
 for it in range(1, N + 1):
