@@ -225,7 +225,9 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     const SumPf cs = sum1;
     row1 = row2;
     if (k + 2 < v.K) row2 = load_row(k + 2);
-    if (k + 1 < v.K) sum1 = load_sums(k + 1);
+    if (k + 1 < v.K) sum1 = load_sums(k + 1);   // (two subframes ahead, 249 VGPRs: same time -- the kernel waits on its own
+                                                // dependent arithmetic at two waves per SIMD, not on these loads; without
+                                                // any SH state, 149 VGPRs and three waves, it still takes 0.50 of 0.68 ms)
     const uint32_t ntiles = cur.nt;
     if (ntiles > 0) {
       const float4 ga = cur.ga, gb = cur.gb;
