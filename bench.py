@@ -62,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--ar-chunks", type=int, default=4,
                     help="N > 1 GPUs: all-reduce the per-Gaussian gradient bucket in this many Gaussian-index chunks on a side "
                          "stream, each as soon as the backward has produced it (1 = one collective after the backward)")
+    ap.add_argument("--allreduce", default=None, choices=["collective", "p2p"],
+                    help="N > 1 GPUs: how the gradient bucket is summed -- the backend's all-reduce (default) or a direct "
+                         "reduce-scatter + all-gather over point-to-point sends (deblurgs_amd.sharding.p2p_allreduce_)")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--no-optimizer", action="store_true",
@@ -239,6 +242,8 @@ def run_rank(args):
     from deblurgs_amd.motion import CameraMotionModule, RefCamera
     from deblurgs_amd.training import default_optimization_params
 
+    if args.allreduce is not None:
+        sharding.ALLREDUCE_MODE = args.allreduce
     rank, world_env, local_rank = sharding.init_distributed("cuda")
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world != max(args.gpus, 1):
@@ -461,6 +466,7 @@ def run_rank(args):
                        "tile_cull": bool(dgr.TILE_CULL),
                        "sharding": (args.shard if world > 1 else "none"), "ranks_in_process_group": world,
                        "ar_chunks": (args.ar_chunks if world > 1 and loop._fused is not None else None),
+                       "allreduce": (sharding.ALLREDUCE_MODE if world > 1 else None),
                        "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
                        "Pv_total": Pv_tot, "R_total": int(R_tot),
                        "pixel_gaussian_evals_upper_bound_per_step": int(256 * R_tot)},

@@ -114,7 +114,71 @@ def _adopt_into_bucket(params):
     return bucket
 
 
+# How large gradient buffers are summed over the ranks: "collective" = the backend's all-reduce (RCCL picks ring / tree);
+# "p2p" = a direct reduce-scatter + all-gather over point-to-point sends (SURVEY 8e's fallback: on MI355X every GPU pair
+# has its own xGMI link, so rank r can receive its shard from all G-1 peers at once -- seven links busy instead of the
+# two a ring uses; choose it with DGS_DIST_ALLREDUCE=p2p, TrainingLoop / bench.py --allreduce p2p, if the scaling run shows
+# RCCL ringing).  Small buffers always take the collective.
+ALLREDUCE_MODE = os.environ.get("DGS_DIST_ALLREDUCE", "collective")
+P2P_MIN_NUMEL = 1 << 16
+
+
+def p2p_allreduce_(flat, average=False, group=None, align=256):
+    """In-place sum (or mean) of the 1-D fp32 tensor `flat` over the ranks without a collective: the buffer is cut into
+    one shard per rank (boundaries on multiples of `align` elements); rank r receives its shard from every peer (one
+    batch of point-to-point operations = one RCCL group), adds the G contributions IN RANK ORDER (so the result is a
+    fixed function of the inputs and bit-identical on every rank), and sends the reduced shard back to every peer.
+    2 (G-1)/G of the buffer leave and enter each rank, as in a ring, but over G-1 links at once."""
+    W = dist.get_world_size(group)
+    if W == 1 or flat.numel() == 0:
+        return
+    r = dist.get_rank(group)
+    peer = (lambda s: dist.get_global_rank(group, s)) if group is not None else (lambda s: s)
+    n = flat.numel()
+    per = -(-n // W)
+    per = -(-per // align) * align
+    bounds = [(min(i * per, n), min((i + 1) * per, n)) for i in range(W)]
+    b0, b1 = bounds[r]
+    mine = b1 - b0
+    recv = torch.empty((W, mine), dtype=flat.dtype, device=flat.device)
+    ops = []
+    for s in range(W):
+        if s == r:
+            continue
+        s0, s1 = bounds[s]
+        if s1 > s0:
+            ops.append(dist.P2POp(dist.isend, flat[s0:s1], peer(s), group))
+        if mine > 0:
+            ops.append(dist.P2POp(dist.irecv, recv[s], peer(s), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if mine > 0:
+        recv[r].copy_(flat[b0:b1])
+        acc = recv[0].clone()
+        for s in range(1, W):
+            acc += recv[s]
+        if average:
+            acc /= W
+        flat[b0:b1].copy_(acc)
+    ops = []
+    for s in range(W):
+        if s == r:
+            continue
+        s0, s1 = bounds[s]
+        if mine > 0:
+            ops.append(dist.P2POp(dist.isend, flat[b0:b1], peer(s), group))
+        if s1 > s0:
+            ops.append(dist.P2POp(dist.irecv, flat[s0:s1], peer(s), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
 def _allreduce(flat, average, group):
+    if ALLREDUCE_MODE == "p2p" and flat.dim() == 1 and flat.is_contiguous() and flat.numel() >= P2P_MIN_NUMEL:
+        p2p_allreduce_(flat, average, group)
+        return
     if average and dist.get_backend(group) == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
     else:
@@ -128,6 +192,10 @@ def allreduce_slices(tensors, average=False, group=None):
     gradient bucket): RCCL gets them as one group call (coalescing manager), other backends one all-reduce each."""
     tensors = [t for t in tensors if t.numel() > 0]
     if not tensors:
+        return
+    if ALLREDUCE_MODE == "p2p":
+        for t in tensors:
+            _allreduce(t.reshape(-1), average, group)
         return
     if dist.get_backend(group) == "nccl" and hasattr(dist, "_coalescing_manager"):
         op = dist.ReduceOp.AVG if average else dist.ReduceOp.SUM

@@ -875,6 +875,10 @@ def test_two_ranks_on_one_gpu(gpu, mode, tmp_path):
     d1, d4 = torch.load(c1), torch.load(c4)
     for x, y in zip(d1["params"], d4["params"]):
         assert x.shape == y.shape and torch.equal(x, y), "ar_chunks = 4 vs 1"
+    # SURVEY 8e's fallback: the bucket summed by a direct reduce-scatter + all-gather over point-to-point sends
+    # (sharding.p2p_allreduce_) instead of the backend's all-reduce -- replicas bit-identical, through densification
+    out = _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--ar-chunks", "4"], dict(env, DGS_DIST_ALLREDUCE="p2p"))
+    assert "identical: True" in out and "densified: True" in out, out
     out = _run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "cfg2", "--steps", "3",
                 "--warmup", "1", "--no-cpu-baseline", "--shard", mode], env)
     line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])

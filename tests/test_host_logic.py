@@ -173,6 +173,57 @@ def test_view_sharding_averages_gradients(tmp_path):
         assert torch.allclose(a, b / 2, atol=1e-6)
 
 
+def _worker_p2p_allreduce(rank, world, port, out):
+    sharding = _setup(rank, world, port)
+    res = {}
+    for n in (1000, 65536 + 7, 3 * 256 * 5, 255):          # ragged last shard, exact multiple, fewer elements than ranks x align
+        torch.manual_seed(10 * n + rank)
+        x = torch.randn(n)
+        for average in (False, True):
+            y = x.clone()
+            sharding.p2p_allreduce_(y, average=average)
+            z = x.clone()
+            dist.all_reduce(z)
+            if average:
+                z /= world
+            res[(n, average)] = (y, z)
+    # the switch: large 1-D buffers take the point-to-point path, small ones and the packed trajectory gradients the collective
+    sharding.ALLREDUCE_MODE = "p2p"
+    torch.manual_seed(rank)
+    params = [torch.randn(30000, 3, requires_grad=True), torch.randn(11, requires_grad=True)]
+    for p in params:
+        p.grad = torch.randn_like(p)
+    want = [p.grad.clone() for p in params]
+    for w_ in want:
+        dist.all_reduce(w_)
+    sharding.flat_allreduce_grads(params, average=False)
+    res["bucket"] = ([p.grad.clone() for p in params], want)
+    sharding.ALLREDUCE_MODE = "collective"
+    torch.save(res, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_p2p_allreduce_equals_the_collective_and_is_identical_on_every_rank(tmp_path):
+    """SURVEY 8e's fallback (direct reduce-scatter + all-gather over point-to-point sends) on 3 gloo ranks: same sums as
+    all_reduce to rounding, bit-identical on every rank (replicas must not drift), any buffer length."""
+    out = str(tmp_path / "p2p.pt")
+    mp.spawn(_worker_p2p_allreduce, args=(3, 29677, out), nprocs=3, join=True)
+    got = [torch.load(out + f".{r}") for r in range(3)]
+    for key in got[0]:
+        if key == "bucket":
+            for r in range(3):
+                for a, b in zip(*got[r]["bucket"]):
+                    assert torch.allclose(a, b, atol=1e-5)
+            for a, b in zip(got[0]["bucket"][0], got[2]["bucket"][0]):
+                assert torch.equal(a, b)
+            continue
+        y0, z0 = got[0][key]
+        assert torch.allclose(y0, z0, atol=1e-5), key
+        for r in (1, 2):
+            assert torch.equal(got[r][key][0], y0), f"{key}: rank {r} holds different bits"
+
+
 def _worker_stats(rank, world, port, out):
     sharding = _setup(rank, world, port)
     import types
