@@ -678,7 +678,12 @@ ranges_search_kernel(uint32_t L, const uint32_t* __restrict__ n_dev, const uint6
 // stable in-block ranks.  A block owns SORT_TILE consecutive pairs; wave w owns a contiguous quarter of them,
 // read in rounds of 64, so the stable order inside a block is (wave, round, lane).
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 16;
+// (32 items = 8192-pair tiles would double the length of the digit runs the scatter writes, but need 256 VGPRs and 78 KB
+// of LDS per block: scatter 265 vs 208 us per pass, measured with -DDGS_SORT_ITEMS=32)
+#ifndef DGS_SORT_ITEMS
+#define DGS_SORT_ITEMS 16
+#endif
+constexpr int SORT_ITEMS = DGS_SORT_ITEMS;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 pairs per block
 constexpr int SORT_MAX_RB = 9;
 constexpr int SORT_MAX_BINS = 1 << SORT_MAX_RB;
