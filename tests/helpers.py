@@ -454,6 +454,16 @@ def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, floor=ROW_FLOOR, report=Non
             if key == "dL_dmeans2D":
                 a, b, n, f = a[:, :2], b[:, :2], n[:, :2], f[:, :2]
         err_row, _, colmax = row_errors(a, b, floor)
+        if os.environ.get("DGS_PARITY_ROW") and REPORT_ONLY:      # one Gaussian across all outputs (debugging aid)
+            rsel = int(os.environ["DGS_PARITY_ROW"])
+            rows_ = [rsel] if a.shape[0] == b.shape[0] and key not in ("dL_dmeans2D", "dL_dconic") else \
+                [kk * (a.shape[0] // max(ora["double"]["dL_dmeans2D"].shape[0], 1)) + rsel
+                 for kk in range(ora["double"]["dL_dmeans2D"].shape[0])]
+            for rr in rows_:
+                if rr < a.shape[0]:
+                    print(f"   [row {rsel}] {key}[{rr}]: hip {a.reshape(a.shape[0], -1)[rr].tolist()} double "
+                          f"{b.reshape(b.shape[0], -1)[rr].tolist()} f32 {n.reshape(n.shape[0], -1)[rr].tolist()} "
+                          f"colmax {colmax.tolist()}")
         d = np.abs(a - b).reshape(a.shape[0], -1)
         nz = colmax > 0
 

@@ -11,6 +11,7 @@ of the duplicate lists, key width per rasterizer_impl.cu:306-314), tile_cull = 0
 tile_cull = 1 (the benchmarked lists) bit for bit, and forward + backward against the OpenMP oracle (deterministic,
 double accumulation) with the conditioning-aware bars of helpers.assert_grads_close.  The oracle is fed the activated
 values the kernels themselves use (dgs_cloud_activations), so radii / tile counts / point lists compare bit for bit."""
+import os
 import time
 
 import numpy as np
@@ -199,6 +200,29 @@ def test_cfg5_stress_as_benchmarked(gpu):
     gC[K // 2] = g_mid[0]
     hip = hip_cloud_forward_backward(sc, K, gC, cull=True, conic_ks=[K // 2])
     ora = cloud_grads_from_activated(act, run.subset([1]).backward(g_mid))
+    if os.environ.get("DGS_PARITY_ROW"):      # debugging aid: the pixels of one Gaussian that sit closest to the alpha threshold
+        gdbg = int(os.environ["DGS_PARITY_ROW"])
+        stm = run.states[1]
+        mx, my = (float(t) for t in stm["means2D"][gdbg])
+        ca, cb, cc, op = (float(t) for t in stm["conic_opacity"][gdbg])
+        rad = int(stm["radii"][gdbg])
+        xs = np.arange(max(int(mx) - rad - 1, 0), min(int(mx) + rad + 2, W), dtype=np.float32)
+        ys = np.arange(max(int(my) - rad - 1, 0), min(int(my) + rad + 2, H), dtype=np.float32)
+        dx = np.float32(mx) - xs[None, :]
+        dy = np.float32(my) - ys[:, None]
+        power = (np.float32(-0.5) * (np.float32(ca) * dx * dx + np.float32(cc) * dy * dy) - np.float32(cb) * dx * dy).astype(np.float32)
+        alpha = np.minimum(np.float32(0.99), np.float32(op) * np.exp(power)).astype(np.float32)
+        rel = np.abs(alpha - 1.0 / 255.0) / (1.0 / 255.0)
+        order = np.argsort(rel.reshape(-1))[:8]
+        print(f"   [row {gdbg}] mean ({mx:.3f}, {my:.3f}) conic ({ca:.5g}, {cb:.5g}, {cc:.5g}) opacity {op:.5g} radius {rad}; "
+              f"{int((alpha >= 1 / 255).sum())} pixels reach 1/255")
+        for o in order:
+            iy, ix = divmod(int(o), xs.shape[0])
+            py_, px_ = int(ys[iy]), int(xs[ix])
+            terms = 0.5 * abs(ca * dx[0, ix] ** 2) + 0.5 * abs(cc * dy[iy, 0] ** 2) + abs(cb * dx[0, ix] * dy[iy, 0])
+            print(f"       pixel ({px_}, {py_}): alpha {alpha[iy, ix]:.9g} (1/255 = {1 / 255:.9g}, rel {rel[iy, ix]:.2e}) power "
+                  f"{power[iy, ix]:.6g} largest term {terms:.4g} unstable {bool(run.unstable[1][py_, px_])} "
+                  f"upstream |g| {float(np.abs(g_mid[0][:, py_, px_]).max()):.3g}")
     for key in ("dL_dmeans2D", "dL_dviewmatrix", "dL_dprojmatrix"):
         rest = np.delete(hip[key], K // 2, axis=0)
         assert not rest.any(), f"{key}: subframes without upstream gradient must get exact zeros"
