@@ -288,7 +288,8 @@ class FusedStep:
         # the parameters; everything else the step allocated is released to the pool here, so that the captures of the
         # other views re-use the same blocks (every replay is a complete step: nothing of one replay is read after the
         # next has started) -- the pool holds ONE step's buffers plus a gradient bucket per graph, not one full set of
-        # buffers per view.  (`losses` of a replay must therefore be read before the next replay is launched.)
+        # buffers per view.  (The kept `losses` tensor belongs to its graph: it holds a replay's values until the same
+        # graph is replayed again.)
         ent["graph"] = graph
         ent["result"] = {"losses": fr["losses"], "K": fr["K"], "skip_flag_ptr": fr["skip_flag_ptr"], "blur": None,
                          "radii": None, "viewspace_grad": None, "subframes": None, "depths": None, "depth_tv": None}
