@@ -10,7 +10,7 @@
 //     set bits of the ballot masks, so a (Gaussian, quadrant) pair that cannot contribute costs nothing.
 //     Culling is conservative, hence the per-pixel tests below are exactly the reference's.
 //   * Backward: no global atomics.  The 10 per-Gaussian partial sums are accumulated over a lane's pixels
-//     in registers, over the wave with a permlane-swap/DPP reduce-scatter, staged per batch in LDS, and stored
+//     in registers, over the wave through LDS (value-major rows, 40 lanes add 16 values each), and stored
 //     as ONE 48-byte contribution row per (tile, Gaussian) duplicate:
 //       [sum w*dx, sum w*dy, sum w*dx*dx, sum w*dx*dy, sum w*dy*dy, sum w, dL_dr, dL_dg, dL_db, dL_ddepth].  geometry_bwd.hip sums a Gaussian's rows in
 //     duplicate order, so the whole backward is bitwise reproducible (the reference issues 10 float
@@ -23,14 +23,10 @@ namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // lowers to v_pk_{mul,add,fma}_f32 on gfx950
 
-// Backward: how the ten per-lane sums of a list entry become one contribution row.  1 (default): through LDS -- ten
-// conflict-free 4-byte stores per lane, 40 lanes read 16 values each and add them, the totals go straight to the row in
-// global memory (one 40-byte store per entry).  0: the round-2 reduce-scatter on the VALU (v_permlane*_swap + DPP) with the
-// batch's rows staged in LDS.  Same box, metric config: 5.41 ms against 5.70-5.77 ms per launch (and 83 instead of 86 VGPRs,
-// 23 instead of 24.5 KB of LDS per block); tools/build_flag_variant.sh <name> -DDGS_BWD_LDS_REDUCE=0 rebuilds the other one.
-#ifndef DGS_BWD_LDS_REDUCE
-#define DGS_BWD_LDS_REDUCE 1
-#endif
+// Backward: the ten per-lane sums of a list entry become one contribution row through LDS -- ten conflict-free 4-byte
+// stores per lane, 40 lanes read 16 values each and add them, the totals go straight to the row in global memory (one
+// 40-byte store per entry).  Round 2's reduce-scatter on the VALU (v_permlane*_swap + DPP, rows staged in LDS) measured
+// 5.70-5.77 ms against 5.41 ms on the same box: variants/bwd_valu_reduce_scatter.patch.
 constexpr int CW = 4;  // waves (= tiles) per 256-thread block; the waves never synchronise with each other
 
 struct TileCtx {
@@ -246,14 +242,9 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
                      const float* __restrict__ dL_ddepth, const uint32_t* __restrict__ dup_off,
                      float* __restrict__ contrib) {
   __shared__ float4 s_row[CW][64 * 3];  // (x, y, A, B | C, op, r, g | b, depth, -, -) per list entry
-#if !DGS_BWD_LDS_REDUCE
-  __shared__ float4 s_acc[CW][64][3];  // per-duplicate gradient rows of the current batch
-#endif
-#if DGS_BWD_LDS_REDUCE
   // the ten per-lane sums of a list entry, value-major (row stride 68 floats: the 16-byte column reads of the rows start
   // in different banks)
   __shared__ __attribute__((aligned(16))) float s_part[CW][10][68];
-#endif
   TileCtx t;
   if (!load_tile_ctx(v, ranges, per_xcd, t)) return;
   const int lane = dgs_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -263,24 +254,11 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   const float qx0 = (float)(t.tx * DGS_TILE), qy0 = (float)(t.ty * DGS_TILE);
   const size_t N = (size_t)v.W * v.H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  // contribution-row slot this lane stores after the per-duplicate reduce-scatter (-1: none); slots are
-  // [S_wx, S_wy, S_xx, S_xy, S_yy, S_w, r, g, b, depth]
-#if DGS_BWD_LDS_REDUCE
+  // contribution-row slots: [S_wx, S_wy, S_xx, S_xy, S_yy, S_w, r, g, b, depth]
   // reduction through LDS: lane (row = lane >> 2, quarter = lane & 3), row < 10 (9 without a depth gradient), sums 16 lanes'
   // values of sum `row`; the quad's four partial sums are combined with two DPP adds and lane quarter 0 stores the total
   const int rrow = lane >> 2, rq = lane & 3;
   const bool rlane = rrow < (HASDEPTH ? 10 : 9);
-#endif
-#if !DGS_BWD_LDS_REDUCE
-  int wslot = -1;
-  if ((lane & 3) == 0) {
-    const int rr = lane >> 4, bank = (lane & 15) >> 2;
-    if (bank == 0) wslot = (rr == 0) ? 0 : (rr == 1) ? 2 : (rr == 2) ? 1 : 3;
-    if (bank == 2) wslot = (rr == 0) ? 4 : (rr == 1) ? 6 : (rr == 2) ? 5 : 7;
-    if (bank == 1 && rr == 0) wslot = 8;
-    if (bank == 1 && rr == 2) wslot = 9;
-  }
-#endif
   
 
   // per-pixel channel state kept as (r,g) and (b,depth) pairs so the channel arithmetic issues as packed fp32
@@ -370,11 +348,6 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       s_row[w][3 * lane + 2] = make_float4(Cc.x, Cc.y, 0.0f, 0.0f);
     }
     const float4 z4 = make_float4(0, 0, 0, 0);
-#if !DGS_BWD_LDS_REDUCE
-    s_acc[w][lane][0] = z4;
-    s_acc[w][lane][1] = z4;
-    s_acc[w][lane][2] = z4;
-#else
     // totals go straight to the contribution rows (one 40-byte store per entry); an entry that no pixel of the tile
     // reaches any more is never walked: its row is zero-filled here
     if (has && (((m[0] | m[1] | m[2] | m[3]) >> lane) & 1ull) == 0ull) {
@@ -383,7 +356,6 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       dst[1] = z4;
       dst[2] = z4;
     }
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -451,11 +423,10 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           S_yy = fmaf(wy, dy, S_yy);
         }
       }
-#if DGS_BWD_LDS_REDUCE
       {
         // 10 wave sums through LDS instead of the VALU (which this kernel saturates): ten conflict-free 4-byte stores per
         // lane, then 40 lanes read 16 values each (four 16-byte loads) and add them; the cross-lane instructions of the
-        // reduce-scatter below (8 v_permlane*_swap at 5.4 issue cycles, 7 DPP adds at 4.4) become 15 plain adds and 2 DPP
+        // VALU reduce-scatter (8 v_permlane*_swap at 5.4 issue cycles, 7 DPP adds at 4.4) become 15 plain adds and 2 DPP
         // adds, and the LDS pipe -- nearly idle here -- does the data movement.  Fixed order of additions: deterministic.
         float* pw = &s_part[w][0][lane];
         pw[0 * 68] = S_wx;
@@ -493,25 +464,6 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         }
         __builtin_amdgcn_wave_barrier();   // the next entry's stores follow this entry's loads (LDS runs a wave's ops in order)
       }
-#else
-      {  // (every dup that reaches here passed the quadrant test for >= 1 quadrant; 98 % of those passes contribute)
-        // 10 wave sums as a reduce-scatter: every fold level halves the number of live registers -- v_permlane32_swap
-        // (half waves), v_permlane16_swap (rows), then bank-masked DPP adds inside the rows (8 lanes, 4 lanes) and a
-        // quad sum: 23 VALU ops instead of 60 for ten independent butterflies.  After it, in row r of the wave,
-        //   lanes 0-3  hold (S_wx, S_xx, S_wy, S_xy)[r],  lanes 8-11 hold (S_yy, sA.x, S_w, sA.y)[r],
-        //   lanes 4-7  hold sB.x (rows 0, 1) or sB.y (rows 2, 3),
-        // and one lane of each of those quads stores its value into the duplicate's LDS row (wslot, set up once).
-        const float ua = dgs_fold16(dgs_fold32(S_wx, S_wy), dgs_fold32(S_xx, S_xy));
-        const float ub = dgs_fold16(dgs_fold32(S_yy, S_w), dgs_fold32(sA.x, sA.y));
-        const float r4 = dgs_fold32(sB.x, sB.y);
-        float uc = dgs_fold16(r4, r4);
-        uc += dgs_dpp<0x128, 0xf>(uc);  // row_ror:8
-        float tot = dgs_quad_sum(dgs_fold4(dgs_fold8(ua, ub), uc));
-        asm volatile("" : "+v"(tot));  // finish the last DPP add here, not inside the store's exec branch
-        // (32-bit LDS index: the generic float* arithmetic compiled to a quarter-rate v_mad_u64_u32)
-        if (wslot >= 0) reinterpret_cast<float*>(&s_acc[w][0][0])[j * DGS_CONTRIB_F + wslot] = tot;
-      }
-#endif
     }
     };
     if ((~pdm & mu_all) == 0ull)
@@ -521,14 +473,6 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#if !DGS_BWD_LDS_REDUCE
-    if (has) {
-      float4* dst = reinterpret_cast<float4*>(contrib + (size_t)u * DGS_CONTRIB_F);
-      dst[0] = s_acc[w][lane][0];
-      dst[1] = s_acc[w][lane][1];
-      dst[2] = s_acc[w][lane][2];
-    }
-#endif
     __builtin_amdgcn_wave_barrier();
   }
 }

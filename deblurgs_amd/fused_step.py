@@ -66,7 +66,9 @@ class FusedStep:
         self._side = None           # side stream of the chunked gradient all-reduce
         self.time_allreduce = False
         self.ar_events = []
-        self._drops_dev = None      # device word: forwards that overflowed so far (DgsForwardOut.drop_counter)
+        self._drops_dev = None      # device word: captured forwards that overflowed so far (DgsForwardOut.drop_counter)
+        self._drops_seen = 0        # ... and how many of them _poll has turned into retries
+        self._bucket = None         # (generation, numel, tensor): the gradient bucket all captured steps write to
         self._graphs = {}           # captured steps by what they bake in (replay)
         self._pool = None           # one memory pool for all of them: replays never overlap
         self._release_pool = False  # a dropped pool's blocks go back to the driver before the next capture
@@ -85,7 +87,19 @@ class FusedStep:
                 R, hi, overflow = (int(x) & 0xFFFFFFFF for x in pnd.host[:3].tolist())
                 if hi != 0:
                     raise RuntimeError("num_rendered exceeds 32 bits: render fewer subframes per call")
-                if pnd.speculative and overflow:
+                if getattr(pnd, "shared_host", False):
+                    # a captured step: every replay of its graph copies its words into the SAME pinned block and the host
+                    # runs several replays ahead, so by now words [0..3] may already be a later replay's.  Drops are
+                    # therefore taken from the running counter all captured forwards share (DgsForwardOut.drop_counter ->
+                    # word [4]): it only grows, the entries are polled in launch order and a block belongs to one view,
+                    # so "what the counter gained since the last poll" is exactly the replays of THIS view that overflowed
+                    # and have not been made up for yet -- none lost, none counted twice.
+                    total = int(pnd.host[4]) & 0xFFFFFFFF
+                    new = (total - self._drops_seen) & 0xFFFFFFFF
+                    self._drops_seen = total
+                    self.dropped += new
+                    self.retry.extend([pnd.request] * new)
+                elif pnd.speculative and overflow:
                     self.dropped += 1
                     self.retry.append(pnd.request)
                 if pnd.generation == self._generation:
@@ -115,6 +129,7 @@ class FusedStep:
             # generation (soak run, 100 k -> 3.4 M Gaussians: 159 GiB instead of 25)
             self._graphs = {}
             self._pool = None
+            self._bucket = None
             self._release_pool = True
 
     def _host_words(self):
@@ -135,6 +150,14 @@ class FusedStep:
         color = torch.zeros((0, 3, H, W), **f32)
         _, l1, sm = sharding.subframe_sharded_loss_grad(color, gt.to(dev, torch.float32).contiguous(), K_total,
                                                         float(lambda_t))
+        # The collectives below are issued in EXACTLY the order run() issues them on a rank that holds subframes -- loss
+        # block, depth-smoothness value, gradient bucket (whole or in chunks) -- because RCCL pairs collectives by issue
+        # order on the communicator: a different order here would pair a one-element all-reduce with a bucket slice.
+        depth_tv = None
+        if lambda_depth_tv > 0.0:      # this rank's share of the depth-smoothness value is zero
+            import torch.distributed as dist
+            depth_tv = torch.zeros((), **f32)
+            dist.all_reduce(depth_tv)
         if ar is None:
             for p in cloud.hot_parameters():
                 p.grad = torch.zeros_like(p)
@@ -159,11 +182,6 @@ class FusedStep:
             m._trans._control_points.grad, m._rot._control_points.grad = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
             if nu_raw.numel() > 0:
                 m._nu.grad = torch.zeros_like(nu_raw)
-        depth_tv = None
-        if lambda_depth_tv > 0.0:      # this rank's share of the depth-smoothness value is zero
-            import torch.distributed as dist
-            depth_tv = torch.zeros((), **f32)
-            dist.all_reduce(depth_tv)
         return {"losses": torch.stack([l1.reshape(()), sm.reshape(())]).float(), "blur": None,
                 "radii": torch.zeros((0, P), dtype=torch.int32, device=dev), "viewspace_grad": torch.zeros((0, P, 3), **f32),
                 "K": K_total, "subframes": color, "depths": torch.zeros((0, 1, H, W), **f32), "skip_flag_ptr": None,
@@ -272,7 +290,19 @@ class FusedStep:
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
         ent = {"hyper": hyper, "host": host}
-        cap_args = {"capacity": cap, "host": host, "lambda_ptr": hyper.data_ptr(),
+        # Two things a replay leaves behind live OUTSIDE the capture pool (ordinary allocations made before the capture):
+        # the loss kernel's work block -- `losses` handed to the caller is a view of it and holds a replay's two values until
+        # the SAME graph is replayed again (in the pool it could be another graph's scratch: all graphs share the pool) --
+        # and the gradient bucket, ONE per cloud generation for all graphs (replays never overlap and the optimiser launch
+        # at the end of a replay has consumed the gradients; a bucket per graph would be 236 MB per view at P = 1M, SH 3).
+        Mr_ = cloud._features_rest.shape[1]
+        P_ = cloud._xyz.shape[0]
+        n_bucket = sum((n + 3) // 4 * 4 for n in (3 * P_, 3 * P_, 3 * Mr_ * P_, P_, 3 * P_, 4 * P_))
+        if self._bucket is None or self._bucket[0] != self._generation or self._bucket[1] != n_bucket:
+            self._bucket = (self._generation, n_bucket, torch.empty(n_bucket, dtype=torch.float32, device=dev))
+        ent["work"] = torch.zeros(8, dtype=torch.float32, device=dev)
+        cap_args = {"capacity": cap, "host": host, "lambda_ptr": hyper.data_ptr(), "work": ent["work"],
+                    "bucket": self._bucket[2],
                     "tail": (lambda fr: tail(fr, hyper.data_ptr() + 4 * 8)) if tail is not None else None}
         bg = hyper[1:4]
         uniform = hyper[48:48 + f - 2] if (m.curve_random_sample and f > 2) else None
@@ -285,11 +315,10 @@ class FusedStep:
         with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
             fr = self.run(cam_idx, 0.0, gt, bg, subframe_indice, uniform=uniform, _cap=cap_args, stats=stats)
         # What a replay leaves behind for the host is the two loss values, the count words (pinned) and the gradients of
-        # the parameters; everything else the step allocated is released to the pool here, so that the captures of the
-        # other views re-use the same blocks (every replay is a complete step: nothing of one replay is read after the
-        # next has started) -- the pool holds ONE step's buffers plus a gradient bucket per graph, not one full set of
-        # buffers per view.  (The kept `losses` tensor belongs to its graph: it holds a replay's values until the same
-        # graph is replayed again.)
+        # the parameters (the first and the last allocated outside the pool, above); everything else the step allocated
+        # is released to the pool here, so that the captures of the other views re-use the same blocks (every replay is a
+        # complete step: nothing of one replay is read after the next has started) -- the pool holds ONE step's buffers,
+        # not one set per view.
         ent["graph"] = graph
         ent["result"] = {"losses": fr["losses"], "K": fr["K"], "skip_flag_ptr": fr["skip_flag_ptr"], "blur": None,
                          "radii": None, "viewspace_grad": None, "subframes": None, "depths": None, "depth_tv": None}
@@ -449,7 +478,8 @@ class FusedStep:
         gtc = gt.to(dev, torch.float32).contiguous()
         blur = torch.empty((3, H, W), **f32)
         dsub = torch.empty((K, 3, H, W), **f32)
-        work = torch.empty(8, **f32)          # dgs_blur_loss_grad's work area: [l1, smooth | accumulators, counter]
+        # dgs_blur_loss_grad's work area: [l1, smooth | accumulators, counter]
+        work = torch.empty(8, **f32) if _cap is None else _cap["work"]
         losses = work[:2]
         if _cap is not None:      # the scheduled weight is read from device memory when the replayed kernel runs
             _lib.check(L.dgs_blur_loss_grad_dev(_ptr(color), _ptr(gtc), K, 3, H * W, ctypes.c_void_p(_cap["lambda_ptr"]),
@@ -470,7 +500,8 @@ class FusedStep:
         offs = [0]
         for n in sizes:
             offs.append(offs[-1] + (n + 3) // 4 * 4)
-        flat = torch.empty(offs[-1], **f32)
+        flat = torch.empty(offs[-1], **f32) if _cap is None else _cap["bucket"]
+        assert flat.numel() == offs[-1]
         seg = lambda i, shape: flat[offs[i]:offs[i] + sizes[i]].view(shape)
         g_xyz, g_dc, g_op, g_sc, g_rot = (seg(0, (P, 3)), seg(1, cloud._features_dc.shape), seg(3, cloud._opacity.shape),
                                           seg(4, (P, 3)), seg(5, (P, 4)))

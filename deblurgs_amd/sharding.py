@@ -120,39 +120,105 @@ def _adopt_into_bucket(params):
 # two a ring uses; choose it with DGS_DIST_ALLREDUCE=p2p, TrainingLoop / bench.py --allreduce p2p, if the scaling run shows
 # RCCL ringing).  Small buffers always take the collective.
 ALLREDUCE_MODE = os.environ.get("DGS_DIST_ALLREDUCE", "collective")
-P2P_MIN_NUMEL = 1 << 16
+# buffers below this many elements always take the collective (DGS_DIST_P2P_MIN_NUMEL=0: every buffer takes the p2p path,
+# which is how the N-rank tests exercise it on small scenes)
+P2P_MIN_NUMEL = int(os.environ.get("DGS_DIST_P2P_MIN_NUMEL", str(1 << 16)))
+
+_pinned = {}      # (slot, numel, dtype) -> pinned host staging buffer of _p2p's non-RCCL path
 
 
-def p2p_allreduce_(flat, average=False, group=None, align=256):
+def _stage(slot, t):
+    key = (slot, t.numel(), t.dtype)
+    h = _pinned.get(key)
+    if h is None:
+        if len(_pinned) > 256:
+            _pinned.clear()
+        h = _pinned[key] = torch.empty(t.numel(), dtype=t.dtype).pin_memory()
+    return h
+
+
+def _p2p(sends, recvs, group=None):
+    """One batch of point-to-point transfers: sends / recvs = [(contiguous tensor, peer rank within `group`)].  Blocks the
+    HOST until the batch is done on every backend but RCCL.
+
+    Backend "nccl" (= RCCL): one batch_isend_irecv = one RCCL group, ordered on the CURRENT stream like any kernel: a
+    send reads what earlier work on this stream wrote, later work sees the received bytes; nothing waits on the host.
+
+    Any other backend (gloo: the CPU tests, and the N-rank functional tests with two ranks on one GPU): such a backend
+    moves bytes from the HOST thread through tensor.data_ptr(), which knows nothing about streams -- handed a device
+    tensor it would read the buffer before the kernels (or the async copy_) producing it have run, and a receive could
+    land while a kernel still reads the old contents.  So the current stream is drained first, device tensors travel
+    through pinned host buffers (the backend never sees a device pointer), and the received bytes are copied back with
+    blocking copies."""
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    if not sends and not recvs:
+        return
+    if dist.get_backend(group) == "nccl":
+        ops = [dist.P2POp(dist.isend, t, peer(r), group) for t, r in sends]
+        ops += [dist.P2POp(dist.irecv, t, peer(r), group) for t, r in recvs]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return
+    dev = next((t.device for t, _ in list(sends) + list(recvs) if t.is_cuda), None)
+    if dev is not None:
+        torch.cuda.current_stream(dev).synchronize()
+    h_send, h_recv = [], []
+    for i, (t, r) in enumerate(sends):
+        if t.is_cuda:
+            h = _stage(("s", i), t)
+            h.copy_(t.reshape(-1))                 # blocking device -> pinned copy (the stream is drained)
+        else:
+            h = t
+        h_send.append((h, r))
+    for i, (t, r) in enumerate(recvs):
+        h_recv.append((_stage(("r", i), t) if t.is_cuda else t, r))
+    reqs = [dist.isend(h, peer(r), group=group) for h, r in h_send]
+    reqs += [dist.irecv(h, peer(r), group=group) for h, r in h_recv]
+    for req in reqs:
+        req.wait()
+    for (t, _), (h, _) in zip(recvs, h_recv):
+        if t.is_cuda:
+            t.reshape(-1).copy_(h)                 # blocking pinned -> device copy
+    if dev is not None:
+        torch.cuda.current_stream(dev).synchronize()
+
+
+def p2p_allreduce_(flat, average=False, group=None, align=256, force=False):
     """In-place sum (or mean) of the 1-D fp32 tensor `flat` over the ranks without a collective: the buffer is cut into
     one shard per rank (boundaries on multiples of `align` elements); rank r receives its shard from every peer (one
     batch of point-to-point operations = one RCCL group), adds the G contributions IN RANK ORDER (so the result is a
     fixed function of the inputs and bit-identical on every rank), and sends the reduced shard back to every peer.
-    2 (G-1)/G of the buffer leave and enter each rank, as in a ring, but over G-1 links at once."""
+    2 (G-1)/G of the buffer leave and enter each rank, as in a ring, but over G-1 links at once.
+    force: in a ONE-rank group, run both phases as a send to / receive from this rank itself (RCCL accepts a self
+    send + receive inside one group; values unchanged) -- tools/rccl_smoke.py puts the RCCL point-to-point path under
+    the product code on a one-GPU box this way."""
     W = dist.get_world_size(group)
-    if W == 1 or flat.numel() == 0:
+    if flat.numel() == 0 or (W == 1 and not force):
         return
     r = dist.get_rank(group)
-    peer = (lambda s: dist.get_global_rank(group, s)) if group is not None else (lambda s: s)
     n = flat.numel()
+    if W == 1:      # (force) the shard goes through a self send / receive and comes back as it was, twice
+        for _phase in range(2):
+            tmp = torch.empty_like(flat)
+            _p2p([(flat, r)], [(tmp, r)], group)
+            flat.copy_(tmp)
+        return
     per = -(-n // W)
     per = -(-per // align) * align
     bounds = [(min(i * per, n), min((i + 1) * per, n)) for i in range(W)]
     b0, b1 = bounds[r]
     mine = b1 - b0
     recv = torch.empty((W, mine), dtype=flat.dtype, device=flat.device)
-    ops = []
+    sends, recvs = [], []
     for s in range(W):
         if s == r:
             continue
         s0, s1 = bounds[s]
         if s1 > s0:
-            ops.append(dist.P2POp(dist.isend, flat[s0:s1], peer(s), group))
+            sends.append((flat[s0:s1], s))
         if mine > 0:
-            ops.append(dist.P2POp(dist.irecv, recv[s], peer(s), group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+            recvs.append((recv[s], s))
+    _p2p(sends, recvs, group)
     if mine > 0:
         recv[r].copy_(flat[b0:b1])
         acc = recv[0].clone()
@@ -161,23 +227,21 @@ def p2p_allreduce_(flat, average=False, group=None, align=256):
         if average:
             acc /= W
         flat[b0:b1].copy_(acc)
-    ops = []
+    sends, recvs = [], []
     for s in range(W):
         if s == r:
             continue
         s0, s1 = bounds[s]
         if mine > 0:
-            ops.append(dist.P2POp(dist.isend, flat[b0:b1], peer(s), group))
+            sends.append((flat[b0:b1], s))
         if s1 > s0:
-            ops.append(dist.P2POp(dist.irecv, flat[s0:s1], peer(s), group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+            recvs.append((flat[s0:s1], s))
+    _p2p(sends, recvs, group)
 
 
 def _allreduce(flat, average, group):
     if ALLREDUCE_MODE == "p2p" and flat.dim() == 1 and flat.is_contiguous() and flat.numel() >= P2P_MIN_NUMEL:
-        p2p_allreduce_(flat, average, group)
+        p2p_allreduce_(flat, average, group, force=FORCE_COLLECTIVES)
         return
     if average and dist.get_backend(group) == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
@@ -326,19 +390,16 @@ def subframe_sharded_loss_grad(local_subframes, gt, K, lambda_t, group=None):
         assert holds[rank][1] - holds[rank][0] == k_loc, "local_subframes does not match shard_range(K, rank, world)"
         lower = next((r for r in range(rank - 1, -1, -1) if holds[r][1] > holds[r][0]), None)
         upper = next((r for r in range(rank + 1, world) if holds[r][1] > holds[r][0]), None)
-        peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
-        ops = []
+        sends, recvs = [], []
         if lower is not None:
-            first = S[0].contiguous()
             prev_last = torch.empty_like(gt)
-            ops += [dist.P2POp(dist.isend, first, peer(lower), group), dist.P2POp(dist.irecv, prev_last, peer(lower), group)]
+            sends.append((S[0].contiguous(), lower))
+            recvs.append((prev_last, lower))
         if upper is not None:
-            last = S[-1].contiguous()
             next_first = torch.empty_like(gt)
-            ops += [dist.P2POp(dist.isend, last, peer(upper), group), dist.P2POp(dist.irecv, next_first, peer(upper), group)]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            sends.append((S[-1].contiguous(), upper))
+            recvs.append((next_first, upper))
+        _p2p(sends, recvs, group)
     d = blur - gt
     g_l1 = _sgn(d) / (E * K)
     dS = g_l1[None].expand_as(S).clone() if k_loc > 0 else S

@@ -91,6 +91,9 @@ class TrainingLoop:
         self.fixed_background = None    # a [3] tensor here replaces the random background (scene/motion.py:112-113)
         self.split_noise_fn = None      # f(iteration, m) -> [2 m, 3] standard normals for densify_and_split (tests)
         self.retried = 0            # dropped fused steps that were re-run through the exact path
+        self.dist_dropped = 0       # sharded runs: steps every rank dropped together (no make-up; counters corrected)
+        self._dist_flags = []
+        self._last_iteration = None
         self._fused = None
         if fused_step:
             try:
@@ -115,6 +118,7 @@ class TrainingLoop:
 
     def step(self, iteration, cam_idx):
         g, opt = self.gaussians, self.opt
+        self._last_iteration = iteration
         g.update_learning_rate(iteration, opt, alignment_lr=self.alignment_func(iteration))     # train.py:109
         densification_threshold = self.densify_threshold_func(iteration)
         lambda_t_smooth = self.lambda_t_smooth_func(iteration)
@@ -189,6 +193,8 @@ class TrainingLoop:
         bg = bg_host.to(dev)
         uniform = None if uni_host is None else uni_host.to(dev)
         shard = None
+        if self.distributed:
+            self._drain_dist_flags(lag=2)
         if self.mode == "subframes":
             import torch.distributed as dist
             shard = (dist.get_rank(), dist.get_world_size())
@@ -219,6 +225,17 @@ class TrainingLoop:
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
                 self._flag_keep = flag
                 skip = flag.data_ptr()
+                # Sharded runs do not re-run a dropped step (the replicas would have to agree on the make-up view); they
+                # account for it: the reduced flag travels to pinned memory behind the step and is read a FIXED number of
+                # iterations later (_drain_dist_flags), on every rank at the same iteration, so that Adam's step counters
+                # -- the bias-correction exponent, the value stored in checkpoints -- count applied updates only and stay
+                # identical on all replicas.
+                h = torch.zeros(1, dtype=torch.int32).pin_memory()
+                h.copy_(flag[:1], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                self._dist_flags.append((h, ev, flag))
+            self._fused.retry.clear()       # (this rank's own overflows: covered by the reduced flag above)
             # "views": a mini-batch of views, gradients averaged; "subframes": partial sums of one view's gradient
             extra = [p for p in self.motion.parameters() if p.requires_grad]
             if ar is not None:         # (the bucket was reduced inside run(), also by a rank without subframes)
@@ -246,6 +263,34 @@ class TrainingLoop:
             if fr["depth_tv"] is not None:
                 out["loss"] = out["loss"] + self.opt.lambda_depth_tv * fr["depth_tv"]
         return out
+
+    def _drain_dist_flags(self, lag=0):
+        """Sharded runs: turn the (MAX-reduced, hence rank-independent) drop flags of all but the last `lag` steps into
+        step-counter corrections.  Waits for a flag's copy if it has to (with lag = 2 it never does in practice)."""
+        while len(self._dist_flags) > lag:
+            h, ev, _ = self._dist_flags.pop(0)
+            ev.synchronize()
+            if int(h[0]) != 0:
+                self.dist_dropped += 1
+                self.gaussians.optimizer.note_skipped_steps(1)
+
+    def flush(self):
+        """Call at the end of training and before writing a checkpoint (on every rank of a sharded run at the same
+        iteration): waits for the count / drop words still in flight, makes up for the dropped steps of a single-process
+        run (as step() does one iteration late) and settles the step counters of a sharded one."""
+        if self._fused is None:
+            return
+        self._fused._poll(block=True)
+        if self.distributed:
+            self._drain_dist_flags(lag=0)
+            self._fused.retry.clear()
+            return
+        it = self._last_iteration
+        while self._fused.retry and it is not None:
+            cam_r, sub_r = self._fused.retry.pop(0)
+            self.gaussians.optimizer.note_skipped_steps(1)
+            self.retried += 1
+            self._step_fused(it, cam_r, sub_r, self.lambda_t_smooth_func(it), self.densify_threshold_func(it), exact=True)
 
     # ---- the iteration as one captured hipGraph
     def _graphable(self, iteration):

@@ -693,6 +693,46 @@ def test_graph_replay_equals_eager_fused_step(gpu):
             assert x.shape == y.shape and torch.equal(x, y)
 
 
+def test_captured_step_that_overflows_is_counted_once_and_made_up_for(gpu):
+    """every replay of a captured graph copies its count words into the same pinned block while the host runs
+    several replays ahead, so the per-replay overflow word can be overwritten before it is read.  The drops are taken
+    from the running device counter instead (DgsForwardOut.drop_counter): ONE view stepped back to back through ONE graph,
+    the splats grown in place (same tensors: the same graph keeps replaying) until its capacity overflows -- every
+    overflowed replay must be counted exactly once, re-run through the exact path, and Adam's step counters must equal
+    the number of step() calls (each applied exactly once)."""
+    import torch
+    from deblurgs_amd.training import TrainingLoop, default_optimization_params
+    sc, cloud, m = _fused_fixture(seed=8, K=5, P=4000)
+    opt = default_optimization_params(iterations=10 ** 6, curve_start_iter=1, densify_from_iter=10 ** 9,
+                                      densify_until_iter=0, opacity_reset_interval=10 ** 9)
+    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, graph="always")
+    fs = loop._fused
+    for it in range(1, 8):
+        loop.step(it, 0)
+    loop.flush()
+    assert fs.replayed >= 4 and fs.captured >= 1 and fs.dropped == 0, (fs.replayed, fs.captured, fs.dropped)
+    counter = lambda: float(cloud.optimizer.state[cloud._xyz]["step"])
+    assert counter() == 7
+    with torch.no_grad():
+        cloud._scaling += 1.0          # e times larger splats: several times the duplicates, beyond capacity + 25 %
+    replayed = fs.replayed
+    for it in range(8, 20):
+        out = loop.step(it, 0)
+    loop.flush()
+    torch.cuda.synchronize()
+    assert fs.replayed > replayed
+    assert fs.dropped >= 1, "the grown cloud never overflowed the captured capacity: the test does not test"
+    assert loop.retried == fs.dropped and not fs.retry, (loop.retried, fs.dropped, fs.retry)
+    assert int(fs._drop_counter("cuda").item()) == fs.dropped
+    assert counter() == 19, (counter(), fs.dropped, loop.retried)
+    # and the run goes on replaying with the capacity the make-up step learnt
+    n = fs.replayed
+    for it in range(20, 24):
+        loop.step(it, 0)
+    loop.flush()
+    assert fs.replayed > n and counter() == 23 and loop.retried == fs.dropped
+
+
 def test_training_matches_the_cpu_reference_loop_on_a_toy_deblurring_scene(gpu):
     """The stand-in for north_star's "PSNR within 0.05 dB of the reference on ExBlur" (no ExBlur, no CUDA here): a toy
     deblurring problem -- 3 blurry views of a 1500-Gaussian scene, 64x48, K = 5 subframes along per-view SE(3) Bezier
@@ -834,40 +874,61 @@ def test_rccl_one_rank_smoke(gpu):
     assert "rccl smoke ok: backend nccl, world 1" in out, out
 
 
-@pytest.mark.parametrize("mode", ["views", "subframes"])
-def test_two_ranks_on_one_gpu(gpu, mode, tmp_path):
-    """The N-rank code path end to end with two ranks sharing this box's GPU (gloo collectives staged through the host:
-    a functional check, not a measurement; RCCL itself needs the driver's multi-GPU run):
-      * tools/dist_training_check.py: TrainingLoop(distributed=mode) through densification -- the cloud AND the trajectory
-        parameters stay bit-identical on both ranks (views: the ranks draw different cam_idx from one shared module);
-      * subframes: the two-rank result equals the single-process step up to summation order;
-      * bench.py --gpus 2 launches its two ranks itself and reports what the process group saw."""
-    import json
+# The N-rank code path end to end with two ranks sharing this box's GPU (gloo collectives staged through the host: a
+# functional check, not a measurement; RCCL itself needs the driver's multi-GPU run).  One test per leg, so that one leg
+# going red names itself and hides nothing else.
+_MODES = ["views", "subframes"]
+
+
+def _two_rank_env(**extra):
     import os
-    import sys
-    import torch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DGS_DIST_BACKEND="gloo", DGS_DIST_ONE_DEVICE="1", PYTHONPATH=root)
-    tool = os.path.join(root, "tools", "dist_training_check.py")
-    # (the ranks draw DIFFERENT random numbers: shared draws -- background, alignment jitter -- come from rank 0)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DGS_DIST_ALLREDUCE", "DGS_DIST_P2P_MIN_NUMEL"):
+        env.pop(k, None)
+    env.update(extra)
+    return root, os.path.join(root, "tools", "dist_training_check.py"), env
+
+
+@pytest.mark.parametrize("mode", _MODES)
+def test_two_ranks_replicas_stay_identical(gpu, mode):
+    """tools/dist_training_check.py: TrainingLoop(distributed=mode) through five densifications -- the cloud AND the
+    trajectory parameters stay bit-identical on both ranks (views: the ranks draw different cam_idx from one shared
+    module; the ranks draw DIFFERENT random numbers: shared draws -- background, alignment jitter -- come from rank 0)."""
+    import sys
+    root, tool, env = _two_rank_env()
     out = _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--random-sample"], env)
     assert "identical: True" in out and "densified: True" in out, out
-    if mode == "subframes":
-        a, b = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
-        _run([sys.executable, tool, "--ranks", "1", "--mode", mode, "--no-densify", "--iters", "8", "--curve-start", "1", "--out", a], env)
-        _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--no-densify", "--iters", "8", "--curve-start", "1", "--out", b], env)
-        da, db = torch.load(a), torch.load(b)
-        # the sharded step IS the single-process step: on identical parameters (iteration 1) the gradients agree up to
-        # the order of the cross-rank sums ...
-        for x, y in zip(da["grads_first"], db["grads_first"]):
-            assert (x is None) == (y is None)
-            if x is not None and x.numel():
-                assert float((x - y).abs().max()) <= 1e-5 * (float(x.abs().max()) + 1e-30), float((x - y).abs().max())
-        # ... and the trained parameters stay together (Adam's g / sqrt(v) turns rounding-level differences of
-        # near-zero gradients into differences of a fraction of one learning-rate step; 8 steps were taken)
-        for x, y in zip(da["params"], db["params"]):
-            assert x.shape == y.shape and float((x - y).abs().max()) <= 2e-3 * (float(x.abs().max()) + 1e-12)
-    # the chunked, overlapped reduction of the gradient bucket gives the same replicas as the single collective
+
+
+def test_two_ranks_subframes_equal_the_single_process_step(gpu, tmp_path):
+    """The subframe-sharded step IS the single-process step: on identical parameters (iteration 1) the gradients agree
+    up to the order of the cross-rank sums, and the trained parameters stay together."""
+    import sys
+    import torch
+    root, tool, env = _two_rank_env()
+    a, b = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    common = ["--mode", "subframes", "--no-densify", "--iters", "8", "--curve-start", "1"]
+    _run([sys.executable, tool, "--ranks", "1"] + common + ["--out", a], env)
+    _run([sys.executable, tool, "--ranks", "2"] + common + ["--out", b], env)
+    da, db = torch.load(a), torch.load(b)
+    for x, y in zip(da["grads_first"], db["grads_first"]):
+        assert (x is None) == (y is None)
+        if x is not None and x.numel():
+            assert float((x - y).abs().max()) <= 1e-5 * (float(x.abs().max()) + 1e-30), float((x - y).abs().max())
+    # (Adam's g / sqrt(v) turns rounding-level differences of near-zero gradients into differences of a fraction of one
+    # learning-rate step; 8 steps were taken)
+    for x, y in zip(da["params"], db["params"]):
+        assert x.shape == y.shape and float((x - y).abs().max()) <= 2e-3 * (float(x.abs().max()) + 1e-12)
+
+
+@pytest.mark.parametrize("mode", _MODES)
+def test_two_ranks_chunked_allreduce_equals_the_single_collective(gpu, mode, tmp_path):
+    """The chunked reduction of the gradient bucket, overlapped with the backward's tail on a side stream, gives the same
+    replicas bit for bit as the single collective after the backward."""
+    import sys
+    import torch
+    root, tool, env = _two_rank_env()
     c1, c4 = str(tmp_path / "c1.pt"), str(tmp_path / "c4.pt")
     for chunks, path in ((1, c1), (4, c4)):
         _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--iters", "14", "--ar-chunks", str(chunks),
@@ -875,10 +936,51 @@ def test_two_ranks_on_one_gpu(gpu, mode, tmp_path):
     d1, d4 = torch.load(c1), torch.load(c4)
     for x, y in zip(d1["params"], d4["params"]):
         assert x.shape == y.shape and torch.equal(x, y), "ar_chunks = 4 vs 1"
-    # SURVEY 8e's fallback: the bucket summed by a direct reduce-scatter + all-gather over point-to-point sends
-    # (sharding.p2p_allreduce_) instead of the backend's all-reduce -- replicas bit-identical, through densification
-    out = _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--ar-chunks", "4"], dict(env, DGS_DIST_ALLREDUCE="p2p"))
+
+
+@pytest.mark.parametrize("mode", _MODES)
+def test_two_ranks_p2p_allreduce(gpu, mode, tmp_path):
+    """SURVEY 8e's fallback: the bucket summed by a direct reduce-scatter + all-gather over point-to-point sends
+    (sharding.p2p_allreduce_) instead of the backend's all-reduce.  DGS_DIST_P2P_MIN_NUMEL=0: EVERY slice of every chunk
+    (and the few-KB trajectory buffer) takes the point-to-point path from iteration 1 on, behind the backward's chunks on
+    the side stream.  Replicas bit-identical through densification, and -- the reduction adds in rank order, which for
+    two ranks is the collective's sum -- bit-identical to the run reduced by the backend's all-reduce."""
+    import sys
+    import torch
+    root, tool, env = _two_rank_env()
+    a, b = str(tmp_path / "coll.pt"), str(tmp_path / "p2p.pt")
+    _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--ar-chunks", "4", "--out", a], env)
+    out = _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--ar-chunks", "4", "--out", b],
+               dict(env, DGS_DIST_ALLREDUCE="p2p", DGS_DIST_P2P_MIN_NUMEL="0"))
     assert "identical: True" in out and "densified: True" in out, out
+    da, db = torch.load(a), torch.load(b)
+    assert da["sizes"] == db["sizes"]
+    for x, y in zip(da["params"], db["params"]):
+        assert x.shape == y.shape and torch.equal(x, y), "p2p reduce-scatter vs the backend's all-reduce"
+
+
+def test_two_ranks_same_collective_order_on_a_rank_without_subframes(gpu):
+    """before curve_start_iter a view has ONE subframe, so in "subframes" mode rank 1 rasterises nothing
+    (FusedStep._empty_slice) yet must issue the loss-block exchange, the depth-smoothness all-reduce and the chunked
+    bucket reduction in the order rank 0 does.  lambda_depth_tv > 0, ar_chunks = 4, six one-subframe iterations first;
+    a wrong order pairs a one-element all-reduce with a bucket slice (gloo: size-mismatch error; RCCL: hang)."""
+    import sys
+    root, tool, env = _two_rank_env()
+    out = _run([sys.executable, tool, "--ranks", "2", "--mode", "subframes", "--ar-chunks", "4", "--depth-tv", "0.01",
+                "--curve-start", "7", "--iters", "20"], env)
+    assert "identical: True" in out and "densified: True" in out, out
+    out = _run([sys.executable, tool, "--ranks", "2", "--mode", "subframes", "--ar-chunks", "4", "--depth-tv", "0.01",
+                "--curve-start", "7", "--iters", "20"], dict(env, DGS_DIST_ALLREDUCE="p2p", DGS_DIST_P2P_MIN_NUMEL="0"))
+    assert "identical: True" in out, out
+
+
+@pytest.mark.parametrize("mode", _MODES)
+def test_two_ranks_bench_launcher(gpu, mode):
+    """bench.py --gpus 2 launches its two ranks itself and reports what the process group saw."""
+    import json
+    import os
+    import sys
+    root, tool, env = _two_rank_env()
     out = _run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "cfg2", "--steps", "3",
                 "--warmup", "1", "--no-cpu-baseline", "--shard", mode], env)
     line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])

@@ -35,7 +35,21 @@ def parse():
     ap.add_argument("--random-sample", action="store_true", help="curve_random_sample on (alignment jitter)")
     ap.add_argument("--ar-chunks", type=int, default=1,
                     help="all-reduce the gradient bucket in this many Gaussian-index chunks, overlapped with the backward")
+    ap.add_argument("--depth-tv", type=float, default=0.0, help="lambda_depth_tv (one more collective per step in subframes mode)")
+    ap.add_argument("--p2p-direct", action="store_true",
+                    help="REPRODUCTION AID, not a product path: replace sharding._p2p by round 3's behaviour (batch_isend_irecv "
+                         "handed device tensors on any backend).  Under gloo the host then reads / writes device memory "
+                         "unordered with the stream: replicas diverge on some boxes (GPUTEST_r03)")
     return ap.parse_args()
+
+
+def _p2p_direct(sends, recvs, group=None):
+    """Round 3's point-to-point layer, kept ONLY here to reproduce its race (see --p2p-direct)."""
+    import torch.distributed as dist
+    ops = [dist.P2POp(dist.isend, t, r, group) for t, r in sends] + [dist.P2POp(dist.irecv, t, r, group) for t, r in recvs]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
 
 
 def launch(args):
@@ -63,6 +77,8 @@ def main():
     from deblurgs_amd.training import TrainingLoop, default_optimization_params
 
     rank, world, local = sharding.init_distributed("cuda")
+    if args.p2p_direct:
+        sharding._p2p = _p2p_direct
     dev = torch.device("cuda", 0 if os.environ.get("DGS_DIST_ONE_DEVICE", "0") == "1" else local)
     torch.cuda.set_device(dev)
     K = 5
@@ -81,7 +97,8 @@ def main():
     opt = default_optimization_params(
         iterations=args.iters + 10, curve_start_iter=args.curve_start, densify_from_iter=far if args.no_densify else 5,
         densification_interval=6, densify_until_iter=args.iters - 3, densify_grad_threshold_init=2e-5,
-        densify_grad_threshold_final=1e-5, opacity_reset_interval=1000, curve_alignment_lr=1e-3, curve_alignment_start=4)
+        densify_grad_threshold_final=1e-5, opacity_reset_interval=1000, curve_alignment_lr=1e-3, curve_alignment_start=4,
+        lambda_depth_tv=args.depth_tv)
     loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=args.mode if world > 1 else False,
                         ar_chunks=args.ar_chunks)
     inplace = []
@@ -108,6 +125,7 @@ def main():
         cam = (it + rank) % n_views if args.mode == "views" else it % n_views
         out = loop.step(it, cam)
         sizes.append(out["num_points"])
+    loop.flush()
     tensors = list(cloud.hot_parameters()) + list(m.parameters())
     sig = torch.stack([p.detach().double().sum() for p in tensors] +
                       [p.detach().double().abs().sum() for p in tensors] +

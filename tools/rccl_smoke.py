@@ -7,7 +7,8 @@ Proves, before the driver's 8-GPU run does: librccl loads, init_process_group(ba
 ReduceOp.AVG on the in-place gradient bucket, ReduceOp.MAX on the int32 skip flag, broadcast of the shared draws, the
 all-reduces of the "subframes" loss block, the packed small-gradient all-reduce and the densification-statistics
 reduction are all supported -- and that with one rank every one of them is the identity: the trained parameters are
-bit-identical to the same run with the collectives skipped.
+bit-identical to the same run with the collectives skipped.  The point-to-point fallback (sharding.p2p_allreduce_) runs
+on RCCL too, as a self send + receive inside one RCCL group.
 """
 import os
 import sys
@@ -69,6 +70,15 @@ def main():
     flag = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     assert flag.tolist() == [0, 1]
+    # SURVEY 8e's fallback on RCCL's point-to-point path: in a one-rank group p2p_allreduce_(force=True) runs both of its
+    # phases as ONE RCCL group holding a send to and a receive from this rank itself (batch_isend_irecv on device tensors,
+    # stream-ordered) -- the values must come back unchanged, also when the producer is still running on the stream
+    for n in (255, 65536 + 7, 3_000_000):
+        x = torch.randn(n, device="cuda")
+        y = x * 1.0                                   # (produced on the stream right before the sends)
+        sharding.p2p_allreduce_(y, average=True, force=True)
+        assert torch.equal(x, y), f"p2p self send/recv changed a buffer of {n} floats"
+    print("rccl smoke: p2p_allreduce_ (batch_isend_irecv, self send + receive in one RCCL group) bit-identical", flush=True)
     for mode in ("views", "subframes"):
         sharding.FORCE_COLLECTIVES = False     # one rank: the gradient / loss-block / statistics collectives are skipped
         base = train(mode)
@@ -83,6 +93,16 @@ def main():
         for i, (a, b) in enumerate(zip(base, got)):
             assert a.shape == b.shape and torch.equal(a, b), f"mode {mode}, 4 chunks: parameter {i} changed"
         print(f"rccl smoke: mode {mode}: 4-chunk overlapped all-reduce bit-identical too", flush=True)
+        # ... and the same steps with every reduction of the bucket (whole, then per chunk on the side stream) and the
+        # few-KB trajectory buffer taking the point-to-point reduce-scatter path on RCCL
+        sharding.ALLREDUCE_MODE, keep_min = "p2p", sharding.P2P_MIN_NUMEL
+        sharding.P2P_MIN_NUMEL = 0
+        for chunks in (1, 4):
+            got = train(mode, ar_chunks=chunks)
+            for i, (a, b) in enumerate(zip(base, got)):
+                assert a.shape == b.shape and torch.equal(a, b), f"mode {mode}, p2p, {chunks} chunk(s): parameter {i} changed"
+        sharding.ALLREDUCE_MODE, sharding.P2P_MIN_NUMEL = "collective", keep_min
+        print(f"rccl smoke: mode {mode}: p2p reduce-scatter (whole bucket and 4 chunks) bit-identical too", flush=True)
     dist.barrier()
     dist.destroy_process_group()
     print("rccl smoke ok: backend nccl, world 1", flush=True)
