@@ -78,7 +78,7 @@ class DgsCloudArrays(ctypes.Structure):
 
 
 ADAM_MAX_GROUPS = 16
-ABI_VERSION = 9            # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
+ABI_VERSION = 10           # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
 
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {
@@ -108,6 +108,9 @@ EXPORTS = {
     "dgs_exclusive_scan_u32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
                                               ctypes.c_void_p, ctypes.c_void_p]),
     "dgs_sort_tmp_bytes": (ctypes.c_size_t, [ctypes.c_uint64]),
+    "dgs_depth_order_tmp_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "dgs_depth_order": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p]),
     "dgs_sort_pairs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p]),

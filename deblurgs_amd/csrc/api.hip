@@ -529,8 +529,9 @@ int dgs_backward_scratch_layout(uint64_t R, int32_t P, int32_t K, size_t* sums_o
 // (tile_cull: its last pass also writes the visibility flags in that order)
 static hipError_t launch_depth_order(const DgsProblem* p, const DgsCarve& c, hipStream_t s) {
   const bool cull = p->tile_cull != 0;
+  // (status word [6]: "a visible depth key needs more than 27 bits", zeroed with the other status words before preprocess)
   return dgs_launch_depth_sort(c.gsort_keys, c.gsort_keys_alt, c.gsort_vals, c.gsort_vals_alt, p->K, (uint32_t)p->P,
-                               c.gsort_tmp, cull ? c.tt_sorted : nullptr, s);
+                               c.gsort_tmp, cull ? c.tt_sorted : nullptr, c.num_rendered + 6, s);
 }
 
 // tile_cull: per-slot test in natural order (independent of the depth order), then records and counts into depth order and
@@ -787,6 +788,24 @@ int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t*
                                  reinterpret_cast<hipStream_t>(stream));
   if (result_in_alt) *result_in_alt = alt;
   return e == hipSuccess ? DGS_OK : fail_hip(e, "sort");
+}
+
+size_t dgs_depth_order_tmp_bytes(int32_t K, int32_t P) {
+  return (K > 0 && P > 0) ? dgs_depth_sort_tmp_words(K, (uint32_t)P) * 4 + 256 : 256;
+}
+int dgs_depth_order(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int32_t K, int32_t P,
+                    void* tmp, uint32_t* visible, dgs_stream_t stream) {
+  if (K < 0 || P < 0) return fail(DGS_E_ARG, "depth_order: bad size");
+  if (K == 0 || P == 0) return DGS_OK;
+  if (keys == nullptr || keys_alt == nullptr || order == nullptr || order_alt == nullptr || tmp == nullptr)
+    return fail(DGS_E_ARG, "depth_order: null buffer");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // the last 256 bytes of tmp hold the "a key needs the fourth pass" word
+  uint32_t* words = reinterpret_cast<uint32_t*>(tmp);
+  uint32_t* flag = words + dgs_depth_sort_tmp_words(K, (uint32_t)P);
+  hipError_t e = hipMemsetAsync(flag, 0, 4, s);
+  if (e == hipSuccess) e = dgs_launch_depth_sort(keys, keys_alt, order, order_alt, K, (uint32_t)P, words, visible, flag, s);
+  return e == hipSuccess ? DGS_OK : fail_hip(e, "depth_order");
 }
 
 static int blur_loss_impl(const float* subframes, const float* gt, int32_t K, int32_t C, int32_t HW, float lambda_t,

@@ -1070,34 +1070,78 @@ onesweep_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __
   }
 }
 
-// ---------------------------------------------------------------------- depth order: segmented 32-bit sort
-// The (k, depth, index) ordering of the K*P (subframe, Gaussian) pairs is K independent sorts of P 32-bit depth keys
-// (positive floats order like their bit patterns; invisible pairs carry 0xFFFFFFFF and sort last): a segmented stable
-// LSD radix sort, four 8-bit passes, one launch chain for all K segments.  Against sorting (k << 32 | depth, index)
-// pairs with the generic 64-bit sort this moves 20 bytes per pair and pass instead of 32 (4-byte keys, the first pass
-// generates the indices instead of reading them, the last pass does not write keys).  A block owns DS_TILE consecutive
-// pairs of ONE segment; the stable order inside a block is (wave, round, lane) as in the generic sort.
-constexpr int DS_THREADS = 256;
+// ---------------------------------------------------------------------- depth order: segmented 27(+5)-bit sort
+// The (k, depth, index) ordering of the K*P (subframe, Gaussian) pairs is K independent sorts of P 32-bit depth keys: a
+// segmented stable LSD radix sort, one launch chain for all K segments.  Against sorting (k << 32 | depth, index) pairs
+// with the generic 64-bit sort this moves 20 bytes per pair and pass instead of 32 (4-byte keys, the first pass
+// generates the indices instead of reading them, the last pass does not write keys).
+//
+// THREE 9-bit passes instead of four 8-bit ones (round 4): a visible pair has view depth > 0.2 (in_frustum,
+// auxiliary.h:159), and positive floats order like their bit patterns, so preprocess stores key = bits(depth) -
+// bits(0.2f) -- order-preserving -- and every depth below 13107 (= the float whose bits are bits(0.2f) + 2^27) gives a
+// key below 2^27: three 9-bit digits.  Invisible pairs carry 0xFFFFFFFF; their three low digits are all ones, so they
+// sort behind every visible key < 2^27 - 1.  A visible key >= 2^27 - 1 (a Gaussian more than 13 km... units deep) sets
+// a device flag (first histogram); the fourth pass on bits [27, 32) and a copy that puts the result where the three-pass
+// result lands are always launched and return at once unless the flag is set: exact for every input, ~4 empty launches
+// in the common case.  A block owns DS_TILE consecutive pairs of ONE segment; the stable order inside a block is
+// (wave, round, lane) as in the generic sort.
+#ifndef DGS_DS_THREADS
+#define DGS_DS_THREADS 512
+#endif
+constexpr int DS_THREADS = DGS_DS_THREADS;
+constexpr int DS_WAVES = DS_THREADS / 64;
 constexpr int DS_ITEMS = 16;
-constexpr int DS_TILE = DS_THREADS * DS_ITEMS;  // 4096 pairs per block
-constexpr int DS_BINS = 256;
+constexpr int DS_TILE = DS_THREADS * DS_ITEMS;  // pairs per block
+constexpr int DS_RB = 9;
+constexpr int DS_BINS = 1 << DS_RB;
+constexpr int DS_BPT = DS_BINS / DS_THREADS > 0 ? DS_BINS / DS_THREADS : 1;   // bins per thread where a block owns all bins
 constexpr int DS_CHUNK = 32;  // blocks per column-scan chunk
+constexpr uint32_t DS_INVISIBLE = 0xFFFFFFFFu;
+constexpr uint32_t DS_NARROW_MAX = (1u << (3 * DS_RB)) - 1u;   // a visible key at or above this needs the fourth pass
+static_assert(DS_BINS % DS_THREADS == 0 || DS_THREADS % DS_BINS == 0, "bins and threads must divide each other");
+static_assert(DS_TILE <= 65535, "per-wave digit counts are kept in 16 bits");
 
-__global__ void __launch_bounds__(DS_THREADS)
-dsort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t P, uint32_t nb, int shift, uint32_t* __restrict__ table) {
-  __shared__ uint32_t h[DS_BINS];
-  h[threadIdx.x] = 0;
+// exclusive scan of one value per thread across an NT-thread block; returns the exclusive prefix, *total = sum
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan_n(uint32_t v, uint32_t* total, uint32_t* lds /*[NT / 64]*/) {
+  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  uint32_t incl = wave_incl_scan(v);
+  if (lane == 63) lds[w] = incl;
   __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NT / 64; i++) {
+    uint32_t s = lds[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+// pass: 0..2 the 9-bit digits, 3 the optional pass on bits [27, 32) (returns unless *wide_flag)
+__global__ void __launch_bounds__(DS_THREADS)
+dsort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t P, uint32_t nb, int pass, uint32_t* __restrict__ table,
+                  uint32_t* __restrict__ wide_flag) {
+  if (pass == 3 && *wide_flag == 0u) return;
+  __shared__ uint32_t h[DS_BINS];
+  for (int i = threadIdx.x; i < DS_BINS; i += DS_THREADS) h[i] = 0;
+  __syncthreads();
+  const int shift = DS_RB * pass;
   const uint32_t k = blockIdx.x / nb, b = blockIdx.x - k * nb;
   const uint32_t* seg = keys + (size_t)k * P;
   const int lane = dgs_lane();
+  bool wide = false;
 #pragma unroll 4
   for (int r = 0; r < DS_ITEMS; r++) {
     const uint32_t i = b * DS_TILE + (uint32_t)r * DS_THREADS + threadIdx.x;
     const bool valid = i < P;
-    const uint32_t d = valid ? (seg[i] >> shift) & 255u : 0u;
-    // the upper digits of depth keys take a handful of values (exponent bits), and after the earlier passes a wave's 64
-    // keys often share theirs: one add of the wave's count instead of 64 same-address LDS atomics
+    const uint32_t key = valid ? seg[i] : 0u;
+    const uint32_t d = (key >> shift) & (uint32_t)(DS_BINS - 1);
+    if (pass == 0) wide = wide || (valid && key != DS_INVISIBLE && key >= DS_NARROW_MAX);
+    // the upper digits of depth keys take few values, and after the earlier passes a wave's 64 keys often share theirs:
+    // one add of the wave's count instead of 64 same-address LDS atomics
     const uint64_t vm = __ballot(valid);
     if (vm == 0ull) continue;
     const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, __builtin_ctzll(vm));
@@ -1107,17 +1151,19 @@ dsort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t P, uint32_t nb, in
       atomicAdd(&h[d], 1u);
     }
   }
+  if (pass == 0 && __ballot(wide) != 0ull && lane == 0) atomicOr(wide_flag, 1u);   // (never, for sane depth ranges)
   __syncthreads();
-  table[(size_t)blockIdx.x * DS_BINS + threadIdx.x] = h[threadIdx.x];
+  for (int i = threadIdx.x; i < DS_BINS; i += DS_THREADS) table[(size_t)blockIdx.x * DS_BINS + i] = h[i];
 }
 
 // (segment, chunk): per digit, exclusive running count over the chunk's blocks (in place) and the chunk total
-// fuse_top (nch == 1, i.e. segments of up to DS_CHUNK * DS_TILE = 131072 pairs): the chunk total IS the digit's count in
+// fuse_top (nch == 1, i.e. segments of up to DS_CHUNK * DS_TILE pairs): the chunk total IS the digit's count in
 // the segment, so the digit bases are formed right here and the top kernel is not launched
 __global__ void __launch_bounds__(DS_BINS)
 dsort_colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nb, uint32_t nch, uint32_t* __restrict__ ctot,
-                           int fuse_top, uint32_t P) {
-  __shared__ uint32_t lds[8];
+                           int fuse_top, uint32_t P, int pass, const uint32_t* __restrict__ wide_flag) {
+  if (pass == 3 && *wide_flag == 0u) return;
+  __shared__ uint32_t lds[DS_BINS / 64];
   const uint32_t k = blockIdx.x / nch, c = blockIdx.x - k * nch;
   const uint32_t t0 = c * DS_CHUNK, t1 = min(t0 + (uint32_t)DS_CHUNK, nb);
   uint32_t* base = table + ((size_t)k * nb) * DS_BINS + threadIdx.x;
@@ -1135,15 +1181,17 @@ dsort_colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nb, uint32_t n
   }
   if (fuse_top) {
     uint32_t tot;
-    run = block_excl_scan(run, &tot, lds) + k * P;   // (what dsort_colscan_top_kernel leaves for the only chunk)
+    run = block_excl_scan_n<DS_BINS>(run, &tot, lds) + k * P;   // (what dsort_colscan_top_kernel leaves for the only chunk)
   }
   ctot[(size_t)blockIdx.x * DS_BINS + threadIdx.x] = run;
 }
 
 // segment k: chunk totals -> exclusive chunk bases per digit, plus the digit's base inside the segment and k * P
 __global__ void __launch_bounds__(DS_BINS)
-dsort_colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nch, uint32_t P) {
-  __shared__ uint32_t lds[8];
+dsort_colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nch, uint32_t P, int pass,
+                         const uint32_t* __restrict__ wide_flag) {
+  if (pass == 3 && *wide_flag == 0u) return;
+  __shared__ uint32_t lds[DS_BINS / 64];
   uint32_t* base = ctot + ((size_t)blockIdx.x * nch) * DS_BINS + threadIdx.x;
   uint32_t run = 0;
   for (uint32_t c = 0; c < nch; c++) {
@@ -1152,22 +1200,28 @@ dsort_colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nch, uint32_t P) 
     run += v;
   }
   uint32_t tot;
-  const uint32_t pre = block_excl_scan(run, &tot, lds) + blockIdx.x * P;
+  const uint32_t pre = block_excl_scan_n<DS_BINS>(run, &tot, lds) + blockIdx.x * P;
   for (uint32_t c = 0; c < nch; c++) base[(size_t)c * DS_BINS] += pre;
 }
 
-// FIRST: the values are generated (flat index k * P + i) instead of read.  LAST: keys are not written.
-template <bool FIRST, bool LAST>
+// PASS 0: the values are generated (flat index k * P + i) instead of read.  PASS 2: the last pass unless the wide flag is
+// set -- keys are then not written, and the visibility flags are.  PASS 3: only if the flag is set.
+template <int PASS>
 __global__ void __launch_bounds__(DS_THREADS)
 dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t P, uint32_t nb,
-                     uint32_t nch, int shift, const uint32_t* __restrict__ table, const uint32_t* __restrict__ ctot,
-                     uint32_t* __restrict__ vis_dst) {
+                     uint32_t nch, const uint32_t* __restrict__ table, const uint32_t* __restrict__ ctot,
+                     uint32_t* __restrict__ vis_dst, const uint32_t* __restrict__ wide_flag) {
+  const bool wide = (PASS >= 2) ? (*wide_flag != 0u) : false;
+  if (PASS == 3 && !wide) return;
+  constexpr int shift = DS_RB * PASS;
+  constexpr bool FIRST = PASS == 0;
+  const bool last = (PASS == 3) || (PASS == 2 && !wide);
   __shared__ uint32_t lds_k[DS_TILE];
   __shared__ uint32_t lds_v[DS_TILE];
-  __shared__ uint32_t whist[DS_THREADS / 64][DS_BINS];
+  __shared__ uint16_t whist[DS_WAVES][DS_BINS];   // per-wave digit counts, then the wave's first slot of the digit in the block
   __shared__ uint32_t gb[DS_BINS];
-  __shared__ uint32_t s_scan[8];
+  __shared__ uint32_t s_scan[DS_THREADS / 64];
   const int lane = dgs_lane(), w = threadIdx.x >> 6;
   const uint32_t k = blockIdx.x / nb, b = blockIdx.x - k * nb;
 #pragma unroll
@@ -1176,23 +1230,24 @@ dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   __builtin_amdgcn_wave_barrier();
   const uint32_t wbase = b * DS_TILE + (uint32_t)w * (64 * DS_ITEMS);  // index inside the segment
   const size_t sbase = (size_t)k * P;
-  uint32_t key[DS_ITEMS], val[DS_ITEMS], rank[DS_ITEMS];
-  volatile uint32_t* wh = whist[w];
+  uint32_t key[DS_ITEMS], val[DS_ITEMS];
+  uint16_t rank[DS_ITEMS];
+  volatile uint16_t* wh = whist[w];
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int r = 0; r < DS_ITEMS; r++) {
     const uint32_t i = wbase + (uint32_t)r * 64 + lane;
     const bool valid = i < P;
-    key[r] = valid ? keys_in[sbase + i] : 0xFFFFFFFFu;
+    key[r] = valid ? keys_in[sbase + i] : DS_INVISIBLE;
     val[r] = FIRST ? (uint32_t)(sbase + i) : (valid ? vals_in[sbase + i] : 0u);
   }
 #pragma unroll
   for (int r = 0; r < DS_ITEMS; r++) {
     const bool valid = (wbase + (uint32_t)r * 64 + lane) < P;
-    const uint32_t d = (key[r] >> shift) & 255u;
+    const uint32_t d = (key[r] >> shift) & (uint32_t)(DS_BINS - 1);
     uint64_t peers = __ballot(valid);
 #pragma unroll
-    for (int bit = 0; bit < 8; bit++) {
+    for (int bit = 0; bit < DS_RB; bit++) {
       const uint64_t m = __ballot((d >> bit) & 1u);
       peers &= ((d >> bit) & 1u) ? m : ~m;
     }
@@ -1200,35 +1255,48 @@ dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     uint32_t pre = 0;
     if (valid) pre = wh[d];
     __builtin_amdgcn_wave_barrier();
-    if (valid && below == 0) wh[d] = pre + (uint32_t)__popcll(peers);
+    if (valid && below == 0) wh[d] = (uint16_t)(pre + (uint32_t)__popcll(peers));
     __builtin_amdgcn_wave_barrier();
-    rank[r] = pre + below;
+    rank[r] = (uint16_t)(pre + below);
   }
   __syncthreads();
-  // thread t owns digit t: block total, per-wave exclusive offsets, start of the digit inside the block
-  uint32_t cnt = 0;
-  {
-    const int d = threadIdx.x;
+  // thread t owns digits t, t + DS_THREADS, ...: block total, per-wave exclusive offsets, start of the digit inside the block
+  uint32_t cnt[DS_BPT], cnt_sum = 0;
 #pragma unroll
-    for (int ww = 0; ww < DS_THREADS / 64; ww++) {
-      const uint32_t c = whist[ww][d];
-      whist[ww][d] = cnt;
-      cnt += c;
+  for (int i = 0; i < DS_BPT; i++) {
+    const int d = threadIdx.x * DS_BPT + i;       // (consecutive digits per thread: the block scan below is then in digit order)
+    uint32_t c = 0;
+    if (d < DS_BINS) {
+#pragma unroll
+      for (int ww = 0; ww < DS_WAVES; ww++) c += whist[ww][d];
     }
+    cnt[i] = c;
+    cnt_sum += c;
   }
   uint32_t tot;
-  const uint32_t dstart = block_excl_scan(cnt, &tot, s_scan);
-  // global position of block-local slot i holding digit d:  gb[d] + i
-  gb[threadIdx.x] = table[(size_t)blockIdx.x * DS_BINS + threadIdx.x] +
-                    ctot[((size_t)k * nch + b / DS_CHUNK) * DS_BINS + threadIdx.x] - dstart;
-  __shared__ uint32_t s_dstart[DS_BINS];
-  s_dstart[threadIdx.x] = dstart;
+  uint32_t dstart = block_excl_scan_n<DS_THREADS>(cnt_sum, &tot, s_scan);
+#pragma unroll
+  for (int i = 0; i < DS_BPT; i++) {
+    const int d = threadIdx.x * DS_BPT + i;
+    if (d < DS_BINS) {
+      // global position of block-local slot i holding digit d:  gb[d] + i
+      gb[d] = table[(size_t)blockIdx.x * DS_BINS + d] + ctot[((size_t)k * nch + b / DS_CHUNK) * DS_BINS + d] - dstart;
+      uint32_t run = dstart;
+#pragma unroll
+      for (int ww = 0; ww < DS_WAVES; ww++) {
+        const uint32_t c = whist[ww][d];
+        whist[ww][d] = (uint16_t)run;              // first block-local slot of (wave ww, digit d)
+        run += c;
+      }
+      dstart += cnt[i];
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < DS_ITEMS; r++) {
     if ((wbase + (uint32_t)r * 64 + lane) < P) {
-      const uint32_t d = (key[r] >> shift) & 255u;
-      const uint32_t slot = s_dstart[d] + whist[w][d] + rank[r];
+      const uint32_t d = (key[r] >> shift) & (uint32_t)(DS_BINS - 1);
+      const uint32_t slot = (uint32_t)whist[w][d] + rank[r];
       lds_k[slot] = key[r];
       lds_v[slot] = val[r];
     }
@@ -1240,16 +1308,24 @@ dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     const uint32_t i = (uint32_t)r * DS_THREADS + threadIdx.x;
     if (i < nvalid) {
       const uint32_t kk = lds_k[i];
-      const uint32_t pos = gb[(kk >> shift) & 255u] + i;
-      if (!LAST) keys_out[pos] = kk;
+      const uint32_t pos = gb[(kk >> shift) & (uint32_t)(DS_BINS - 1)] + i;
+      if (!last) keys_out[pos] = kk;
       const uint32_t vv = lds_v[i];
       vals_out[pos] = vv;
       // tile_cull: the last pass also writes the visibility flags in the final order (invisible pairs sort to the end of
       // their subframe); the 16-byte cull records follow in a gather kernel of their own -- done here, behind this
       // kernel's LDS exchange and at its occupancy, the dependent random reads cost 225 us instead of ~100
-      if (LAST && vis_dst != nullptr) vis_dst[pos] = (kk != 0xFFFFFFFFu) ? 1u : 0u;
+      if (last && vis_dst != nullptr) vis_dst[pos] = (kk != DS_INVISIBLE) ? 1u : 0u;
     }
   }
+}
+
+// only if the fourth pass ran: its result into the buffer the three-pass result lands in
+__global__ void __launch_bounds__(256)
+dsort_copy_if_wide_kernel(uint64_t n, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                          const uint32_t* __restrict__ wide_flag) {
+  if (*wide_flag == 0u) return;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 // tile_cull: the surviving-tile counts (natural order) into (k, depth, index) order, the input of the scan.
@@ -1481,36 +1557,41 @@ size_t dgs_depth_sort_tmp_words(int K, uint32_t P) {
   return (size_t)((uint64_t)K * (nb + nch) * DS_BINS + 256);
 }
 
-// keys [K*P] u32 (destroyed), order out [K*P] u32 = flat (k, Gaussian) indices in (k, key, index) order.  Four passes:
-// the result always lands in `order` (the first of the two value buffers).
+// keys [K*P] u32 = bits(depth) - DGS_DEPTH_KEY_BASE for a visible pair, 0xFFFFFFFF for an invisible one (destroyed);
+// order out [K*P] u32 = flat (k, Gaussian) indices in (k, key, index) order.  Three 9-bit passes (+ the conditional
+// fourth): the result always lands in `order`.  wide_flag: one device word, zero on entry.
 hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
-                                 uint32_t P, uint32_t* tmp, uint32_t* vis_dst, hipStream_t s) {
+                                 uint32_t P, uint32_t* tmp, uint32_t* vis_dst, uint32_t* wide_flag, hipStream_t s) {
   if (K <= 0 || P == 0) return hipSuccess;
   const uint32_t nb = (P + DS_TILE - 1) / DS_TILE;
   const uint32_t nch = (nb + DS_CHUNK - 1) / DS_CHUNK;
   uint32_t* table = tmp;
   uint32_t* ctot = tmp + (size_t)K * nb * DS_BINS;
   const dim3 grid((uint32_t)K * nb), cgrid((uint32_t)K * nch);
-  uint32_t* kin = keys;
-  uint32_t* kout = keys_alt;
-  uint32_t* vin = order;       // pass 0 generates the values and writes order_alt, pass 3 writes order
-  uint32_t* vout = order_alt;
+  // buffers A = (keys, order), B = (keys_alt, order_alt):
+  //   pass 0  A.keys          -> B.keys, A.order        pass 1  B.keys, A.order -> A.keys, B.order
+  //   pass 2  A.keys, B.order -> A.order (+ B.keys if wide)     pass 3 (wide)  B.keys, A.order -> B.order, copied to A.order
   for (int pass = 0; pass < 4; pass++) {
-    const int shift = 8 * pass;
-    hipLaunchKernelGGL(dsort_hist_kernel, grid, dim3(DS_THREADS), 0, s, kin, P, nb, shift, table);
-    hipLaunchKernelGGL(dsort_colscan_chunk_kernel, cgrid, dim3(DS_BINS), 0, s, table, nb, nch, ctot, nch == 1 ? 1 : 0, P);
-    if (nch > 1) hipLaunchKernelGGL(dsort_colscan_top_kernel, dim3((uint32_t)K), dim3(DS_BINS), 0, s, ctot, nch, P);
-    if (pass == 0)
-      hipLaunchKernelGGL((dsort_scatter_kernel<true, false>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P, nb,
-                         nch, shift, table, ctot, vis_dst);
-    else if (pass == 3)
-      hipLaunchKernelGGL((dsort_scatter_kernel<false, true>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P, nb,
-                         nch, shift, table, ctot, vis_dst);
-    else
-      hipLaunchKernelGGL((dsort_scatter_kernel<false, false>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P,
-                         nb, nch, shift, table, ctot, vis_dst);
-    uint32_t* tk = kin; kin = kout; kout = tk;
-    uint32_t* tv = vin; vin = vout; vout = tv;
+    const uint32_t* kin = (pass & 1) ? keys_alt : keys;
+    uint32_t* kout = (pass & 1) ? keys : keys_alt;
+    const uint32_t* vin = (pass & 1) ? order : order_alt;
+    uint32_t* vout = (pass & 1) ? order_alt : order;
+    hipLaunchKernelGGL(dsort_hist_kernel, grid, dim3(DS_THREADS), 0, s, kin, P, nb, pass, table, wide_flag);
+    hipLaunchKernelGGL(dsort_colscan_chunk_kernel, cgrid, dim3(DS_BINS), 0, s, table, nb, nch, ctot, nch == 1 ? 1 : 0, P,
+                       pass, wide_flag);
+    if (nch > 1)
+      hipLaunchKernelGGL(dsort_colscan_top_kernel, dim3((uint32_t)K), dim3(DS_BINS), 0, s, ctot, nch, P, pass, wide_flag);
+#define DGS_DS_SCATTER(PASS_)                                                                                         \
+  hipLaunchKernelGGL((dsort_scatter_kernel<PASS_>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P, nb, nch, table, \
+                     ctot, vis_dst, wide_flag)
+    if (pass == 0) DGS_DS_SCATTER(0);
+    else if (pass == 1) DGS_DS_SCATTER(1);
+    else if (pass == 2) DGS_DS_SCATTER(2);
+    else DGS_DS_SCATTER(3);
+#undef DGS_DS_SCATTER
   }
+  const uint64_t n = (uint64_t)K * P;
+  const uint32_t cb = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(dsort_copy_if_wide_kernel, dim3(cb), dim3(256), 0, s, n, order_alt, order, wide_flag);
   return hipGetLastError();
 }

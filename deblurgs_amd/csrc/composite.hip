@@ -86,8 +86,16 @@ using CullGauss = DgsCull;
 // ------------------------------------------------------------------------------------------------ forward
 // WITHDEPTH = false: the caller does not consume the depth image (DgsForwardOut.out_depth == NULL; the default training
 // loss never reads it): the depth channel drops out of the per-pair math and nothing is stored for it.
+#ifndef DGS_FWD_WAVES
+#define DGS_FWD_WAVES 0
+#endif
+#if DGS_FWD_WAVES
+#define DGS_FWD_OCC __attribute__((amdgpu_waves_per_eu(DGS_FWD_WAVES, DGS_FWD_WAVES)))
+#else
+#define DGS_FWD_OCC
+#endif
 template <bool WITHDEPTH>
-__global__ void __launch_bounds__(64 * CW)
+__global__ void __launch_bounds__(64 * CW) DGS_FWD_OCC
 composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
                      const uint32_t* __restrict__ point_list, const uint64_t* __restrict__ keys,
                      const DgsRow* __restrict__ rows,
@@ -232,8 +240,22 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
 // ----------------------------------------------------------------------------------------------- backward
 // TIGHT: the duplicate index travels in the low key word (tile_cull emission).  HASDEPTH: dL_ddepth is given (the
 // default training loss does not use the depth output: the depth channel then drops out of the per-pair math)
+#ifndef DGS_BWD_WAVES
+#define DGS_BWD_WAVES 0
+#endif
+#ifndef DGS_BWD_SPEC
+#define DGS_BWD_SPEC 0
+#endif
+#ifndef DGS_BWD_ADDTID
+#define DGS_BWD_ADDTID 0
+#endif
+#if DGS_BWD_WAVES
+#define DGS_BWD_OCC __attribute__((amdgpu_waves_per_eu(DGS_BWD_WAVES, DGS_BWD_WAVES)))
+#else
+#define DGS_BWD_OCC
+#endif
 template <bool TIGHT, bool HASDEPTH>
-__global__ void __launch_bounds__(64 * CW)
+__global__ void __launch_bounds__(64 * CW) DGS_BWD_OCC
 composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
                      const uint32_t* __restrict__ point_list, const uint64_t* __restrict__ keys,
                      const DgsRow* __restrict__ rows,
@@ -259,6 +281,11 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   // values of sum `row`; the quad's four partial sums are combined with two DPP adds and lane quarter 0 stores the total
   const int rrow = lane >> 2, rq = lane & 3;
   const bool rlane = rrow < (HASDEPTH ? 10 : 9);
+#if DGS_BWD_ADDTID
+  static_assert(sizeof(float) * 68 == 272, "the store offsets below are multiples of one s_part row");
+  // LDS byte offset of this wave's s_part block (the low half of a flat LDS address is the offset inside the LDS)
+  const uint32_t part_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(&s_part[w][0][0]));
+#endif
   
 
   // per-pixel channel state kept as (r,g) and (b,depth) pairs so the channel arithmetic issues as packed fp32
@@ -382,9 +409,11 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       float S_w = 0, S_wx = 0, S_wy = 0, S_xx = 0, S_xy = 0, S_yy = 0;
       v2f sA = {0.0f, 0.0f}, sB = {0.0f, 0.0f};  // (dL_dr, dL_dg), (dL_db, dL_ddepth)
       const v2f colA = {b.z, b.w}, colB = {c.x, c.y};
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if ((m[q] >> j) & 1ull) {  // wave-uniform
+      // one (Gaussian, quadrant) pass.  FIRST: the entry's first executed pass STARTS the ten sums (a product instead of
+      // 0 + product: the same value, up to the sign of a zero), so no accumulator is initialised and none of its adds runs
+      auto pass = [&](auto qc, auto firstc) __attribute__((always_inline)) {
+          constexpr int q = decltype(qc)::value;
+          constexpr bool FIRST = decltype(firstc)::value;
           const float dx = a.x - ((q & 1) ? pxf1 : pxf0);
           const float dy = a.y - ((q >> 1) ? pyf1 : pyf0);
           // backward.cu:566-637, branch-free per lane.  A pair that the reference skips gets alpha = 0: then
@@ -411,23 +440,94 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           const float wgt = au * (behind * T[q]);  // au == 0 for a skipped pair
           const float wx = wgt * dx, wy = wgt * dy;
           // (scalar FMAs: a packed v_pk_fma_f32 was measured slower than the two scalar ones it replaces)
-          sA.x = fmaf(gA[q].x, dchannel_dcolor, sA.x);
-          sA.y = fmaf(gA[q].y, dchannel_dcolor, sA.y);
-          sB.x = fmaf(gB[q].x, dchannel_dcolor, sB.x);
-          if (HASDEPTH) sB.y = fmaf(gB[q].y, dchannel_dcolor, sB.y);
-          S_w += wgt;
-          S_wx += wx;
-          S_wy += wy;
-          S_xx = fmaf(wx, dx, S_xx);
-          S_xy = fmaf(wx, dy, S_xy);
-          S_yy = fmaf(wy, dy, S_yy);
+          if (FIRST) {
+            sA.x = gA[q].x * dchannel_dcolor;
+            sA.y = gA[q].y * dchannel_dcolor;
+            sB.x = gB[q].x * dchannel_dcolor;
+            if (HASDEPTH) sB.y = gB[q].y * dchannel_dcolor;
+            S_w = wgt;
+            S_wx = wx;
+            S_wy = wy;
+            S_xx = wx * dx;
+            S_xy = wx * dy;
+            S_yy = wy * dy;
+          } else {
+            sA.x = fmaf(gA[q].x, dchannel_dcolor, sA.x);
+            sA.y = fmaf(gA[q].y, dchannel_dcolor, sA.y);
+            sB.x = fmaf(gB[q].x, dchannel_dcolor, sB.x);
+            if (HASDEPTH) sB.y = fmaf(gB[q].y, dchannel_dcolor, sB.y);
+            S_w += wgt;
+            S_wx += wx;
+            S_wy += wy;
+            S_xx = fmaf(wx, dx, S_xx);
+            S_xy = fmaf(wx, dy, S_xy);
+            S_yy = fmaf(wy, dy, S_yy);
+          }
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      using I3 = std::integral_constant<int, 3>;
+      // straight-line code for one set of hit quadrants (MASK bit q = quadrant q is walked): no per-pass branch tests
+      auto passes = [&](auto maskc) __attribute__((always_inline)) {
+          constexpr int M_ = decltype(maskc)::value;
+          if constexpr (M_ & 1) pass(I0{}, std::true_type{});
+          if constexpr (M_ & 2) pass(I1{}, std::bool_constant<(M_ & 1) == 0>{});
+          if constexpr (M_ & 4) pass(I2{}, std::bool_constant<(M_ & 3) == 0>{});
+          if constexpr (M_ & 8) pass(I3{}, std::bool_constant<(M_ & 7) == 0>{});
+      };
+#if DGS_BWD_SPEC
+      {
+        const uint32_t hm = (uint32_t)((m[0] >> j) & 1ull) | ((uint32_t)((m[1] >> j) & 1ull) << 1) |
+                            ((uint32_t)((m[2] >> j) & 1ull) << 2) | ((uint32_t)((m[3] >> j) & 1ull) << 3);
+#define DGS_CASE(M_) case M_: passes(std::integral_constant<int, M_>{}); break;
+        switch (hm) {
+          DGS_CASE(1) DGS_CASE(2) DGS_CASE(3) DGS_CASE(4) DGS_CASE(5) DGS_CASE(6) DGS_CASE(7) DGS_CASE(8)
+          DGS_CASE(9) DGS_CASE(10) DGS_CASE(11) DGS_CASE(12) DGS_CASE(13) DGS_CASE(14) DGS_CASE(15)
+          default: break;
         }
+#undef DGS_CASE
       }
+#else
+      if ((m[0] >> j) & 1ull) pass(I0{}, std::false_type{});   // wave-uniform
+      if ((m[1] >> j) & 1ull) pass(I1{}, std::false_type{});
+      if ((m[2] >> j) & 1ull) pass(I2{}, std::false_type{});
+      if ((m[3] >> j) & 1ull) pass(I3{}, std::false_type{});
+#endif
       {
         // 10 wave sums through LDS instead of the VALU (which this kernel saturates): ten conflict-free 4-byte stores per
         // lane, then 40 lanes read 16 values each (four 16-byte loads) and add them; the cross-lane instructions of the
         // VALU reduce-scatter (8 v_permlane*_swap at 5.4 issue cycles, 7 DPP adds at 4.4) become 15 plain adds and 2 DPP
         // adds, and the LDS pipe -- nearly idle here -- does the data movement.  Fixed order of additions: deterministic.
+#if DGS_BWD_ADDTID
+        // ds_write_addtid_b32: LDS address = M0 + offset + 4 * lane -- no address VGPR to ship to the LDS, 2 cycles per
+        // store instead of ds_write_b32's 4 (MI355X_MICROARCH.md, LDS table).  (s_nop: an SALU write of M0 needs one wait
+        // state before an add-TID LDS instruction reads it -- the compiler inserts it for its own code, not inside asm;
+        // without it the stores of some waves went to a stale M0: tools/addtid_probe.hip.)  The ten stores are 40 of the ~64 LDS
+        // cycles an entry costs its CU, and the CU's LDS is ~70 % busy in this kernel.
+        if (HASDEPTH)
+          asm volatile(
+              "s_mov_b32 m0, %10\n\ts_nop 0\n\t"
+              "ds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:272\n\t"
+              "ds_write_addtid_b32 %2 offset:544\n\tds_write_addtid_b32 %3 offset:816\n\t"
+              "ds_write_addtid_b32 %4 offset:1088\n\tds_write_addtid_b32 %5 offset:1360\n\t"
+              "ds_write_addtid_b32 %6 offset:1632\n\tds_write_addtid_b32 %7 offset:1904\n\t"
+              "ds_write_addtid_b32 %8 offset:2176\n\tds_write_addtid_b32 %9 offset:2448\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              :: "v"(S_wx), "v"(S_wy), "v"(S_xx), "v"(S_xy), "v"(S_yy), "v"(S_w), "v"(sA.x), "v"(sA.y), "v"(sB.x),
+                 "v"(sB.y), "s"(part_base) : "m0", "memory");
+        else
+          asm volatile(
+              "s_mov_b32 m0, %9\n\ts_nop 0\n\t"
+              "ds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:272\n\t"
+              "ds_write_addtid_b32 %2 offset:544\n\tds_write_addtid_b32 %3 offset:816\n\t"
+              "ds_write_addtid_b32 %4 offset:1088\n\tds_write_addtid_b32 %5 offset:1360\n\t"
+              "ds_write_addtid_b32 %6 offset:1632\n\tds_write_addtid_b32 %7 offset:1904\n\t"
+              "ds_write_addtid_b32 %8 offset:2176\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              :: "v"(S_wx), "v"(S_wy), "v"(S_xx), "v"(S_xy), "v"(S_yy), "v"(S_w), "v"(sA.x), "v"(sA.y), "v"(sB.x),
+                 "s"(part_base) : "m0", "memory");
+#else
         float* pw = &s_part[w][0][lane];
         pw[0 * 68] = S_wx;
         pw[1 * 68] = S_wy;
@@ -439,6 +539,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         pw[7 * 68] = sA.y;
         pw[8 * 68] = sB.x;
         if (HASDEPTH) pw[9 * 68] = sB.y;
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -6,6 +6,11 @@
 #include "../../include/dgs_hip.h"
 
 #define DGS_TILE 16                 // reference BLOCK_X/BLOCK_Y (config.h:16-17): tile ids must match
+// Depth-sort key of a visible (subframe, Gaussian) pair = bits(view depth) - DGS_DEPTH_KEY_BASE.  in_frustum keeps
+// depth > 0.2f only (auxiliary.h:159), positive floats order like their bit patterns, so the difference is positive,
+// order-preserving and below 2^27 for every depth under 13107: the depth order is then three 9-bit radix passes
+// (binning.hip; a key that needs more bits sets a flag that switches a fourth pass on).  Invisible pairs: 0xFFFFFFFF.
+#define DGS_DEPTH_KEY_BASE 0x3E4CCCCDu   // bits(0.2f)
 #define DGS_ROW_F 12                // floats per geometry row (48 B)
 #define DGS_CONTRIB_F 12            // floats per backward contribution row (48 B): 10 used
 #define DGS_SUMS_F 16               // float stride of the per-(subframe, Gaussian) totals of those rows: 64-byte slots, so the
@@ -250,7 +255,7 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
                                 hipStream_t s);
 
 hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
-                                 uint32_t P, uint32_t* tmp, uint32_t* vis_dst, hipStream_t s);
+                                 uint32_t P, uint32_t* tmp, uint32_t* vis_dst, uint32_t* wide_flag, hipStream_t s);
 size_t dgs_depth_sort_tmp_words(int K, uint32_t P);
 size_t dgs_scan_tmp_words(uint64_t n);
 size_t dgs_sort_tmp_words(uint64_t n);

@@ -247,7 +247,7 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
       tiles_touched[o] = out_tiles;
       // sort key of the (k, Gaussian) pair for the depth-ordered duplication (binning.hip): invisible pairs sort
       // to the end of their subframe and emit nothing
-      dkeys[o] = out_tiles ? __float_as_uint(row.depth) : 0xFFFFFFFFu;
+      dkeys[o] = out_tiles ? __float_as_uint(row.depth) - DGS_DEPTH_KEY_BASE : 0xFFFFFFFFu;
     }
     // wave-transposed stores of the 64 rows / colour masks of this (wave, k); invisible pairs store zeros
     {

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 9
+#define DGS_ABI_VERSION 10
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -158,7 +158,7 @@ typedef struct DgsLayout {
   size_t scan_tmp;       /* u32 scan block sums */
   size_t num_rendered;   /* u32 [8] status words: [0],[1] rectangle total lo/hi (tile_cull = 0), [2],[3] surviving total lo/hi
                           * (tile_cull = 1), [4] the count the lists were built with, [5] overflow flag (capacity mode) */
-  size_t gsort_keys;     /* u32 [K,P] depth bits (0xFFFFFFFF = invisible): keys of the segmented depth sort */
+  size_t gsort_keys;     /* u32 [K,P] bits(depth) - bits(0.2f) (0xFFFFFFFF = invisible): keys of the segmented depth sort */
   size_t gsort_keys_alt; /* u32 [K,P] its ping-pong buffer */
   size_t gsort_vals;     /* u32 [K*P] flat (k, Gaussian) indices in (k, depth, index) order (the sort's result) */
   size_t gsort_vals_alt; /* u32 [K*P] */
@@ -261,6 +261,16 @@ size_t dgs_sort_tmp_bytes(uint64_t n);
  * clobbered; *result_in_alt tells which pair holds the result (0: keys/vals, 1: keys_alt/vals_alt). */
 int dgs_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt, uint64_t n,
                    int32_t begin_bit, int32_t end_bit, void* tmp, int32_t* result_in_alt, dgs_stream_t stream);
+
+/* The depth order of the fused rasteriser on its own (the stage between preprocess and duplicateWithKeys; the reference
+ * sorts depth inside its one 64-bit cub sort, rasterizer_impl.cu:306-314): K independent stable sorts of P u32 keys,
+ * key = bits(view depth) - bits(0.2f) for a visible (subframe, Gaussian) pair, 0xFFFFFFFF for an invisible one.
+ * order[K*P] receives the flat indices k * P + g in (k, key, g) order; visible (optional, [K*P]) 1 / 0 in that order.
+ * keys, keys_alt, order_alt are clobbered; tmp: dgs_depth_order_tmp_bytes(K, P) bytes.  Three 9-bit passes when every
+ * visible key is below 2^27 - 1 (depth < 13107), a fourth one otherwise -- decided on the device. */
+size_t dgs_depth_order_tmp_bytes(int32_t K, int32_t P);
+int dgs_depth_order(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int32_t K, int32_t P,
+                    void* tmp, uint32_t* visible, dgs_stream_t stream);
 
 /* Fused loss-gradient image (train.py:143-165, utils/loss_utils.py:17-18,80-93): from the K rendered subframes
  * and the target, produces blur = mean_k, the L1 and temporal-smoothness loss values and/or dL/dsubframes in one pass.

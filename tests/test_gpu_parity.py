@@ -76,6 +76,52 @@ def test_radix_sort_pairs_stable(gpu, n, bits):
     assert np.array_equal(ko, keys[order])
 
 
+@pytest.mark.parametrize("K,P,kind", [(1, 1, "narrow"), (3, 4097, "narrow"), (2, 8192, "narrow"), (15, 100_003, "narrow"),
+                                      (4, 1_000_001, "narrow"), (3, 20_000, "wide"), (2, 4096, "edge"),
+                                      (5, 3_000, "all_invisible"), (2, 70_000, "ties")])
+def test_depth_order_segmented_sort(gpu, K, P, kind):
+    """dgs_depth_order: K independent stable sorts of keys = bits(depth) - bits(0.2f) (0xFFFFFFFF = invisible) against
+    numpy's stable argsort per segment; bit-exact order and visibility flags.  "narrow": depths below 13107 -- three 9-bit
+    passes; "wide": some depths beyond (keys >= 2^27: the device switches the fourth pass on); "edge": keys at 2^27 - 2,
+    2^27 - 1 (the first one that needs the fourth pass: its low 27 bits equal the invisible marker's) and 2^27; "ties":
+    few distinct depths (stability)."""
+    import ctypes
+    import torch
+    from deblurgs_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(K * 7919 + P)
+    base = np.float32(0.2).view(np.uint32)
+    if kind == "wide":
+        depth = np.exp(rng.uniform(np.log(0.21), np.log(3.0e6), size=(K, P))).astype(np.float32)
+    elif kind == "ties":
+        depth = rng.choice(np.array([0.25, 1.0, 1.5, 7.0, 99.0], np.float32), size=(K, P))
+    else:
+        depth = rng.uniform(0.2001, 100.0, size=(K, P)).astype(np.float32)
+    keys = (depth.view(np.uint32) - base).astype(np.uint32)
+    if kind == "edge":
+        keys[:, ::5] = np.uint32((1 << 27) - 2)
+        keys[0, 1::7] = np.uint32((1 << 27) - 1)
+        keys[1, 2::11] = np.uint32(1 << 27)
+    invisible = rng.random((K, P)) < (1.0 if kind == "all_invisible" else 0.22)
+    keys[invisible] = np.uint32(0xFFFFFFFF)
+    want = np.concatenate([k * P + np.argsort(keys[k], kind="stable") for k in range(K)]).astype(np.uint32)
+    t = lambda a: torch.from_numpy(a.view(np.int32).copy()).to(gpu)
+    k0, k1 = t(keys.reshape(-1)), torch.zeros(K * P, dtype=torch.int32, device=gpu)
+    o0, o1 = torch.full((K * P,), -1, dtype=torch.int32, device=gpu), torch.full((K * P,), -1, dtype=torch.int32, device=gpu)
+    vis = torch.full((K * P,), 7, dtype=torch.int32, device=gpu)
+    tmp = torch.empty(L.dgs_depth_order_tmp_bytes(K, P), dtype=torch.uint8, device=gpu)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.dgs_depth_order(k0.data_ptr(), k1.data_ptr(), o0.data_ptr(), o1.data_ptr(), K, P, tmp.data_ptr(),
+                                 vis.data_ptr(), st), "depth_order")
+    torch.cuda.synchronize()
+    got = o0.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, want), f"{kind}: first mismatch at {int(np.argmax(got != want))}"
+    assert np.array_equal(vis.cpu().numpy(), (keys.reshape(-1)[want] != np.uint32(0xFFFFFFFF)).astype(np.int32))
+    wide_needed = bool(((keys != np.uint32(0xFFFFFFFF)) & (keys >= np.uint32((1 << 27) - 1))).any())
+    flag = int(tmp[-256:].view(torch.int32)[0].item())
+    assert flag == int(wide_needed), (kind, flag, wide_needed)
+
+
 # --------------------------------------------------------------------------------------------- stage parity
 @pytest.fixture(scope="module")
 def scene_states(gpu):
