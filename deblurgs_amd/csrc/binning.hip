@@ -347,9 +347,6 @@ duplicate_sorted_kernel(DgsView v, DgsRow* __restrict__ rows, const uint32_t* __
 //     again (identical instructions -- this file is built with -ffp-contract=off).
 // The low key word carries the duplicate's own index u (its contribution-row slot for the backward) instead of the depth
 // bits, which the tile-bits-only stable sort never looks at.
-#ifndef DGS_RANGES_SWEEP
-#define DGS_RANGES_SWEEP 0
-#endif
 constexpr uint32_t CULL_BIG = 0x80000000u;   // record.x: rectangle of more than 64 slots (otherwise minx | miny << 12 | (width - 1) << 24)
 constexpr int CULL_CH = 32;                  // rounds (of 64 slots) per refill of the segment-start bit table
 
@@ -624,30 +621,6 @@ __global__ void finalize_count_kernel(uint32_t* __restrict__ nr, int cull, uint3
 
 // ---------------------------------------------------------------------------------------------- ranges
 __global__ void __launch_bounds__(256)
-ranges_kernel(uint32_t L, const uint32_t* __restrict__ n_dev, const uint64_t* __restrict__ keys,
-              uint2* __restrict__ ranges, int tile_shift) {
-  if (n_dev != nullptr) L = min(L, n_dev[0]);
-  const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= L) return;
-  const uint32_t currtile = (uint32_t)(keys[idx] >> tile_shift);
-  if (idx == 0)
-    ranges[currtile].x = 0;
-  else {
-    const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> tile_shift);
-    if (currtile != prevtile) {
-      ranges[prevtile].y = idx;
-      ranges[currtile].x = idx;
-    }
-  }
-  if (idx == L - 1) ranges[currtile].y = L;
-}
-
-// The same ranges without reading the 8 R bytes of sorted keys: thread t finds the first list position whose tile is
-// >= t by binary search (26 probes at 37 M keys; the threads of a block probe neighbouring positions, so the upper levels
-// of every search hit the same few cache lines) and a tile's range is [bound(t), bound(t + 1)) -- (0, 0) when empty, as
-// the reference's zero-filled array has it (rasterizer_impl.cu:113-138).  122 k tiles x 26 probes instead of a 296 MB
-// sweep: 0.10 -> 0.03 ms per metric step; no memset, every tile is written.
-__global__ void __launch_bounds__(256)
 ranges_search_kernel(uint32_t L, const uint32_t* __restrict__ n_dev, const uint64_t* __restrict__ keys,
                      uint2* __restrict__ ranges, int tile_shift, uint32_t ntiles) {
   __shared__ uint32_t s_b[257];
@@ -687,88 +660,6 @@ constexpr int SORT_ITEMS = DGS_SORT_ITEMS;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 pairs per block
 constexpr int SORT_MAX_RB = 9;
 constexpr int SORT_MAX_BINS = 1 << SORT_MAX_RB;
-
-__global__ void __launch_bounds__(SORT_THREADS)
-sort_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift, int rb, uint32_t nblocks,
-                 uint32_t* __restrict__ table) {
-  __shared__ uint32_t h[SORT_MAX_BINS];
-  const int bins = 1 << rb;
-  for (int i = threadIdx.x; i < bins; i += SORT_THREADS) h[i] = 0;
-  __syncthreads();
-  const uint64_t base = (uint64_t)blockIdx.x * SORT_TILE;
-  const uint32_t mask = (uint32_t)bins - 1;
-#pragma unroll 4
-  for (int r = 0; r < SORT_ITEMS; r++) {
-    const uint64_t i = base + (uint64_t)r * SORT_THREADS + threadIdx.x;
-    if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < bins; i += SORT_THREADS) table[(uint64_t)i * nblocks + blockIdx.x] = h[i];
-}
-
-__global__ void __launch_bounds__(SORT_THREADS)
-sort_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint64_t n, int shift, int rb,
-                    uint32_t nblocks, const uint32_t* __restrict__ table) {
-  // per-wave running digit counts, then (after the barrier) per-wave exclusive bases
-  __shared__ uint32_t whist[SORT_THREADS / 64][SORT_MAX_BINS];
-  const int bins = 1 << rb;
-  const uint32_t mask = (uint32_t)bins - 1;
-  const int lane = dgs_lane(), w = threadIdx.x >> 6;
-  for (int i = lane; i < bins; i += 64) whist[w][i] = 0;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-
-  const uint64_t wbase = (uint64_t)blockIdx.x * SORT_TILE + (uint64_t)w * (64 * SORT_ITEMS);
-  uint64_t key[SORT_ITEMS];
-  uint32_t val[SORT_ITEMS];
-  uint32_t rank[SORT_ITEMS];
-  volatile uint32_t* wh = whist[w];
-  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-  for (int r = 0; r < SORT_ITEMS; r++) {
-    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
-    const bool valid = i < n;
-    key[r] = valid ? keys_in[i] : ~0ull;
-    val[r] = valid ? vals_in[i] : 0u;
-    const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-    // lanes of this wave holding the same digit (invalid lanes match nobody valid)
-    uint64_t peers = __ballot(valid);
-    for (int b = 0; b < rb; b++) {
-      const uint64_t m = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? m : ~m;
-    }
-    const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
-    uint32_t pre = 0;
-    if (valid) pre = wh[d];
-    __builtin_amdgcn_wave_barrier();
-    if (valid && below == 0) wh[d] = pre + (uint32_t)__popcll(peers);
-    __builtin_amdgcn_wave_barrier();
-    rank[r] = pre + below;
-  }
-  __syncthreads();
-  // whist[w][d] now holds wave totals.  Turn them into global bases: table[d][block] + sum of earlier waves.
-  for (int d = threadIdx.x; d < bins; d += SORT_THREADS) {
-    uint32_t run = table[(uint64_t)d * nblocks + blockIdx.x];
-#pragma unroll
-    for (int ww = 0; ww < SORT_THREADS / 64; ww++) {
-      const uint32_t c = whist[ww][d];
-      whist[ww][d] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < SORT_ITEMS; r++) {
-    const uint64_t i = wbase + (uint64_t)r * 64 + lane;
-    if (i < n) {
-      const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-      const uint32_t pos = whist[w][d] + rank[r];
-      keys_out[pos] = key[r];
-      vals_out[pos] = val[r];
-    }
-  }
-}
 
 // ----------------------------------------------------------------------- tile-major histogram table + column scan
 // The classic table is digit-major ([digit][tile]) so that one flat scan yields scatter bases, but that makes
@@ -876,60 +767,19 @@ colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nchunks, const uint32_t
   dbase[threadIdx.x + 256] = pre1;
 }
 
-// ------------------------------------------------------------------------------------ onesweep radix sort
-// Single-pass-per-digit variant (default): the digit histograms of ALL passes come from one read of the keys;
-// each pass then reads every pair once and writes it once.  A tile (4096 pairs) takes a ticket, ranks its pairs
-// exactly like sort_scatter_kernel, publishes its per-digit counts as self-tagged 32-bit words
-// {flag:2 | count:30} and resolves its global offsets by decoupled look-back over the preceding tiles.  The words
-// are written/read with relaxed agent-scope atomics (sc1): flag and payload travel in one word, so no fence is
-// needed and no dispatch-order or XCD-placement assumption is made beyond "a tile with a smaller ticket has
-// started" (MI355X_MICROARCH.md, inter-workgroup visibility).  Pairs are re-ordered through LDS so that the
-// global writes are contiguous runs per digit instead of 64 scattered 8-byte stores per wave instruction.
-constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_INCL = 2u << 30, OS_VALUE_MASK = (1u << 30) - 1;
-constexpr int OS_MAX_PASSES = 8;
-
-struct OsPlan {
-  int n;
-  int shift[OS_MAX_PASSES];
-  int rb[OS_MAX_PASSES];
-};
-
-__global__ void __launch_bounds__(256)
-onesweep_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, OsPlan plan, uint32_t* __restrict__ ghist) {
-  __shared__ uint32_t h[OS_MAX_PASSES * SORT_MAX_BINS];
-  const int total = plan.n * SORT_MAX_BINS;
-  for (int i = threadIdx.x; i < total; i += 256) h[i] = 0;
-  __syncthreads();
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-    const uint64_t k = keys[i];
-    for (int p = 0; p < plan.n; p++)
-      atomicAdd(&h[p * SORT_MAX_BINS + ((uint32_t)(k >> plan.shift[p]) & ((1u << plan.rb[p]) - 1))], 1u);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < total; i += 256)
-    if (h[i] != 0) atomicAdd(&ghist[i], h[i]);
-}
-
-// one block per pass: exclusive prefix over the (<= 512) bins, in place
-__global__ void __launch_bounds__(256) onesweep_prefix_kernel(uint32_t* __restrict__ ghist) {
-  __shared__ uint32_t lds[8];
-  uint32_t* g = ghist + (size_t)blockIdx.x * SORT_MAX_BINS;
-  const uint32_t a = g[2 * threadIdx.x], b = g[2 * threadIdx.x + 1];
-  uint32_t tot;
-  const uint32_t pre = block_excl_scan(a + b, &tot, lds);
-  g[2 * threadIdx.x] = pre;
-  g[2 * threadIdx.x + 1] = pre + a;
-}
-
-// LOOKBACK = false (default): same ranking + LDS re-ordering, but the tile's global digit bases come from the
-// tile-major histogram table (gbase) and the column-scanned chunk bases (status); ticket unused.
-template <bool LOOKBACK>
+// ---------------------------------------------------------------------------------------- scatter pass
+// Ranks its 4096 pairs (wave-ballot match per digit bit, per-wave running counts in LDS), takes the tile's global digit
+// bases from the tile-major histogram table (gbase: in-chunk exclusive counts) and the column-scanned chunk bases
+// (ctot, followed by the row of digit bases), and re-orders the pairs through LDS so that the global writes are
+// contiguous runs per digit instead of 64 scattered 8-byte stores per wave instruction.  (A decoupled-look-back
+// "onesweep" version of this kernel -- one read of the keys for the histograms of all passes, ticketed tiles, self-tagged
+// status words -- measured slower here: variants/NOTES.md.)
 __global__ void __launch_bounds__(SORT_THREADS)
-onesweep_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                        uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint64_t n, int shift, int rb,
-                        const uint32_t* __restrict__ gbase, uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
-                        uint32_t nblocks, const uint32_t* __restrict__ n_dev) {
-  if (!LOOKBACK && n_dev != nullptr) {
+sort_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint64_t n, int shift, int rb,
+                    const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ ctot, uint32_t nblocks,
+                    const uint32_t* __restrict__ n_dev) {
+  if (n_dev != nullptr) {
     n = min(n, (uint64_t)n_dev[0]);
     if ((uint64_t)blockIdx.x * SORT_TILE >= n) return;  // block-uniform, before any barrier
   }
@@ -938,15 +788,11 @@ onesweep_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __
   __shared__ uint32_t dstart[SORT_MAX_BINS];
   __shared__ uint32_t gb[SORT_MAX_BINS];
   __shared__ uint32_t s_scan[8];
-  __shared__ uint32_t s_tile;
   const uint32_t mask = (1u << rb) - 1;
   const int lane = dgs_lane(), w = threadIdx.x >> 6;
-  if (LOOKBACK) {
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-  }
   for (int i = lane; i < SORT_MAX_BINS; i += 64) whist[w][i] = 0;
   __syncthreads();
-  const uint32_t tile = LOOKBACK ? s_tile : blockIdx.x;
+  const uint32_t tile = blockIdx.x;
 
   const uint64_t tbase = (uint64_t)tile * SORT_TILE;
   const uint64_t wbase = tbase + (uint64_t)w * (64 * SORT_ITEMS);
@@ -1000,38 +846,13 @@ onesweep_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __
   dstart[2 * threadIdx.x] = pre2;
   dstart[2 * threadIdx.x + 1] = pre2 + cnt[0];
 
-  // publish the tile aggregate, look back, publish the inclusive prefix
+  // global position of tile-local slot i holding digit d:  gb[d] + i
 #pragma unroll
   for (int e = 0; e < 2; e++) {
     const int d = 2 * threadIdx.x + e;
-    uint32_t* mine = status + (size_t)tile * SORT_MAX_BINS + d;
-    uint32_t excl = 0;
-    if (!LOOKBACK) {
-      // gbase = tile-major table of in-chunk exclusive counts, status = chunk bases, followed by the row of digit bases
-      const uint32_t cap_chunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
-      gb[d] = gbase[(size_t)tile * SORT_MAX_BINS + d] + status[(size_t)(tile / CS_CHUNK) * SORT_MAX_BINS + d] +
-              status[(size_t)cap_chunks * SORT_MAX_BINS + d] - (e == 0 ? pre2 : pre2 + cnt[0]);
-      continue;
-    }
-    if (tile == 0) {
-      __hip_atomic_store(mine, OS_FLAG_INCL | cnt[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __hip_atomic_store(mine, OS_FLAG_AGG | cnt[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int64_t t = (int64_t)tile - 1; t >= 0; t--) {
-        const uint32_t* theirs = status + (size_t)t * SORT_MAX_BINS + d;
-        uint32_t s = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((s & ~OS_VALUE_MASK) == 0) {
-          __builtin_amdgcn_s_sleep(1);
-          s = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        excl += s & OS_VALUE_MASK;
-        if (s & OS_FLAG_INCL) break;
-      }
-      __hip_atomic_store(mine, OS_FLAG_INCL | ((excl + cnt[e]) & OS_VALUE_MASK), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // global position of tile-local slot i holding digit d:  gb[d] + i
-    gb[d] = gbase[d] + excl - (e == 0 ? pre2 : pre2 + cnt[0]);
+    const uint32_t cap_chunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
+    gb[d] = gbase[(size_t)tile * SORT_MAX_BINS + d] + ctot[(size_t)(tile / CS_CHUNK) * SORT_MAX_BINS + d] +
+            ctot[(size_t)cap_chunks * SORT_MAX_BINS + d] - (e == 0 ? pre2 : pre2 + cnt[0]);
   }
   __syncthreads();
 
@@ -1394,17 +1215,9 @@ int dgs_sort_num_passes(int begin_bit, int end_bit) { return plan_passes(begin_b
 
 size_t dgs_sort_tmp_words(uint64_t n) {
   const uint64_t nblocks = (n + SORT_TILE - 1) / SORT_TILE;
-  const uint64_t table = nblocks * SORT_MAX_BINS;  // classic: histogram table; onesweep: look-back status words
   const uint64_t chunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
-  return (size_t)(table + dgs_scan_tmp_words(table) + OS_MAX_PASSES * SORT_MAX_BINS + (chunks + 1) * SORT_MAX_BINS + 256);
+  return (size_t)(nblocks * SORT_MAX_BINS + (chunks + 1) * SORT_MAX_BINS + 256);   // histogram rows, chunk bases + digit bases
 }
-
-// DGS_SORT_MODE = 0 classic | 1 reorder (default) | 2 onesweep: compile-time A/B switch for the sort benchmark
-// (tools/build_flag_variant.sh <name> -DDGS_SORT_MODE=2); the library reads no environment variable
-#ifndef DGS_SORT_MODE
-#define DGS_SORT_MODE 1
-#endif
-static constexpr int sort_mode() { return DGS_SORT_MODE; }
 
 // n_dev (optional): device word holding the actual pair count (<= n); every launch is then sized by the capacity n and
 // the kernels read the count themselves (no host read of num_rendered between duplication and sort)
@@ -1414,78 +1227,22 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
   const PassPlan plan = plan_passes(begin_bit, end_bit);
   *result_in_alt = plan.n & 1;
   if (n == 0) return hipSuccess;
-  if (n_dev != nullptr && sort_mode() != 1) return hipErrorInvalidValue;  // device-side counts: default path only
-  if (vals == nullptr && sort_mode() == 0) return hipErrorInvalidValue;   // keys-only: not in the classic A/B variant
   const uint32_t nblocks = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
-  if (sort_mode() == 2 && n < (1ull << 30) && plan.n <= OS_MAX_PASSES) {
-    // tmp layout: [status: nblocks*512][ghist: passes*512][tickets: passes]
-    uint32_t* status = tmp;
-    uint32_t* ghist = tmp + (uint64_t)nblocks * SORT_MAX_BINS;
-    uint32_t* tickets = ghist + OS_MAX_PASSES * SORT_MAX_BINS;
-    OsPlan op;
-    op.n = plan.n;
-    for (int i = 0; i < plan.n; i++) {
-      op.shift[i] = plan.shift[i];
-      op.rb[i] = plan.rb[i];
-    }
-    hipError_t e = hipMemsetAsync(ghist, 0, (size_t)(OS_MAX_PASSES * SORT_MAX_BINS + OS_MAX_PASSES) * 4, s);
-    if (e != hipSuccess) return e;
-    const uint32_t hb = nblocks < 2048u ? nblocks : 2048u;
-    hipLaunchKernelGGL(onesweep_hist_kernel, dim3(hb), dim3(256), 0, s, keys, n, op, ghist);
-    hipLaunchKernelGGL(onesweep_prefix_kernel, dim3(plan.n), dim3(256), 0, s, ghist);
-    uint64_t* kin = keys;
-    uint32_t* vin = vals;
-    uint64_t* kout = keys_alt;
-    uint32_t* vout = vals_alt;
-    for (int p = 0; p < plan.n; p++) {
-      e = hipMemsetAsync(status, 0, (size_t)nblocks * SORT_MAX_BINS * 4, s);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(onesweep_scatter_kernel<true>, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout,
-                         n, plan.shift[p], plan.rb[p], ghist + (size_t)p * SORT_MAX_BINS, status, tickets + p, nblocks,
-                         (const uint32_t*)nullptr);
-      uint64_t* tk = kin;
-      kin = kout;
-      kout = tk;
-      uint32_t* tv = vin;
-      vin = vout;
-      vout = tv;
-    }
-    return hipGetLastError();
-  }
   uint32_t* table = tmp;
-  uint32_t* scan_tmp = tmp + (uint64_t)nblocks * SORT_MAX_BINS;
+  uint32_t* ctot = tmp + (uint64_t)nblocks * SORT_MAX_BINS;  // [nchunks + 1][512]
+  const uint32_t nchunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
   uint64_t* kin = keys;
   uint32_t* vin = vals;
   uint64_t* kout = keys_alt;
   uint32_t* vout = vals_alt;
-  if (sort_mode() == 1) {
-    const uint32_t nchunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
-    uint32_t* ctot = scan_tmp;  // [nchunks][512]
-    for (int p = 0; p < plan.n; p++) {
-      hipLaunchKernelGGL(sort_hist_rows_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, n_dev, plan.shift[p],
-                         plan.rb[p], table);
-      hipLaunchKernelGGL(colscan_chunk_kernel, dim3(nchunks), dim3(256), 0, s, table, nblocks, n_dev, ctot);
-      hipLaunchKernelGGL(colscan_top_kernel, dim3(1), dim3(256), 0, s, ctot, nchunks, n_dev,
-                         ctot + (size_t)nchunks * SORT_MAX_BINS);
-      hipLaunchKernelGGL(onesweep_scatter_kernel<false>, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout,
-                         n, plan.shift[p], plan.rb[p], table, ctot, nullptr, nblocks, n_dev);
-      uint64_t* tk = kin;
-      kin = kout;
-      kout = tk;
-      uint32_t* tv = vin;
-      vin = vout;
-      vout = tv;
-    }
-    return hipGetLastError();
-  }
   for (int p = 0; p < plan.n; p++) {
-    const uint64_t tn = (uint64_t)nblocks << plan.rb[p];
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, plan.shift[p], plan.rb[p],
-                       nblocks, table);
-    hipError_t e = dgs_launch_scan(table, table, tn, scan_tmp, nullptr, s);
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sort_hist_rows_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, n, n_dev, plan.shift[p],
+                       plan.rb[p], table);
+    hipLaunchKernelGGL(colscan_chunk_kernel, dim3(nchunks), dim3(256), 0, s, table, nblocks, n_dev, ctot);
+    hipLaunchKernelGGL(colscan_top_kernel, dim3(1), dim3(256), 0, s, ctot, nchunks, n_dev,
+                       ctot + (size_t)nchunks * SORT_MAX_BINS);
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout, n,
-                         plan.shift[p], plan.rb[p], nblocks, table);
+                       plan.shift[p], plan.rb[p], table, ctot, nblocks, n_dev);
     uint64_t* tk = kin;
     kin = kout;
     kout = tk;
@@ -1538,16 +1295,8 @@ hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const
 hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s, const uint32_t* n_dev,
                              int tile_shift) {
   const uint32_t ntiles = (uint32_t)v.K * (uint32_t)v.T;
-#if DGS_RANGES_SWEEP   // the reference's formulation: one thread per sorted key, boundaries stamped into a zero-filled array
-  hipError_t e = hipMemsetAsync(c.ranges, 0, (size_t)ntiles * sizeof(uint2), s);
-  if (e != hipSuccess) return e;
-  if (R > 0)
-    hipLaunchKernelGGL(ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, n_dev, c.keys_sorted, c.ranges,
-                       tile_shift);
-#else
   hipLaunchKernelGGL(ranges_search_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, s, R, n_dev, c.keys_sorted, c.ranges,
                      tile_shift, ntiles);
-#endif
   return hipGetLastError();
 }
 

@@ -16,11 +16,8 @@
 //     written as per-block partials that a second kernel sums in block order: deterministic as well.
 #include "dgs_common.h"
 
-// 1 (default): the 21 per-subframe pose terms of a wave are summed through LDS; 0: with DPP butterflies (round 2).
-// Same box, metric config: 0.61 against 0.69 ms per launch.
-#ifndef DGS_GEOM_LDS_POSE_SUMS
-#define DGS_GEOM_LDS_POSE_SUMS 1
-#endif
+// (the 21 per-subframe pose terms of a wave are summed through LDS; with DPP butterflies, round 2, the launch took 0.69
+// instead of 0.61 ms: variants/NOTES.md)
 
 namespace {
 
@@ -138,9 +135,7 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
                     const int32_t* __restrict__ radii, float* __restrict__ st_max_radii, float* __restrict__ st_accum,
                     float* __restrict__ st_denom, float st_inc) {
   extern __shared__ __attribute__((aligned(16))) float s_part[];  // [waves][K][NMAT]
-#if DGS_GEOM_LDS_POSE_SUMS
   __shared__ __attribute__((aligned(16))) float s_m[GB_THREADS / 64][21][68];  // one subframe's 21 pose terms of every lane
-#endif
   if (status[5] != 0u) return;  // capacity mode, truncated lists (see contrib_reduce_kernel); the caller discards the step
   // Gaussians [g_begin, g_end) (g_begin a multiple of the block size): a caller may run the per-Gaussian half in index
   // chunks so that the all-reduce of one chunk's gradients overlaps the next chunk's kernel (dgs_backward_geometry)
@@ -455,7 +450,6 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
       st_dn += st_inc;
     }
     // ---- per-subframe pose gradients: wave sum (skipped when no lane of the wave is visible in k)
-#if DGS_GEOM_LDS_POSE_SUMS
     // through LDS, like the compositing backward's per-entry reduction: 21 conflict-free 4-byte stores per lane, then
     // lane (row, quarter) adds 16 values of one sum and a quad sum finishes -- 34 VALU adds instead of 21 six-step DPP
     // butterflies (126 DPP adds, the most expensive plain class)
@@ -487,17 +481,6 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
         sp[lane] = 0.0f;
       }
     }
-#else
-    if (__ballot(ntiles > 0) != 0ull) {
-#pragma unroll
-      for (int i = 0; i < 21; i++) mat[i] = dgs_wave_sum63(mat[i]);
-    }
-    if (lane == 63) {
-      float* sp = s_part + ((size_t)w * v.K + k) * NMAT;
-#pragma unroll
-      for (int i = 0; i < 21; i++) sp[i] = mat[i];
-    }
-#endif
   }
 
   if (valid && stats) {

@@ -1,43 +1,57 @@
 // Micro-benchmark: what one SIMD of this chip sustains, in wave64 instructions per CORE CLOCK CYCLE, for each
-// instruction class the compositing kernels are made of -- plain fp32 FMA, packed FMA, the two transcendentals, compare +
-// select, DPP adds, v_permlane32_swap / v_permlane16_swap, v_mov, broadcast ds_read_b128 -- at 1..8 waves per SIMD.
-// Cycles are MEASURED (s_memtime deltas around the instruction stream of every wave, the longest wave of the launch
-// counts), not derived from a nominal clock: the issue-slot cost of a class is cycles / instructions, and the
-// "issue-slot-weighted" VALU roofline of a kernel is  sum_class(count_class * cost_class) / (SIMDs * kernel cycles)
-// (profiles/make_valu.py combines this table with the ISA census and the PMC instruction counts).
+// instruction class the compositing kernels are made of, at W = 1..8 waves per SIMD.
 //
-//   hipcc --offload-arch=gfx950 -O2 -o tools/valu_rate tools/valu_rate.hip && tools/valu_rate > profiles/valu_classes_r03.txt
+// Round 4: round 3 took the LONGEST wave of a launch whose blocks were not guaranteed to spread
+// evenly over the CUs, and got "costs" the real kernels then beat (busy fractions above 1).  Now
+//   * occupancy is FORCED: a block is 4 waves (one per SIMD) and allocates 160 KB / W of LDS, so exactly W blocks fit a
+//     CU; the grid is CUs x W x ROUNDS blocks, so every CU stays full for several rounds whatever the dispatch order;
+//   * the rate comes from the SUM of all waves' s_memtime deltas: W waves share a SIMD for their whole life, so
+//     instr / cycle / SIMD = W x (instructions per wave) / (mean wave cycles);
+//   * every class is its own kernel symbol (valu_rate_k<CLASS>), so the same binary under
+//         rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES -- tools/valu_rate 8
+//     gives the counter-side figure  SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)  per class
+//     (profiles/make_valu_peak.py puts the two side by side).
+//   * operand forms are separated: v_fma_f32 with three distinct VGPR sources, v_fmac_f32 (two sources + the
+//     accumulator), v_mul_f32 / v_add_f32 (two sources), because the register-file read ports, not the ALU, set the rate.
+//
+//   hipcc --offload-arch=gfx950 -O2 -o tools/valu_rate tools/valu_rate.hip && tools/valu_rate > profiles/valu_classes_r04.txt
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
-enum Cls { FMA = 0, PKFMA, EXP, RCP, CMPSEL, DPPADD, PERM32, PERM16, MOV, DSREAD, NCLS };
-static const char* NAMES[NCLS] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_cmp+v_cndmask (2 instr)",
-                                  "v_add_f32_dpp", "v_permlane32_swap", "v_permlane16_swap", "v_mov_b32",
-                                  "ds_read_b128 (broadcast)"};
+enum Cls { FMA3 = 0, FMAC, MUL2, ADD2, PKFMA, EXP, RCP, CMPSEL, DPPADD, MOV, READLANE, MADU64, NCLS };
+static const char* NAMES[NCLS] = {"v_fma_f32 (3 VGPR sources)", "v_fmac_f32 (2 sources + acc)", "v_mul_f32 (2 sources)",
+                                  "v_add_f32 (2 sources)", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32",
+                                  "v_cmp+v_cndmask (2 instr)", "v_add_f32_dpp", "v_mov_b32", "v_readlane_b32",
+                                  "v_mad_u64_u32"};
 constexpr int UNROLL = 8;   // independent chains per loop iteration
+constexpr int ITERS = 4000;
 
 template <int C>
-__global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, int iters, float a, float b) {
-  __shared__ float4 lds[64];
-  if (threadIdx.x < 64) lds[threadIdx.x] = make_float4(a, b, a, b);
-  __syncthreads();
-  float x[UNROLL];
-  float y[UNROLL];
+__global__ void __launch_bounds__(256) valu_rate_k(float* out, unsigned long long* acc, float a, float b) {
+  extern __shared__ float dyn[];   // occupancy limiter only
+  float x[UNROLL], y[UNROLL];
   for (int i = 0; i < UNROLL; i++) {
     x[i] = threadIdx.x * 0.001f + i;
     y[i] = x[i] + 1.0f;
   }
+  float c0 = a * 1.5f, c1 = b * 0.25f;
+  asm volatile("" : "+v"(c0), "+v"(c1));
+  unsigned long long sink = 0;
   const unsigned long long t0 = __builtin_readcyclecounter();
-  for (int it = 0; it < iters; it++) {
+  for (int it = 0; it < ITERS; it++) {
 #pragma unroll
     for (int i = 0; i < UNROLL; i++) {
-      if (C == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+      if (C == FMA3) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(c0), "v"(c1));
+      if (C == FMAC) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[i]) : "v"(c0), "v"(c1));
+      if (C == MUL2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(c0));
+      if (C == ADD2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(c1));
       if (C == PKFMA) {
         typedef float v2f __attribute__((ext_vector_type(2)));
         v2f p = {x[i], y[i]};
-        const v2f aa = {a, a}, bb = {b, b};
+        const v2f aa = {c0, c0}, bb = {c1, c1};
         asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p) : "v"(aa), "v"(bb));
         x[i] = p.x;
         y[i] = p.y;
@@ -45,66 +59,78 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, in
       if (C == EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
       if (C == RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]));
       if (C == CMPSEL)
-        asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %2, %0, vcc" : "+v"(x[i]) : "v"(a), "v"(b) : "vcc");
+        asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %2, %0, vcc" : "+v"(x[i]) : "v"(c0), "v"(c1) : "vcc");
       if (C == DPPADD)
         asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x[i]) : "v"(y[i]));
-      if (C == PERM32) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x[i]), "+v"(y[i]));
-      if (C == PERM16) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(x[i]), "+v"(y[i]));
       if (C == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(x[i]) : "v"(y[i]));
-      if (C == DSREAD) {
-        float4 q;
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(q) : "v"((unsigned)((i & 7) * 16)));
-        x[i] += q.x;
+      if (C == READLANE) {
+        int s;
+        asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s) : "v"(x[i]));
+        sink += (unsigned)s;
+      }
+      if (C == MADU64) {
+        unsigned long long r;
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "=v"(r) : "v"(__float_as_uint(x[i])), "v"(48u) : "vcc");
+        sink += r;
       }
     }
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
-  float s = 0;
+  float s = (float)sink;
   for (int i = 0; i < UNROLL; i++) s += x[i] + y[i];
-  out[blockIdx.x * 256 + threadIdx.x] = s;
-  if ((threadIdx.x & 63) == 0) atomicMax(cyc, t1 - t0);
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = s + dyn[threadIdx.x & 7] * 0.0f;
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&acc[0], t1 - t0);
+    atomicAdd(&acc[1], 1ull);
+  }
 }
 
 template <int C>
-void run(float* out, unsigned long long* cyc, int waves_per_simd, int n_cu) {
-  const int iters = 4000, grid = n_cu * waves_per_simd;   // 256 threads = 4 waves = one per SIMD of a CU
+void run(float* out, unsigned long long* acc, int W, int n_cu) {
+  const int rounds = 4, grid = n_cu * W * rounds;
+  // exactly W blocks per CU: 160 KB of LDS per CU, a little slack for the allocation granule
+  const size_t lds = (size_t)(160 * 1024) / W - (W > 1 ? 1024 : 2048);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(valu_rate_k<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   double best = 1e30;
   for (int rep = 0; rep < 3; rep++) {
-    hipMemset(cyc, 0, 8);
-    hipLaunchKernelGGL(k<C>, dim3(grid), dim3(256), 0, 0, out, cyc, iters, 1.0001f, 0.5f);
+    hipMemset(acc, 0, 16);
+    hipLaunchKernelGGL(valu_rate_k<C>, dim3(grid), dim3(256), lds, 0, out, acc, 1.0001f, 0.5f);
     hipDeviceSynchronize();
-    unsigned long long c = 0;
-    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-    if ((double)c < best) best = (double)c;
+    unsigned long long h[2] = {0, 0};
+    hipMemcpy(h, acc, 16, hipMemcpyDeviceToHost);
+    const double mean = (double)h[0] / (double)(h[1] ? h[1] : 1);
+    if (mean < best) best = mean;
   }
-  const double per_wave = (double)iters * UNROLL * (C == CMPSEL ? 2 : 1);
-  // one SIMD executed waves_per_simd waves' streams within `best` cycles (all blocks resident at once: grid = CUs x
-  // waves per SIMD, 4 waves per block)
-  printf("%-28s waves/SIMD %d  cycles/instr %.2f  instr/cycle/SIMD %.3f\n", NAMES[C], waves_per_simd,
-         best / (per_wave * waves_per_simd), per_wave * waves_per_simd / best);
+  const double per_wave = (double)ITERS * UNROLL * (C == CMPSEL ? 2 : 1);
+  printf("%-30s waves/SIMD %d  cycles/instr %.2f  instr/cycle/SIMD %.3f  (kernel valu_rate_k<%d>)\n", NAMES[C], W,
+         best / (per_wave * W), per_wave * W / best, C);
 }
 
-int main() {
+int main(int argc, char** argv) {
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
   const int n_cu = prop.multiProcessorCount;
   float* out;
-  unsigned long long* cyc;
-  hipMalloc(&out, (size_t)256 * n_cu * 8 * 4);
-  hipMalloc(&cyc, 8);
-  printf("# %s, %d CUs; cycles = s_memtime deltas (core clock as the shader sees it), longest wave of the launch\n",
-         prop.gcnArchName, n_cu);
-  for (int w = 1; w <= 8; w *= 2) {
-    run<FMA>(out, cyc, w, n_cu);
-    run<PKFMA>(out, cyc, w, n_cu);
-    run<EXP>(out, cyc, w, n_cu);
-    run<RCP>(out, cyc, w, n_cu);
-    run<CMPSEL>(out, cyc, w, n_cu);
-    run<DPPADD>(out, cyc, w, n_cu);
-    run<PERM32>(out, cyc, w, n_cu);
-    run<PERM16>(out, cyc, w, n_cu);
-    run<MOV>(out, cyc, w, n_cu);
-    run<DSREAD>(out, cyc, w, n_cu);
+  unsigned long long* acc;
+  hipMalloc(&out, (size_t)256 * n_cu * 8 * 4 * 4);
+  hipMalloc(&acc, 16);
+  const int only = argc > 1 ? atoi(argv[1]) : 0;
+  printf("# %s, %d CUs; cycles = s_memtime deltas, MEAN over all waves of a launch that keeps every CU at exactly W blocks "
+         "(4 waves each) for 4 rounds\n", prop.gcnArchName, n_cu);
+  for (int W = 1; W <= 8; W *= 2) {
+    if (only && W != only) continue;
+    run<FMA3>(out, acc, W, n_cu);
+    run<FMAC>(out, acc, W, n_cu);
+    run<MUL2>(out, acc, W, n_cu);
+    run<ADD2>(out, acc, W, n_cu);
+    run<PKFMA>(out, acc, W, n_cu);
+    run<EXP>(out, acc, W, n_cu);
+    run<RCP>(out, acc, W, n_cu);
+    run<CMPSEL>(out, acc, W, n_cu);
+    run<DPPADD>(out, acc, W, n_cu);
+    run<MOV>(out, acc, W, n_cu);
+    run<READLANE>(out, acc, W, n_cu);
+    run<MADU64>(out, acc, W, n_cu);
   }
   return 0;
 }
