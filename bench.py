@@ -359,7 +359,9 @@ def run_rank(args):
                              shard=(rank, world) if subframes_mode else None)
         Pv_tot = int((probe["radii_all"] > 0).sum().item())
         del probe
-    replaying = world == 1 and loop.graph and loop._fused is not None and not args.autograd_path and not args.no_graph
+    # (N ranks, "views": the step up to its first collective is replayed -- FusedStep.replay_front; "subframes": eager)
+    replaying = ((world == 1 or not subframes_mode) and loop.graph and loop._fused is not None and
+                 not args.autograd_path and not args.no_graph)
     dt = timed(args.steps, profile=not replaying)
     allreduce_ms = None
     if ar_events:
@@ -475,8 +477,9 @@ def run_rank(args):
                          "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["avg_ms"],
                          "avg_launch_ms_source": "HIP events on the launch stream inside this run (dgs_profile_*)" +
                                                  (", recorded in the eager region that follows the replayed one" if graph_info else ""),
-                         "note": "compositing is VALU/LDS-bound, not HBM-bound (SURVEY 8d); frac is the honest HBM "
-                                 "fraction of the byte model"},
+                         "note": "the dominant kernel (compositing) is bound by VALU issue, not by HBM (SURVEY 8d): `frac` is "
+                                 "the honest HBM fraction of its byte model, `valu` (when the round's PMC profile of this "
+                                 "config is committed) the fraction of the VALU issue peak it reaches"},
             "pipeline_hbm": {"alg_bytes_per_step": int(total_bytes),
                              "achieved_GBps": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                              "frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
@@ -486,7 +489,7 @@ def run_rank(args):
             result["value_reference_lists"] = ref_lists
         # PMC counters cannot be collected inside this run (rocprofv3 wraps the process): traffic / VALU figures are the
         # committed measurements of the same command, with their provenance, or null
-        for fname, key in (("traffic_r03.json", "traffic"), ("valu_r03.json", "valu")):
+        for fname, key in (("traffic_r04.json", "traffic"), ("valu_r04.json", "valu")):
             path = os.path.join(ROOT, "profiles", fname)
             if not os.path.exists(path) or world != 1:
                 continue
@@ -500,9 +503,17 @@ def run_rank(args):
                 if key == "valu":
                     hit = [v_ for k_, v_ in doc.items() if k_.startswith(dom + "_kernel")]
                     if hit:
-                        result["roofline"]["valu"] = dict(hit[0], frac=hit[0].get("weighted_busy_frac"),
-                                                          class_cost_cycles=doc.get("_class_cost_cycles"),
-                                                          source=f"profiles/{fname}: {doc.get('_source', '')}")
+                        h = hit[0]
+                        # the bound that actually limits the dominant kernel: VALU issue.  frac = measured wave64 VALU
+                        # instructions per cycle and SIMD / 0.5 (one fp32 instruction per 2 cycles on a SIMD-32);
+                        # issue_weighted_frac prices every instruction class at its own PMC-measured issue cost (<= 1)
+                        result["roofline"]["valu"] = {
+                            "bound": "valu", "achieved": h.get("ipc_per_simd"), "peak": 0.5,
+                            "unit": "wave64 VALU instructions / cycle / SIMD", "frac": h.get("frac_of_peak_issue"),
+                            "issue_weighted_frac": h.get("issue_weighted_frac"), "lds_busy_frac": h.get("lds_busy_frac"),
+                            "valu_insts_per_launch": h.get("valu_insts"), "cycles_per_launch": h.get("cycles_per_xcd"),
+                            "passes_per_entry": h.get("passes_per_entry"),
+                            "source": f"profiles/{fname}: {doc.get('_source', '')}"}
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

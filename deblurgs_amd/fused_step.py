@@ -69,6 +69,7 @@ class FusedStep:
         self._drops_dev = None      # device word: captured forwards that overflowed so far (DgsForwardOut.drop_counter)
         self._drops_seen = 0        # ... and how many of them _poll has turned into retries
         self._bucket = None         # (generation, numel, tensor): the gradient bucket all captured steps write to
+        self._front_shared = None   # (key, radii, screen gradients, skip word) of the captured sharded fronts
         self._graphs = {}           # captured steps by what they bake in (replay)
         self._pool = None           # one memory pool for all of them: replays never overlap
         self._release_pool = False  # a dropped pool's blocks go back to the driver before the next capture
@@ -130,6 +131,7 @@ class FusedStep:
             self._graphs = {}
             self._pool = None
             self._bucket = None
+            self._front_shared = None
             self._release_pool = True
 
     def _host_words(self):
@@ -185,7 +187,7 @@ class FusedStep:
         return {"losses": torch.stack([l1.reshape(()), sm.reshape(())]).float(), "blur": None,
                 "radii": torch.zeros((0, P), dtype=torch.int32, device=dev), "viewspace_grad": torch.zeros((0, P, 3), **f32),
                 "K": K_total, "subframes": color, "depths": torch.zeros((0, 1, H, W), **f32), "skip_flag_ptr": None,
-                "depth_tv": depth_tv}
+                "skip_flag": None, "depth_tv": depth_tv}
 
     def _linspace_sel(self, f, n, dev):
         key = (f, n, str(dev))
@@ -272,6 +274,117 @@ class FusedStep:
         self.last_capacity = cap
         self.replayed += 1
         return ent["result"]
+
+    def replay_front(self, cam_idx, lambda_t, gt, subframe_indice, ar, background=None, uniform=None):
+        """A SHARDED step ("views" mode) with everything up to its first collective replayed as one hipGraph: alignment ->
+        cameras -> dgs_forward (capacity sized ahead) -> loss -> the compositing half of the backward
+        (dgs_backward_composite; the whole dgs_backward when the bucket is reduced in one piece) -- then, eagerly, what
+        run() does after that point: the per-Gaussian half in Gaussian-index chunks with each chunk's all-reduce behind it
+        on the side stream, the camera gradients.  The caller's reductions of the skip flag and the trajectory gradients and
+        its optimiser step follow as after run().  Bit-identical to the eager step (the same launches in the same order on
+        the same stream); what it saves is the ~20 ctypes calls and driver round trips of the front, 0.2-0.3 ms per step.
+
+        Returns run()'s result dict ('subframes', 'blur' and 'depths' are None: the images live in the graph's pool), or
+        None when the step cannot be replayed yet (no duplicate count learnt for the view)."""
+        cloud, m = self.cloud, self.motion
+        dev = cloud._xyz.device
+        f = m.n_subframes
+        self._poll()
+        K_total = f if (isinstance(subframe_indice, str) and subframe_indice == "all") else (
+            int(subframe_indice) if isinstance(subframe_indice, int) else len(subframe_indice))
+        ckey = (int(cam_idx), K_total, 0)
+        cap = self._capacity(ckey) if self.speculative else None
+        if cap is None or isinstance(subframe_indice, (list, tuple)) or torch.is_tensor(subframe_indice):
+            return None
+        q = 1 << max(cap.bit_length() - 5, 10)
+        cap = -(-cap // q) * q
+        hot = list(cloud.hot_parameters())
+        cull = dgr.TILE_CULL if self.tile_cull is None else bool(self.tile_cull)
+        chunks = 1 if ar is None else int(ar.get("chunks", 1))
+        gkey = ("front", int(cam_idx), subframe_indice, int(cloud.active_sh_degree), bool(m.is_optimizing()),
+                bool(m.curve_random_sample), cap, self._generation, gt.data_ptr(), bool(cull), bool(dgr.WIDE_RECORDS),
+                tuple(p.data_ptr() for p in hot), chunks, float(self.lambda_hinge))
+        ent = self._graphs.get(gkey)
+        if ent is None:
+            ent = self._capture_front(gkey, cam_idx, gt, subframe_indice, cap, ar, K_total)
+        slot = self._ring[self._ring_pos % len(self._ring)] if self._ring else None
+        if slot is None or slot[0].numel() != ent["hyper"].numel():
+            self._ring = [(torch.zeros(ent["hyper"].numel(), dtype=torch.float32).pin_memory(), torch.cuda.Event())
+                          for _ in range(8)]
+            self._ring_pos = 0
+            slot = self._ring[0]
+        self._ring_pos += 1
+        hbuf, hev = slot
+        hev.synchronize()
+        hv = hbuf.numpy()
+        hv[0] = float(lambda_t)
+        hv[1:4] = (torch.rand(3) if background is None else background.detach().float().cpu()).numpy()
+        if m.curve_random_sample and f > 2:
+            hv[48:48 + f - 2] = (torch.rand(f - 2) if uniform is None else uniform.detach().float().cpu()).numpy()
+        ent["hyper"].copy_(hbuf, non_blocking=True)
+        hev.record(torch.cuda.current_stream(dev))
+        ent["graph"].replay()
+        pnd = _Pending()
+        pnd.host, pnd.speculative, pnd.key, pnd.generation = ent["host"], True, ckey, self._generation
+        pnd.request, pnd.capacity = (cam_idx, subframe_indice), cap
+        pnd.event = torch.cuda.Event()
+        pnd.event.record(torch.cuda.current_stream(dev))
+        pnd.shared_host = True
+        self._pending.append(pnd)
+        self.last_capacity = cap
+        self.replayed += 1
+        return ent["finish"]()
+
+    def _capture_front(self, gkey, cam_idx, gt, subframe_indice, cap, ar, K_total):
+        cloud, m = self.cloud, self.motion
+        dev = cloud._xyz.device
+        f = m.n_subframes
+        if len(self._graphs) >= self.max_graphs:
+            self._graphs.pop(next(iter(self._graphs)))
+        hyper = torch.zeros(self._hyper_words(f), dtype=torch.float32, device=dev)
+        host = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self._drop_counter(dev)
+        if self._release_pool:
+            self._release_pool = False
+            self._keep = None
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        ent = {"hyper": hyper, "host": host}
+        # What the eager part and the caller read after a replay lives OUTSIDE the capture pool, shared by all graphs of a
+        # cloud generation (steps never overlap): the gradient bucket, the loss values, the skip word, and -- sharded runs
+        # update the densification statistics in a launch of their own -- the radii and the screen-space gradients.
+        Mr_, P_ = cloud._features_rest.shape[1], cloud._xyz.shape[0]
+        n_bucket = sum((n + 3) // 4 * 4 for n in (3 * P_, 3 * P_, 3 * Mr_ * P_, P_, 3 * P_, 4 * P_))
+        if self._bucket is None or self._bucket[0] != self._generation or self._bucket[1] != n_bucket:
+            self._bucket = (self._generation, n_bucket, torch.empty(n_bucket, dtype=torch.float32, device=dev))
+        skey = (self._generation, K_total, P_)
+        if self._front_shared is None or self._front_shared[0] != skey:
+            self._front_shared = (skey, torch.empty((K_total, P_), dtype=torch.int32, device=dev),
+                                  torch.empty((K_total, P_, 3), dtype=torch.float32, device=dev),
+                                  torch.zeros(1, dtype=torch.int32, device=dev))
+        ent["work"] = torch.zeros(8, dtype=torch.float32, device=dev)
+        cap_args = {"capacity": cap, "host": host, "lambda_ptr": hyper.data_ptr(), "work": ent["work"],
+                    "bucket": self._bucket[2], "split": True, "radii": self._front_shared[1],
+                    "means2D": self._front_shared[2], "skipw": self._front_shared[3], "tail": None}
+        bg = hyper[1:4]
+        uniform = hyper[48:48 + f - 2] if (m.curve_random_sample and f > 2) else None
+        for p in list(cloud.hot_parameters()) + (list(m.parameters()) if m.is_optimizing() else []):
+            p.grad = None
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
+            front = self.run(cam_idx, 0.0, gt, bg, subframe_indice, uniform=uniform, _cap=cap_args, ar=ar)
+        # the step's large buffers go back to the pool (the other views' captures re-use the blocks); finish() reaches them
+        # through the raw pointers of its DgsProblem / DgsBackwardIO -- valid until the next replay of ANY graph of the pool,
+        # which is enqueued after this step's eager part on the same stream
+        front["big"][0] = None
+        ent["graph"], ent["finish"], ent["keep"] = graph, front["finish"], front["_keep"]
+        self._keep = None
+        self._graphs[gkey] = ent
+        self.captured += 1
+        return ent
 
     def _capture(self, gkey, cam_idx, gt, subframe_indice, cap, optimizer, tail, stats=None):
         cloud, m = self.cloud, self.motion
@@ -420,7 +533,8 @@ class FusedStep:
         # the depth images are rendered only if somebody reads them (the reference always renders them, and its default
         # loss, lambda_depth_tv = 0, never looks at them: train.py:150-153)
         depth = torch.empty((K, 1, H, W), **f32) if (need_depth or lambda_depth_tv > 0.0) else None
-        radii = torch.empty((K, P), dtype=torch.int32, device=dev)
+        radii = (torch.empty((K, P), dtype=torch.int32, device=dev) if (_cap is None or "radii" not in _cap)
+                 else _cap["radii"])
         geom = torch.empty(L.dgs_geom_state_bytes(P, K), dtype=torch.uint8, device=dev)
         image = torch.empty(L.dgs_image_state_bytes(W, H, K), dtype=torch.uint8, device=dev)
         bg = background.to(dev, torch.float32).contiguous()
@@ -506,7 +620,8 @@ class FusedStep:
         g_xyz, g_dc, g_op, g_sc, g_rot = (seg(0, (P, 3)), seg(1, cloud._features_dc.shape), seg(3, cloud._opacity.shape),
                                           seg(4, (P, 3)), seg(5, (P, 4)))
         g_rest = seg(2, cloud._features_rest.shape)
-        g_means2D = None if stats is not None else torch.empty((K, P, 3), **f32)
+        g_means2D = None if stats is not None else (torch.empty((K, P, 3), **f32) if (_cap is None or "means2D" not in _cap)
+                                                    else _cap["means2D"])
         g_colors = torch.empty((P, 3), **f32)
         g_cov3D = torch.empty((P, 6), **f32)
         g_view, g_proj = torch.empty((K, 4, 4), **f32), torch.empty((K, 4, 4), **f32)
@@ -538,73 +653,104 @@ class FusedStep:
         if stats is not None:
             io.stats_max_radii2D, io.stats_grad_accum, io.stats_denom = (_ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]))
             io.stats_K_total = int(K_total)
-        if ar is None or int(ar.get("chunks", 1)) <= 1 or P < 512:
+        # ---- the launches up to the first collective ...
+        chunked = not (ar is None or int(ar.get("chunks", 1)) <= 1 or P < 512)
+        if chunked:
+            _lib.check(L.dgs_backward_composite(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_composite")
+        else:
             _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward")
-            if ar is not None and P > 0:
+        split = _cap is not None and bool(_cap.get("split"))
+        # the step's large buffers, held through a one-element list: a captured front (replay_front) empties it after the
+        # capture so that they go back to the graph pool, and finish() below touches them through prob / io only
+        big = [(geom, image, binning, scratch, color, depth, dsub, blur, g_colors, g_cov3D)]
+        skip_flag = None
+        if skip_ptr is not None:
+            off = skip_ptr - geom.data_ptr()
+            skip_flag = geom[off:off + 4].view(torch.int32)
+            if split:          # a word of its own, outside the pool (the view above would pin the whole geometry blob)
+                _cap["skipw"].copy_(skip_flag)
+                skip_flag = _cap["skipw"]
+
+        # ---- ... and everything after it (a sharded run's reduction of the bucket, overlapped with the per-Gaussian half
+        # of the backward when `chunked`; then the camera gradients).  Eager steps run it right away; a captured front
+        # (replay_front) replays the launches above as one hipGraph and calls this after every replay.
+        def finish():
+            # (the stream of THIS call: a captured front was recorded on torch's capture stream, its eager part runs on the
+            # caller's stream, behind the replay)
+            stream_obj = torch.cuda.current_stream(dev)
+            stream = ctypes.c_void_p(stream_obj.cuda_stream)
+            if chunked:
+                from . import sharding
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                side = self._side
+                flat.record_stream(side)
+                widths = [3, 3, 3 * Mr, 1, 3, 4]
+                t_ar = None
+                if self.time_allreduce:  # (bench.py: span of the side stream's reductions, first chunk ready -> last done)
+                    t_ar = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                for ci, (b0, b1) in enumerate(sharding.chunk_bounds(P, int(ar["chunks"]))):
+                    _lib.check(L.dgs_backward_geometry(ctypes.byref(prob), ctypes.byref(io), b0, b1, stream),
+                               "dgs_backward_geometry")
+                    ev = torch.cuda.Event()
+                    ev.record(stream_obj)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        if t_ar is not None and ci == 0:
+                            t_ar[0].record(side)
+                        sharding.allreduce_slices([flat[offs[i] + b0 * c:offs[i] + b1 * c] for i, c in enumerate(widths)],
+                                                  bool(ar.get("average", False)), ar.get("group"))
+                _lib.check(L.dgs_backward_pose(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_pose")
+                done = torch.cuda.Event()
+                done.record(side)
+                if t_ar is not None:
+                    t_ar[1].record(side)
+                    self.ar_events = (self.ar_events + [t_ar])[-256:]
+                stream_obj.wait_event(done)
+            elif ar is not None and P > 0:
                 from . import sharding
                 sharding._allreduce(flat, bool(ar.get("average", False)), ar.get("group"))
-        else:
-            from . import sharding
-            _lib.check(L.dgs_backward_composite(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_composite")
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
-            side = self._side
-            flat.record_stream(side)
-            widths = [3, 3, 3 * Mr, 1, 3, 4]
-            t_ar = None
-            if self.time_allreduce:      # (bench.py: span of the side stream's reductions, first chunk ready -> last done)
-                t_ar = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            for ci, (b0, b1) in enumerate(sharding.chunk_bounds(P, int(ar["chunks"]))):
-                _lib.check(L.dgs_backward_geometry(ctypes.byref(prob), ctypes.byref(io), b0, b1, stream),
-                           "dgs_backward_geometry")
-                ev = torch.cuda.Event()
-                ev.record(stream_obj)
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
-                    if t_ar is not None and ci == 0:
-                        t_ar[0].record(side)
-                    sharding.allreduce_slices([flat[offs[i] + b0 * c:offs[i] + b1 * c] for i, c in enumerate(widths)],
-                                              bool(ar.get("average", False)), ar.get("group"))
-            _lib.check(L.dgs_backward_pose(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_pose")
-            done = torch.cuda.Event()
-            done.record(side)
-            if t_ar is not None:
-                t_ar[1].record(side)
-                self.ar_events = (self.ar_events + [t_ar])[-256:]
-            stream_obj.wait_event(done)
-        if P == 0:
-            flat.zero_()
-            if g_means2D is not None:
-                g_means2D.zero_()
-        cloud._xyz.grad, cloud._features_dc.grad, cloud._features_rest.grad = g_xyz, g_dc, g_rest
-        cloud._opacity.grad, cloud._scaling.grad, cloud._rotation.grad = g_op, g_sc, g_rot
+            if P == 0:
+                flat.zero_()
+                if g_means2D is not None:
+                    g_means2D.zero_()
+            cloud._xyz.grad, cloud._features_dc.grad, cloud._features_rest.grad = g_xyz, g_dc, g_rest
+            cloud._opacity.grad, cloud._scaling.grad, cloud._rotation.grad = g_op, g_sc, g_rot
 
-        # ---- cameras -> control points and alignment (only while the trajectory is being optimised)
-        if m.is_optimizing():
-            d_ct_all, d_cr_all = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
-            d_nu = torch.empty(K, **f32)
-            pscratch = torch.empty(L.dgs_pose_scratch_bytes(K), dtype=torch.uint8, device=dev)
-            _lib.check(L.dgs_pose_backward(_ptr(ct_all, row), _ptr(cr_all, rrow), _ptr(nu_loc), _ptr(proj), C, K, quat,
-                                           _ptr(g_view),
-                                           _ptr(g_proj), ctypes.c_void_p(pscratch.data_ptr()), _ptr(d_ct_all, row),
-                                           _ptr(d_cr_all, rrow), _ptr(d_nu), stream), "dgs_pose_backward")
-            m._trans._control_points.grad, m._rot._control_points.grad = d_ct_all, d_cr_all
-            if nrow > 0:
-                d_raw_all = torch.zeros_like(nu_raw)
-                if shard is not None:                    # this rank's slice of the view's subframe times
-                    d_all = torch.zeros(K_total, **f32)
-                    d_all[k0:k0 + K] = d_nu
-                    d_nu = d_all
-                if sel is not None:                      # gradients of the selected subframes back to all f slots
-                    d_full = torch.zeros(f, **f32)
-                    d_full.index_add_(0, sel, d_nu)
-                    d_nu = d_full
-                _lib.check(L.dgs_alignment_backward(raw_ptr, _ptr(uniform), f, f, _ptr(src), _ptr(d_nu),
-                                                    _ptr(d_raw_all, cam * nrow), stream), "dgs_alignment_backward")
-                m._nu.grad = d_raw_all
-        self._keep = (geom, image, binning, scratch, color, depth, dsub, view, full, campos, nu, gtc, bg, flat, g_depth)
-        fr = {"losses": losses, "blur": blur if need_blur else None, "radii": radii, "viewspace_grad": g_means2D,
-              "K": K_total, "subframes": color, "depths": depth, "skip_flag_ptr": skip_ptr, "depth_tv": depth_tv}
+            # ---- cameras -> control points and alignment (only while the trajectory is being optimised)
+            if m.is_optimizing():
+                d_ct_all, d_cr_all = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
+                d_nu = torch.empty(K, **f32)
+                pscratch = torch.empty(L.dgs_pose_scratch_bytes(K), dtype=torch.uint8, device=dev)
+                _lib.check(L.dgs_pose_backward(_ptr(ct_all, row), _ptr(cr_all, rrow), _ptr(nu_loc), _ptr(proj), C, K, quat,
+                                               _ptr(g_view),
+                                               _ptr(g_proj), ctypes.c_void_p(pscratch.data_ptr()), _ptr(d_ct_all, row),
+                                               _ptr(d_cr_all, rrow), _ptr(d_nu), stream), "dgs_pose_backward")
+                m._trans._control_points.grad, m._rot._control_points.grad = d_ct_all, d_cr_all
+                if nrow > 0:
+                    d_raw_all = torch.zeros_like(nu_raw)
+                    if shard is not None:                    # this rank's slice of the view's subframe times
+                        d_all = torch.zeros(K_total, **f32)
+                        d_all[k0:k0 + K] = d_nu
+                        d_nu = d_all
+                    if sel is not None:                      # gradients of the selected subframes back to all f slots
+                        d_full = torch.zeros(f, **f32)
+                        d_full.index_add_(0, sel, d_nu)
+                        d_nu = d_full
+                    _lib.check(L.dgs_alignment_backward(raw_ptr, _ptr(uniform), f, f, _ptr(src), _ptr(d_nu),
+                                                        _ptr(d_raw_all, cam * nrow), stream), "dgs_alignment_backward")
+                    m._nu.grad = d_raw_all
+            held = big[0]
+            self._keep = (tuple(held[:7]) if held is not None else (None,) * 7) + (view, full, campos, nu, gtc, bg, flat, g_depth)
+            return {"losses": losses, "blur": held[7] if (need_blur and held is not None) else None, "radii": radii,
+                    "viewspace_grad": g_means2D, "K": K_total, "subframes": held[4] if held is not None else None,
+                    "depths": held[5] if held is not None else None, "skip_flag_ptr": skip_ptr, "skip_flag": skip_flag,
+                    "depth_tv": depth_tv}
+
+        if split:
+            return {"finish": finish, "big": big,
+                    "_keep": (nu_all, src, proj, work, g_view, g_proj, sel, uniform, view, full, campos, nu, gtc, bg)}
+        fr = finish()
         if _cap is not None:
             fr["_keep"] = self._keep + (nu_all, src, proj, work, blur, g_colors, g_cov3D, g_view, g_proj, radii,
                                         g_means2D, sel, uniform)

@@ -207,9 +207,16 @@ class TrainingLoop:
         stats = None
         if iteration < self.opt.densify_until_iter and not self.distributed:
             stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom)
-        fr = self._fused.run(cam_idx, lambda_t_smooth, gt, bg, subframe_indice, uniform=uniform,
-                             lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0), shard=shard, exact=exact, ar=ar,
-                             stats=stats)
+        fr = None
+        if (self.graph and not exact and self.mode == "views" and self._graphable(iteration, sharded=True)):
+            # sharded step: everything up to the first collective as one hipGraph, the reductions and what depends on
+            # them eagerly (FusedStep.replay_front); None = no duplicate count learnt for this view yet
+            fr = self._fused.replay_front(cam_idx, lambda_t_smooth, gt, subframe_indice, ar, background=bg_host,
+                                          uniform=uni_host)
+        if fr is None:
+            fr = self._fused.run(cam_idx, lambda_t_smooth, gt, bg, subframe_indice, uniform=uniform,
+                                 lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0), shard=shard, exact=exact,
+                                 ar=ar, stats=stats)
         skip = fr["skip_flag_ptr"]
         if self.distributed:
             from . import sharding
@@ -217,9 +224,8 @@ class TrainingLoop:
             if self._fused.speculative:
                 # a rank whose duplicate capacity overflowed holds a meaningless gradient: every rank must drop the
                 # step (a rank that took the exact path this iteration, or rasterised nothing, brings a zero)
-                if skip is not None:
-                    off = skip - self._fused._keep[0].data_ptr()
-                    flag = self._fused._keep[0][off:off + 4].view(torch.int32)
+                if fr.get("skip_flag") is not None:
+                    flag = fr["skip_flag"]
                 else:
                     flag = torch.zeros(1, dtype=torch.int32, device=dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
@@ -293,11 +299,14 @@ class TrainingLoop:
             self._step_fused(it, cam_r, sub_r, self.lambda_t_smooth_func(it), self.densify_threshold_func(it), exact=True)
 
     # ---- the iteration as one captured hipGraph
-    def _graphable(self, iteration):
+    def _graphable(self, iteration, sharded=False):
+        """sharded=True: the question for a sharded ("views") step, whose captured part ends before the first collective."""
         opt = self.opt
         if not hasattr(self.gaussians.optimizer, "step_enqueue"):
             return False
-        if self.distributed or opt.lambda_depth_tv > 0.0 or self.noise_func(iteration) > 0.0 or iteration >= opt.iterations:
+        if self.distributed != sharded:
+            return False
+        if opt.lambda_depth_tv > 0.0 or self.noise_func(iteration) > 0.0 or iteration >= opt.iterations:
             return False
         if iteration < opt.densify_until_iter:      # densify_and_prune / reset_opacity go BETWEEN statistics and step
             if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:

@@ -1,4 +1,4 @@
-"""Builds profiles/traffic_<round>.json (default r03) from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
+"""Builds profiles/traffic_<round>.json (default r04) from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
 MI355X_MICROARCH.md, "HBM" and the TCC slot table):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d <fetch_dir> --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d <write_dir> --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists
@@ -19,8 +19,8 @@ STAGE_OF = {
     "composite_bwd_kernel": "composite_bwd", "composite_fwd_kernel": "composite_fwd",
     "preprocess_fwd_kernel": "preprocess", "cull_emit_kernel": "duplicate", "cull_count_kernel": "tile_cull(count)",
     "gather_cnt_kernel": "tile_cull(gather)",
-    "duplicate_sorted_kernel": "duplicate", "ranges_kernel": "ranges", "contrib_reduce_kernel": "geometry_bwd(contrib_reduce)",
-    "geometry_bwd_kernel": "geometry_bwd(kernel)", "onesweep_scatter_kernel": "sort(scatter)",
+    "duplicate_sorted_kernel": "duplicate", "ranges_search_kernel": "ranges", "contrib_reduce_kernel": "geometry_bwd(contrib_reduce)",
+    "geometry_bwd_kernel": "geometry_bwd(kernel)", "sort_scatter_kernel": "sort(scatter)",
     "sort_hist_rows_kernel": "sort(hist)", "blur_loss_kernel": "blur_loss", "blur_loss_all_kernel": "blur_loss",
     "adam_kernel": "adam", "dsort_scatter_kernel": "depth_order(scatter)", "dsort_hist_kernel": "depth_order(hist)",
 }

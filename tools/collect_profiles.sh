@@ -2,7 +2,7 @@
 # Collects the round's committed evidence on the GPU box into gpurun_out/profiles_<round>/ (copy what is to be judged into
 # profiles/ afterwards): kernel-trace summary, VALU counters, FETCH / WRITE counters (separate passes, kernel-trace only),
 # the per-class issue costs, and the derived json files.   usage: tools/collect_profiles.sh [round]
-rnd=${1:-r03}
+rnd=${1:-r04}
 root=$(cd "$(dirname "$0")/.." && pwd)
 cd $root
 export TMPDIR=/tmp
@@ -11,15 +11,18 @@ mkdir -p $out
 B="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists --no-graph"
 tools/valu_rate > $out/valu_classes_$rnd.txt 2>&1
 cp $out/valu_classes_$rnd.txt profiles/valu_classes_$rnd.txt
+( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES -d $out/valu_peak -o pmc --output-format csv -- $root/tools/valu_rate 8 > $out/valu_peak.log 2>&1 )
+python3 profiles/make_valu_peak.py $out/valu_peak $out/valu_classes_$rnd.txt > profiles/valu_peak_$rnd.json 2> $out/valu_peak_err.log
+python3 tools/isa_census.py --json profiles/isa_census_$rnd.json > $out/isa_census.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-reference-lists --no-graph > $out/trace.log 2>&1
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/${rnd}_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d $out/trace_graph -o trace --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-reference-lists > $out/trace_graph.log 2>&1
 cp $(find $out/trace_graph -name "*kernel_stats.csv" | head -1) $out/${rnd}_kernel_stats_graph_replay.csv
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE -d $out/valu -o pmc --output-format csv -- $B > $out/valu.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -d $out/valu -o pmc --output-format csv -- $B > $out/valu.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -o pmc --output-format csv -- $B > $out/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -o pmc --output-format csv -- $B > $out/write.log 2>&1
 R=$(grep -o '"R_total": [0-9]*' $out/valu.log | head -1 | grep -o '[0-9]*$')
 python3 profiles/make_valu.py $out/valu metric $rnd $R > $out/make_valu.log 2>&1
 python3 profiles/make_traffic.py $out/fetch $out/write metric $rnd > $out/make_traffic.log 2>&1
-cp profiles/valu_$rnd.json profiles/traffic_$rnd.json $out/ 2>/dev/null
+cp profiles/valu_$rnd.json profiles/traffic_$rnd.json profiles/valu_peak_$rnd.json profiles/isa_census_$rnd.json $out/ 2>/dev/null
 tail -3 $out/make_valu.log; echo "R_total=$R"; ls $out

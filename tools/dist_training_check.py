@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--random-sample", action="store_true", help="curve_random_sample on (alignment jitter)")
     ap.add_argument("--ar-chunks", type=int, default=1,
                     help="all-reduce the gradient bucket in this many Gaussian-index chunks, overlapped with the backward")
+    ap.add_argument("--graph", default="auto", choices=["auto", "always", "off"],
+                    help="TrainingLoop(graph=...): 'always' replays the sharded step's front as a hipGraph whenever possible")
+    ap.add_argument("--densify-interval", type=int, default=6)
     ap.add_argument("--depth-tv", type=float, default=0.0, help="lambda_depth_tv (one more collective per step in subframes mode)")
     ap.add_argument("--p2p-direct", action="store_true",
                     help="REPRODUCTION AID, not a product path: replace sharding._p2p by round 3's behaviour (batch_isend_irecv "
@@ -96,11 +99,11 @@ def main():
     far = 10 ** 9
     opt = default_optimization_params(
         iterations=args.iters + 10, curve_start_iter=args.curve_start, densify_from_iter=far if args.no_densify else 5,
-        densification_interval=6, densify_until_iter=args.iters - 3, densify_grad_threshold_init=2e-5,
+        densification_interval=args.densify_interval, densify_until_iter=args.iters - 3, densify_grad_threshold_init=2e-5,
         densify_grad_threshold_final=1e-5, opacity_reset_interval=1000, curve_alignment_lr=1e-3, curve_alignment_start=4,
         lambda_depth_tv=args.depth_tv)
     loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=args.mode if world > 1 else False,
-                        ar_chunks=args.ar_chunks)
+                        ar_chunks=args.ar_chunks, graph={"auto": "auto", "always": "always", "off": False}[args.graph])
     inplace = []
     _orig = sharding.flat_allreduce_grads
 
@@ -138,6 +141,12 @@ def main():
     moved = [float((p.detach() - q).abs().max()) for p, q in
              zip(m.parameters(), [torch.zeros_like(p) for p in m.parameters()])]
     if rank == 0:
+        import hashlib
+        hsh = hashlib.sha1()
+        for p_ in tensors:
+            hsh.update(p_.detach().cpu().numpy().tobytes())
+        print(f"params sha1 {hsh.hexdigest()[:16]} replayed {0 if loop._fused is None else loop._fused.replayed} "
+              f"dropped {0 if loop._fused is None else loop._fused.dropped} dist_dropped {loop.dist_dropped}", flush=True)
         print(f"mode {args.mode} ranks {world} points {sizes[0]} -> {sizes[-1]} densified: {len(set(sizes)) > 1} "
               f"replicas (cloud + trajectory) identical: {same} bucket reduced in place: "
               f"{all(inplace) if inplace else None} curve state steps: "
@@ -147,8 +156,9 @@ def main():
         assert world == 1 or not inplace or all(inplace[1:]), "the gradient bucket must be reduced in place"
         assert cloud.optimizer.state[m._nu]["step"] > 0 and moved[0] > 0
         if args.out:
-            torch.save({"params": [p.detach().cpu() for p in tensors], "sizes": sizes, "grads_first": snap.get("grads")},
-                       args.out)
+            torch.save({"params": [p.detach().cpu() for p in tensors], "sizes": sizes, "grads_first": snap.get("grads"),
+                        "replayed": 0 if loop._fused is None else loop._fused.replayed,
+                        "captured": 0 if loop._fused is None else loop._fused.captured}, args.out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

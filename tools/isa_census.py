@@ -4,7 +4,7 @@ deblurgs_amd/build.py) and counts instructions per class
   * per list ENTRY                 = the rest of the innermost loop (row fetch from LDS, hit tests, zero-fill, the
                                      per-duplicate reduce-scatter and its LDS store),
   * per BATCH of 64 entries        = the enclosing loop minus the entry loop (gather, quadrant culling, LDS staging, stores).
-With the per-class issue costs measured by tools/valu_rate (cycles per wave64 instruction at saturation) this gives the
+With the per-class issue costs of profiles/valu_peak_<round>.json (tools/valu_rate under rocprofv3 PMC) this gives the
 issue-slot-weighted VALU demand per pass / entry / batch that profiles/make_valu.py turns into roofline.valu.
 
     python tools/isa_census.py [--json out.json]
@@ -17,8 +17,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLASSES = ["valu_plain", "valu_trans", "valu_cmp", "valu_select", "valu_dpp", "valu_permlane", "valu_mov", "salu",
-           "branch", "lds", "vmem", "smem", "wait_nop"]
+CLASSES = ["valu_plain", "valu_trans", "valu_cmp", "valu_select", "valu_dpp", "valu_permlane", "valu_mov", "valu_readlane",
+           "valu_quarter", "valu_pk", "salu", "branch", "lds", "vmem", "smem", "wait_nop"]
 
 
 def classify(op):
@@ -36,6 +36,12 @@ def classify(op):
         return "vmem"
     if op.startswith("v_permlane"):
         return "valu_permlane"
+    if op.startswith(("v_readlane", "v_readfirstlane", "v_writelane")):
+        return "valu_readlane"
+    if op.startswith(("v_mad_u64", "v_mad_i64", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32")):
+        return "valu_quarter"
+    if op.startswith("v_pk_"):
+        return "valu_pk"
     if "_dpp" in op:
         return "valu_dpp"
     if op.startswith(("v_exp", "v_rcp", "v_rsq", "v_sqrt", "v_log", "v_sin", "v_cos")):
