@@ -443,8 +443,9 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
       using I3 = std::integral_constant<int, 3>;
-      // (specialising the entry body on its hit mask -- 15 straight-line variants, or only the four one-quadrant ones,
-      // whose sums are the pass's products and need no zeroed accumulators -- measured 8-15 % SLOWER: variants/NOTES.md)
+      // (every way of letting the first executed pass START the sums instead of zeroing nine accumulators -- 15 straight-line
+      // hit-mask variants, only the four one-quadrant ones, or a compare / branch chain on the first hit quadrant -- made the
+      // kernel 5-17 % SLOWER although it removes instructions: more copies of the pass body in the loop.  variants/NOTES.md)
       if ((m[0] >> j) & 1ull) pass(I0{});   // wave-uniform
       if ((m[1] >> j) & 1ull) pass(I1{});
       if ((m[2] >> j) & 1ull) pass(I2{});

@@ -533,6 +533,111 @@ def test_huge_gaussian_and_long_tile_lists(gpu):
     sharp_backward_check(sc, 1)
 
 
+def _needle_scene(P=350, W=160, H=120, seed=31, n_needles=150, length_px=4000.0):
+    """Splats whose 2D covariance is singular by a hair in fp32: 4000-pixel-long needles in the image plane, 0.55 pixels
+    wide (the 0.3 low-pass filter), at random angles.  Their conics are positive definite as make_cull evaluates them,
+    yet along the axis the three terms of `power` (each ~3.3 t^2) cancel to -t^2 / (2 L^2): below fp32 resolution, so
+    the reference's `power > 0.0f` skip (forward.cu:354-355, backward.cu:575-576) fires through ROUNDING on a few pixels."""
+    sc = synthetic.make_scene(P, W, H, K=1, seed=seed, sigma_px=2.0)
+    rng = np.random.default_rng(seed)
+    focal = W / (2.0 * sc["tanfovx"])
+    idx = np.arange(n_needles)
+    z = sc["means3D"][idx, 2]
+    sc["means3D"][idx, 0] = rng.uniform(-0.5, 0.5, n_needles) * sc["tanfovx"] * z
+    sc["means3D"][idx, 1] = rng.uniform(-0.5, 0.5, n_needles) * sc["tanfovy"] * z
+    sc["scales"][idx, 0] = (length_px * z / focal).astype(np.float32)
+    sc["scales"][idx, 1:] = 1e-4
+    th = rng.uniform(0, np.pi, n_needles)
+    q = np.zeros((n_needles, 4), np.float32)
+    q[:, 0], q[:, 3] = np.cos(th / 2), np.sin(th / 2)      # rotation about the viewing axis
+    sc["rotations"][idx] = q
+    sc["opacities"][idx] = rng.uniform(0.3, 0.9, (n_needles, 1)).astype(np.float32)
+    return sc
+
+
+def test_pd_fast_path_on_near_singular_conics(gpu):
+    """the compositing kernels drop the `power > 0` compare for batches whose conics are positive
+    definite in fp32 (composite.hip, `pdm`).  For such a conic `power` can only come out positive through rounding --
+    argued, now tested where it bites: a scene of near-singular needles in which the reference's fp32 evaluation DOES
+    produce power > 0 for positive-definite conics on some pixels.  Every such pixel must be one the checker already
+    classifies as unstable (a pair within the fp32 evaluation uncertainty of a threshold), and off the unstable pixels
+    images, n_contrib and the compositing backward's direct outputs hold the usual bars -- with and without tile culling."""
+    sc = _needle_scene()
+    o = oracle_forward(sc, 0)
+    un = unstable_pixels(o)
+    W, H = sc["W"], sc["H"]
+    ys, xs = np.mgrid[0:H, 0:W]
+    px, py = xs.reshape(-1).astype(np.float32), ys.reshape(-1).astype(np.float32)
+    co, m2 = o["conic_opacity"], o["means2D"]
+    hit = np.zeros(W * H, bool)
+    pairs = 0
+    for g in np.nonzero(o["radii"] > 0)[0]:
+        a, b, c = co[g, 0], co[g, 1], co[g, 2]
+        if np.float32(a * c) - np.float32(b * b) <= 0:
+            continue                                               # not positive definite in fp32: takes the checked path
+        dx, dy = (m2[g, 0] - px).astype(np.float32), (m2[g, 1] - py).astype(np.float32)
+        power = (np.float32(-0.5) * (a * dx * dx + c * dy * dy) - b * dx * dy).astype(np.float32)   # forward.cu:353
+        pos = (power > 0) & (co[g, 3] >= 1.0 / 255.0)
+        pairs += int(pos.sum())
+        hit |= pos
+    print(f"\n[needles] {pairs} (pixel, Gaussian) pairs with a positive-definite conic and fp32 power > 0 on {int(hit.sum())} "
+          f"pixels; unstable pixels {un.mean():.4f}")
+    assert pairs >= 1, "no pair whose fp32 power rounds positive: the scene does not exercise the fast path's blind spot"
+    assert not (hit & ~un.reshape(-1)).any(), "a rounding-positive power on a pixel the checker calls stable"
+    assert un.mean() < 0.06
+    s = ~un.reshape(-1)
+    # The needles are ill-conditioned everywhere, not only at the thresholds: 100 pixels along an axis the three terms of
+    # `power` are ~3e4 and two correct fp32 evaluations (the reference's, the kernels' pre-scaled log2 form) differ by up
+    # to ~1e-3 in power, i.e. in alpha (measured: 6e-4 in the image).  The image bar of THIS scene is therefore 2e-3 -- two
+    # orders of magnitude below what a pair blended on one side and skipped on the other shows (alpha ~ 0.3-0.9) -- and
+    # n_contrib / final_T are held exactly as everywhere else.
+    for cull in (True, False):
+        with tile_cull(cull):
+            hip = hip_forward_state(sc, 1)
+        dc = np.abs(hip["color"][0] - o["color"]).max(axis=0)
+        print(f"[needles] tile_cull {cull}: colour off the unstable pixels {dc[~un].max():.2e}, on them {dc[un].max():.2e}")
+        assert dc[~un].max() <= 2e-3, f"colour (tile_cull {cull}): {dc[~un].max()}"
+        assert np.array_equal(hip["n_contrib"][0][s], o["n_contrib"][s]), f"n_contrib (tile_cull {cull})"
+        assert np.abs(hip["final_T"][0][s] - o["final_T"][s]).max() <= 1e-3
+    run = OracleRun(sc, 1)
+    gC, gD = run.mask(*_grads(sc, 1))
+    a = hip_forward_backward(sc, 1, gC, gD)
+    ora = run.backward(gC, gD)
+    # the same for the gradients: within 1e-4 + 20 x what two correct fp32 builds of the reference (fp32 vs double
+    # accumulation, FMA contraction on vs off) differ by on this scene
+    for key in ("dL_dopacities", "dL_dsh", "dL_dmeans2D"):
+        b_, n_, f_ = ora["double"][key], ora["f32"][key], ora["fma"][key]
+        noise = max(relerr(n_, b_), relerr(f_, b_))
+        e = relerr(np.asarray(a[key], np.float64).reshape(b_.shape), b_)
+        print(f"[needles] {key}: vs oracle {e:.2e}, reference's own builds {noise:.2e}")
+        assert e <= GRAD_TOL + 20.0 * noise, f"{key}: {e:.2e} (reference noise {noise:.2e})"
+
+
+def test_view_matrix_gradient_flat_bar_on_a_well_conditioned_problem(gpu):
+    """elsewhere dL_dviewmatrix is held to max(1e-4, 4 x the difference between two fp32 builds of the
+    reference), because with white-noise upstream gradients and strongly anisotropic splats it is a sum of ~P signed terms
+    that cancel (the floating part reached 2e-3).  Here the problem itself is well conditioned -- near-isotropic splats
+    (sigma_log 0.2), a smooth upstream gradient: the reference's own builds agree to ~1e-6 -- and the bar is north_star's
+    flat 1e-4 for every subframe, dL_dprojmatrix included."""
+    K = 3
+    sc = small_scene(P=3000, W=200, H=136, K=K, seed=1, sigma_log=0.2)
+    ys, xs = np.mgrid[0:sc["H"], 0:sc["W"]].astype(np.float32)
+    gC = np.stack([np.stack([0.6 + 0.4 * np.sin(0.05 * xs * (c + 1) + 0.3 * k) * np.cos(0.04 * ys + c) for c in range(3)])
+                   for k in range(K)]).astype(np.float32)
+    run = OracleRun(sc, K)
+    gC, _ = run.mask(gC, None)
+    ora = run.backward(gC, None)
+    hip = hip_forward_backward(sc, K, gC, None)
+    for key in ("dL_dviewmatrix", "dL_dprojmatrix"):
+        b, n, f = ora["double"][key], ora["f32"][key], ora["fma"][key]
+        noise = max(max(relerr(n[k], b[k]), relerr(f[k], b[k])) for k in range(K))
+        assert noise <= 2.5e-5, f"{key}: the reference's own fp32 builds differ by {noise:.2e}: not the well-conditioned case"
+        a = np.asarray(hip[key], np.float64).reshape(b.shape)
+        errs = [relerr(a[k], b[k]) for k in range(K)]
+        print(f"\n[{key}] vs oracle per subframe: {['%.2e' % e for e in errs]} (reference noise {noise:.2e})")
+        assert max(errs) <= GRAD_TOL, f"{key}: {max(errs):.2e} > {GRAD_TOL:.0e} (flat bar)"
+
+
 def test_argument_errors(gpu):
     import torch
     from helpers import hip_settings, _t

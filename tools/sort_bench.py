@@ -1,4 +1,4 @@
-"""Micro-benchmark of dgs_sort_pairs (A/B of sort modes: build variants with tools/build_flag_variant.sh <name> -DDGS_SORT_MODE=0|1|2 and select one with DGS_LIB_PATH): python tools/sort_bench.py [n] [bits]"""
+"""Micro-benchmark of dgs_sort_pairs (A/B of library builds: select one with DGS_LIB_PATH; the rejected sort modes live in variants/binning_sort_modes_and_ranges_sweep.patch): python tools/sort_bench.py [n] [bits]"""
 import ctypes, sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
