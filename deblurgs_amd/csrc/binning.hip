@@ -61,6 +61,25 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total,
   return base + incl - v;
 }
 
+// exclusive scan of one value per thread across an NT-thread block; returns the exclusive prefix, *total = sum
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan_n(uint32_t v, uint32_t* total, uint32_t* lds /*[NT / 64]*/) {
+  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  uint32_t incl = wave_incl_scan(v);
+  if (lane == 63) lds[w] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NT / 64; i++) {
+    uint32_t s = lds[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_reduce_kernel(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t lds[8];
@@ -650,7 +669,11 @@ ranges_search_kernel(uint32_t L, const uint32_t* __restrict__ n_dev, const uint6
 // digit-major [digit][block]; (2) exclusive scan of that table = global scatter bases; (3) scatter with
 // stable in-block ranks.  A block owns SORT_TILE consecutive pairs; wave w owns a contiguous quarter of them,
 // read in rounds of 64, so the stable order inside a block is (wave, round, lane).
-constexpr int SORT_THREADS = 256;
+#ifndef DGS_SORT_THREADS
+#define DGS_SORT_THREADS 256
+#endif
+constexpr int SORT_THREADS = DGS_SORT_THREADS;
+constexpr int SORT_WAVES = SORT_THREADS / 64;
 // (32 items = 8192-pair tiles would double the length of the digit runs the scatter writes, but need 256 VGPRs and 78 KB
 // of LDS per block: scatter 265 vs 208 us per pass, measured with -DDGS_SORT_ITEMS=32)
 #ifndef DGS_SORT_ITEMS
@@ -783,11 +806,12 @@ sort_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __rest
     n = min(n, (uint64_t)n_dev[0]);
     if ((uint64_t)blockIdx.x * SORT_TILE >= n) return;  // block-uniform, before any barrier
   }
-  __shared__ uint64_t lds_k[SORT_TILE];  // 32 KB; re-used for the values
-  __shared__ uint32_t whist[SORT_THREADS / 64][SORT_MAX_BINS];
+  __shared__ uint64_t lds_k[SORT_TILE];  // 8 bytes per pair; re-used for the values
+  __shared__ uint16_t whist[SORT_WAVES][SORT_MAX_BINS];   // (a tile holds fewer than 65536 pairs)
   __shared__ uint32_t dstart[SORT_MAX_BINS];
   __shared__ uint32_t gb[SORT_MAX_BINS];
-  __shared__ uint32_t s_scan[8];
+  __shared__ uint32_t s_scan[SORT_WAVES];
+  static_assert(SORT_TILE < 65536 && SORT_MAX_BINS % SORT_THREADS == 0, "16-bit wave counts; whole digits per thread");
   const uint32_t mask = (1u << rb) - 1;
   const int lane = dgs_lane(), w = threadIdx.x >> 6;
   for (int i = lane; i < SORT_MAX_BINS; i += 64) whist[w][i] = 0;
@@ -799,7 +823,7 @@ sort_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __rest
   uint64_t key[SORT_ITEMS];
   uint32_t val[SORT_ITEMS];
   uint32_t rank[SORT_ITEMS];
-  volatile uint32_t* wh = whist[w];
+  volatile uint16_t* wh = whist[w];
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS; r++) {
@@ -821,38 +845,39 @@ sort_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __rest
     uint32_t pre = 0;
     if (valid) pre = wh[d];
     __builtin_amdgcn_wave_barrier();
-    if (valid && below == 0) wh[d] = pre + (uint32_t)__popcll(peers);
+    if (valid && below == 0) wh[d] = (uint16_t)(pre + (uint32_t)__popcll(peers));
     __builtin_amdgcn_wave_barrier();
     rank[r] = pre + below;
   }
   __syncthreads();
 
-  // thread t owns digits 2t, 2t+1: block totals, per-wave exclusive offsets, start of each digit inside the tile
-  uint32_t cnt[2];
+  // thread t owns digits DPT t .. DPT t + DPT - 1: block totals, per-wave exclusive offsets, start of each digit inside the tile
+  constexpr int DPT = SORT_MAX_BINS / SORT_THREADS;
+  uint32_t cnt[DPT], sum = 0;
 #pragma unroll
-  for (int e = 0; e < 2; e++) {
-    const int d = 2 * threadIdx.x + e;
+  for (int e = 0; e < DPT; e++) {
+    const int d = DPT * threadIdx.x + e;
     uint32_t run = 0;
 #pragma unroll
-    for (int ww = 0; ww < SORT_THREADS / 64; ww++) {
+    for (int ww = 0; ww < SORT_WAVES; ww++) {
       const uint32_t c = whist[ww][d];
-      whist[ww][d] = run;
+      whist[ww][d] = (uint16_t)run;
       run += c;
     }
     cnt[e] = run;
+    sum += run;
   }
   uint32_t tot;
-  const uint32_t pre2 = block_excl_scan(cnt[0] + cnt[1], &tot, s_scan);
-  dstart[2 * threadIdx.x] = pre2;
-  dstart[2 * threadIdx.x + 1] = pre2 + cnt[0];
-
+  uint32_t pre2 = block_excl_scan_n<SORT_THREADS>(sum, &tot, s_scan);
   // global position of tile-local slot i holding digit d:  gb[d] + i
+  const uint32_t cap_chunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
 #pragma unroll
-  for (int e = 0; e < 2; e++) {
-    const int d = 2 * threadIdx.x + e;
-    const uint32_t cap_chunks = (nblocks + CS_CHUNK - 1) / CS_CHUNK;
+  for (int e = 0; e < DPT; e++) {
+    const int d = DPT * threadIdx.x + e;
+    dstart[d] = pre2;
     gb[d] = gbase[(size_t)tile * SORT_MAX_BINS + d] + ctot[(size_t)(tile / CS_CHUNK) * SORT_MAX_BINS + d] +
-            ctot[(size_t)cap_chunks * SORT_MAX_BINS + d] - (e == 0 ? pre2 : pre2 + cnt[0]);
+            ctot[(size_t)cap_chunks * SORT_MAX_BINS + d] - pre2;
+    pre2 += cnt[e];
   }
   __syncthreads();
 
@@ -921,25 +946,6 @@ constexpr uint32_t DS_INVISIBLE = 0xFFFFFFFFu;
 constexpr uint32_t DS_NARROW_MAX = (1u << (3 * DS_RB)) - 1u;   // a visible key at or above this needs the fourth pass
 static_assert(DS_BINS % DS_THREADS == 0 || DS_THREADS % DS_BINS == 0, "bins and threads must divide each other");
 static_assert(DS_TILE <= 65535, "per-wave digit counts are kept in 16 bits");
-
-// exclusive scan of one value per thread across an NT-thread block; returns the exclusive prefix, *total = sum
-template <int NT>
-__device__ __forceinline__ uint32_t block_excl_scan_n(uint32_t v, uint32_t* total, uint32_t* lds /*[NT / 64]*/) {
-  const int lane = dgs_lane(), w = threadIdx.x >> 6;
-  uint32_t incl = wave_incl_scan(v);
-  if (lane == 63) lds[w] = incl;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < NT / 64; i++) {
-    uint32_t s = lds[i];
-    if (i < w) base += s;
-    tot += s;
-  }
-  __syncthreads();
-  *total = tot;
-  return base + incl - v;
-}
 
 // pass: 0..2 the 9-bit digits, 3 the optional pass on bits [27, 32) (returns unless *wide_flag)
 __global__ void __launch_bounds__(DS_THREADS)
