@@ -667,10 +667,13 @@ ranges_search_kernel(uint32_t L, const uint32_t* __restrict__ n_dev, const uint6
 // Stable LSD radix sort, RB-bit digits (RB <= 9; 10-bit digits were measured slower per key: 5 x 1.11 ms vs
 // 6 x 0.81 ms at the metric config).  Per pass: (1) per-block digit histogram written
 // digit-major [digit][block]; (2) exclusive scan of that table = global scatter bases; (3) scatter with
-// stable in-block ranks.  A block owns SORT_TILE consecutive pairs; wave w owns a contiguous quarter of them,
+// stable in-block ranks.  A block owns SORT_TILE consecutive pairs; wave w owns a contiguous share of them,
 // read in rounds of 64, so the stable order inside a block is (wave, round, lane).
+// 512-thread blocks of 8192 pairs (round 4): the digit runs a block writes are twice as long (128 bytes on average with
+// 512 digits) and, with 16-bit wave counts, two blocks = 16 waves fit a CU (the 256-thread block was held to 3 waves per SIMD
+// by its 130 VGPRs): scatter + histogram of a pass 0.312 -> 0.275 ms at the metric config (-DDGS_SORT_THREADS=256: the old shape)
 #ifndef DGS_SORT_THREADS
-#define DGS_SORT_THREADS 256
+#define DGS_SORT_THREADS 512
 #endif
 constexpr int SORT_THREADS = DGS_SORT_THREADS;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
@@ -680,7 +683,7 @@ constexpr int SORT_WAVES = SORT_THREADS / 64;
 #define DGS_SORT_ITEMS 16
 #endif
 constexpr int SORT_ITEMS = DGS_SORT_ITEMS;
-constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 pairs per block
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 8192 pairs per block
 constexpr int SORT_MAX_RB = 9;
 constexpr int SORT_MAX_BINS = 1 << SORT_MAX_RB;
 
@@ -791,7 +794,7 @@ colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nchunks, const uint32_t
 }
 
 // ---------------------------------------------------------------------------------------- scatter pass
-// Ranks its 4096 pairs (wave-ballot match per digit bit, per-wave running counts in LDS), takes the tile's global digit
+// Ranks its SORT_TILE pairs (wave-ballot match per digit bit, per-wave running counts in LDS), takes the tile's global digit
 // bases from the tile-major histogram table (gbase: in-chunk exclusive counts) and the column-scanned chunk bases
 // (ctot, followed by the row of digit bases), and re-orders the pairs through LDS so that the global writes are
 // contiguous runs per digit instead of 64 scattered 8-byte stores per wave instruction.  (A decoupled-look-back
