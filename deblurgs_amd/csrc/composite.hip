@@ -27,10 +27,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // lowers to v_pk_{mul,a
 // stores per lane, 40 lanes read 16 values each and add them, the totals go straight to the row in global memory (one
 // 40-byte store per entry).  Round 2's reduce-scatter on the VALU (v_permlane*_swap + DPP, rows staged in LDS) measured
 // 5.70-5.77 ms against 5.41 ms on the same box: variants/bwd_valu_reduce_scatter.patch.
-#ifndef DGS_COMPOSITE_CW
-#define DGS_COMPOSITE_CW 4
-#endif
-constexpr int CW = DGS_COMPOSITE_CW;  // waves (= tiles) per block; the waves never synchronise with each other
+// waves (= tiles) per block; the waves never synchronise with each other.  (1 or 2 waves per block -- finer scheduling of
+// tiles whose lists differ in length -- measured 5.25-5.28 ms against 5.09-5.13 for the backward, 2.39 against 2.42 for the
+// forward: kept at 4)
+constexpr int CW = 4;
 
 struct TileCtx {
   int k, tx, ty;
