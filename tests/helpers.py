@@ -475,7 +475,15 @@ def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, floor=ROW_FLOOR, report=Non
         if key not in CHAIN_KEYS:
             col, row = flat(np.ones(a.shape[0], bool))
             if report is not None:
-                report.append((key, {"col": col, "row": row, "noise_row_max": float(noise_row.max())}))
+                rep = {"col": col, "row": row, "noise_row_max": float(noise_row.max())}
+                if nz.any():      # where the column measure is reached, and how far two fp32 builds of the reference differ there
+                    dcol = d[:, nz] / colmax[nz]
+                    w = int(np.argmax(dcol.max(axis=1)))
+                    ncol = np.maximum(np.abs(n - b).reshape(a.shape[0], -1), np.abs(f - b).reshape(a.shape[0], -1))[:, nz] / colmax[nz]
+                    rep["col_worst_row"] = w
+                    rep["col_noise_at_worst_row"] = float(ncol[w].max())
+                    rep["col_noise_max"] = float(ncol.max())
+                report.append((key, rep))
             _check(col <= tol, f"{key} col: {col:.2e} > {tol:.0e}", failures)
             _check(row <= row_tol, f"{key} row: {row:.2e} > {row_tol:.0e}", failures)
             continue

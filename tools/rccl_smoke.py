@@ -17,7 +17,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 
 
-def train(mode, iters=12, ar_chunks=1):
+def train(mode, iters=12, ar_chunks=1, graph="auto", depth_tv=0.01):
     import torch
     from deblurgs_amd import synthetic
     from deblurgs_amd.cloud import GaussianCloud
@@ -38,12 +38,14 @@ def train(mode, iters=12, ar_chunks=1):
                                       densification_interval=4, densify_until_iter=iters - 2,
                                       densify_grad_threshold_init=2e-5, densify_grad_threshold_final=1e-5,
                                       opacity_reset_interval=1000, curve_alignment_lr=1e-3, curve_alignment_start=4,
-                                      lambda_depth_tv=0.01)
-    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=mode, ar_chunks=ar_chunks)
+                                      lambda_depth_tv=depth_tv)
+    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=mode, ar_chunks=ar_chunks, graph=graph)
     for it in range(1, iters + 1):
         torch.manual_seed(it)
         loop.step(it, it % 2)
+    loop.flush()
     torch.cuda.synchronize()
+    train.replayed = 0 if loop._fused is None else loop._fused.replayed
     return [p.detach().clone() for p in list(cloud.hot_parameters()) + list(m.parameters())]
 
 
@@ -93,6 +95,16 @@ def main():
         for i, (a, b) in enumerate(zip(base, got)):
             assert a.shape == b.shape and torch.equal(a, b), f"mode {mode}, 4 chunks: parameter {i} changed"
         print(f"rccl smoke: mode {mode}: 4-chunk overlapped all-reduce bit-identical too", flush=True)
+        if mode == "views":
+            # the sharded step with its front replayed as a captured hipGraph from the first possible iteration on
+            # (FusedStep.replay_front), RCCL reductions behind it on the side stream: same parameters, and it did replay
+            # (without the depth-smoothness term, which is not captured: its own eager baseline)
+            base0 = train(mode, ar_chunks=4, graph=False, depth_tv=0.0)
+            got = train(mode, ar_chunks=4, graph="always", depth_tv=0.0)
+            for i, (a, b) in enumerate(zip(base0, got)):
+                assert a.shape == b.shape and torch.equal(a, b), f"mode {mode}, captured front: parameter {i} changed"
+            assert train.replayed >= 2, train.replayed
+            print(f"rccl smoke: mode {mode}: captured front + RCCL reductions bit-identical ({train.replayed} replays)", flush=True)
         # ... and the same steps with every reduction of the bucket (whole, then per chunk on the side stream) and the
         # few-KB trajectory buffer taking the point-to-point reduce-scatter path on RCCL
         sharding.ALLREDUCE_MODE, keep_min = "p2p", sharding.P2P_MIN_NUMEL
