@@ -1,8 +1,8 @@
 #!/bin/bash
 # Everything the round's DESIGN / profiles quote, produced in one GPU session into gpurun_out/profiles_<round>/:
 #   profiles (tools/collect_profiles.sh), bench lines per config, the config tests' own parity report, the CU-mask
-#   overlap probe, the RCCL smoke test.   usage: tools/final_evidence.sh [round]
-rnd=${1:-r03}
+#   overlap probe (round 3), soak + list stress + p2p repeats, the RCCL smoke test.   usage: tools/final_evidence.sh [round]
+rnd=${1:-r04}
 root=$(cd "$(dirname "$0")/.." && pwd)
 cd $root
 out=$root/gpurun_out/profiles_$rnd
@@ -18,9 +18,12 @@ done
 python3 bench.py --config metric --steps 50 --warmup 5 --no-cpu-baseline --no-reference-lists --no-graph > $out/bench_${rnd}_metric_eager.json 2>/dev/null
 python3 bench.py --config cfg2 --steps 50 --warmup 5 --no-cpu-baseline --no-reference-lists --no-graph > $out/bench_${rnd}_cfg2_eager.json 2>/dev/null
 python3 bench.py --config metric --steps 30 --warmup 5 --no-cpu-baseline --no-reference-lists --autograd-path > $out/bench_${rnd}_metric_autograd.json 2>/dev/null
-python3 tools/cu_mask_probe.py > $out/${rnd}_cu_mask_probe.txt 2>&1
+python3 tools/soak.py 2000 always > $out/soak_${rnd}.log 2>&1
+python3 tools/stress_lists.py > $out/stress_lists_${rnd}.log 2>&1
+python3 tools/p2p_repeat.py --repeat 10 --mode subframes > $out/${rnd}_p2p_repeat_final.log 2>&1
 python3 tools/rccl_smoke.py > $out/${rnd}_rccl_smoke.txt 2>&1
 python3 -m pytest tests/test_gpu_configs.py -q -s > $out/${rnd}_gpu_configs.log 2>&1
-python3 -m pytest tests/test_gpu_train.py -q -s -k "toy_deblurring or graph_replay or rccl or two_ranks" > $out/${rnd}_gpu_train_extract.log 2>&1
+python3 -m pytest tests/test_gpu_train.py -q -s -k "toy_deblurring or graph_replay or rccl or two_ranks or captured" > $out/${rnd}_gpu_train_extract.log 2>&1
+DGS_DIST_BACKEND=gloo DGS_DIST_ONE_DEVICE=1 python3 bench.py --gpus 2 --config cfg2 --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_${rnd}_cfg2_2ranks_one_gpu.json 2>/dev/null
 for f in $out/bench_${rnd}_*.json; do tail -1 $f | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$f'.split('/')[-1], d['value'], d['ms_per_step'])"; done
 tail -3 $out/${rnd}_gpu_configs.log
