@@ -94,6 +94,7 @@ class TrainingLoop:
         self.dist_dropped = 0       # sharded runs: steps every rank dropped together (no make-up; counters corrected)
         self._dist_flags = []
         self._last_iteration = None
+        self._front_failed = False  # the captured front of sharded steps was refused once: stay eager
         self._fused = None
         if fused_step:
             try:
@@ -208,11 +209,25 @@ class TrainingLoop:
         if iteration < self.opt.densify_until_iter and not self.distributed:
             stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom)
         fr = None
-        if (self.graph and not exact and self.mode == "views" and self._graphable(iteration, sharded=True)):
+        if (self.graph and not exact and self.mode == "views" and not self._front_failed and
+                self._graphable(iteration, sharded=True)):
             # sharded step: everything up to the first collective as one hipGraph, the reductions and what depends on
             # them eagerly (FusedStep.replay_front); None = no duplicate count learnt for this view yet
-            fr = self._fused.replay_front(cam_idx, lambda_t_smooth, gt, subframe_indice, ar, background=bg_host,
-                                          uniform=uni_host)
+            captured_before = self._fused.captured
+            try:
+                fr = self._fused.replay_front(cam_idx, lambda_t_smooth, gt, subframe_indice, ar, background=bg_host,
+                                              uniform=uni_host)
+            except RuntimeError as ex:
+                # A capture that the runtime refuses (e.g. a collective library that does not tolerate a capturing
+                # stream next to it) must not take an N-rank run down: nothing of the step has been enqueued when a
+                # CAPTURE fails, so the eager step below runs it, and the front is not tried again.  (A failure after a
+                # successful capture -- in the eager part -- is a real error and is re-raised.)
+                if self._fused.captured != captured_before:
+                    raise
+                import warnings
+                warnings.warn(f"captured front disabled for this run (falling back to the eager sharded step): {ex}")
+                self._front_failed = True
+                fr = None
         if fr is None:
             fr = self._fused.run(cam_idx, lambda_t_smooth, gt, bg, subframe_indice, uniform=uniform,
                                  lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0), shard=shard, exact=exact,
