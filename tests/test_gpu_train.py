@@ -996,6 +996,28 @@ def test_two_ranks_captured_front_equals_the_eager_sharded_step(gpu, chunks, tmp
 
 
 @pytest.mark.parametrize("mode", _MODES)
+def test_two_ranks_drop_an_overflowed_step_together(gpu, mode):
+    """in a sharded run a rank whose duplicate capacity overflowed holds a meaningless gradient, so the
+    MAX-reduced flag makes EVERY rank's optimiser launch a no-op; nobody re-runs the step, and the step counters (Adam's
+    bias-correction exponent, what a checkpoint stores) must count applied updates only -- corrected on every rank at the
+    same iteration (TrainingLoop._drain_dist_flags / flush).  Rank 1 is made to overflow at iteration 31 (after the last
+    densification): both ranks report the same dropped steps, the same corrected step count, and identical replicas."""
+    import re
+    import sys
+    root, tool, env = _two_rank_env()
+    out = _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--ar-chunks", "4", "--force-overflow", "31"], env)
+    assert "identical: True" in out, out
+    m = re.search(r"dist_dropped per rank (\d+) (\d+) xyz steps per rank (\d+) (\d+)", out)
+    assert m, out
+    d0, d1, s0, s1 = (int(x) for x in m.groups())
+    assert d0 == d1 and 1 <= d0 <= 2, out       # (each of rank 1's two views overflows once before its count is learnt anew)
+    base = _run([sys.executable, tool, "--ranks", "2", "--mode", mode, "--ar-chunks", "4"], env)
+    mb = re.search(r"dist_dropped per rank (\d+) (\d+) xyz steps per rank (\d+) (\d+)", base)
+    assert mb and int(mb.group(1)) == 0 and int(mb.group(2)) == 0
+    assert s0 == s1 == int(mb.group(3)) - d0, (out, base)
+
+
+@pytest.mark.parametrize("mode", _MODES)
 def test_two_ranks_bench_launcher(gpu, mode):
     """bench.py --gpus 2 launches its two ranks itself and reports what the process group saw."""
     import json

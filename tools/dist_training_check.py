@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--graph", default="auto", choices=["auto", "always", "off"],
                     help="TrainingLoop(graph=...): 'always' replays the sharded step's front as a hipGraph whenever possible")
     ap.add_argument("--densify-interval", type=int, default=6)
+    ap.add_argument("--force-overflow", type=int, default=0,
+                    help="at this iteration rank 1 pretends its view used to need a quarter of the duplicates: its capacity "
+                         "overflows, the MAX-reduced flag must make EVERY rank drop the step and correct its step counters")
     ap.add_argument("--depth-tv", type=float, default=0.0, help="lambda_depth_tv (one more collective per step in subframes mode)")
     ap.add_argument("--p2p-direct", action="store_true",
                     help="REPRODUCTION AID, not a product path: replace sharding._p2p by round 3's behaviour (batch_isend_irecv "
@@ -126,6 +129,10 @@ def main():
         snap["it"] = it
         torch.manual_seed(it if args.same_seed else 7919 * (rank + 1) + it)   # ranks draw DIFFERENT random numbers
         cam = (it + rank) % n_views if args.mode == "views" else it % n_views
+        if it == args.force_overflow and rank == min(1, world - 1) and loop._fused is not None:
+            loop._fused._poll(block=True)
+            assert loop._fused._seen, "no duplicate count learnt yet: nothing to shrink"
+            loop._fused._seen = {k: [max(c // 4, 1) for c in v] for k, v in loop._fused._seen.items()}
         out = loop.step(it, cam)
         sizes.append(out["num_points"])
     loop.flush()
@@ -140,7 +147,14 @@ def main():
         same = all(torch.equal(allsig[0], s) for s in allsig)
     moved = [float((p.detach() - q).abs().max()) for p, q in
              zip(m.parameters(), [torch.zeros_like(p) for p in m.parameters()])]
+    dropped = torch.tensor([float(loop.dist_dropped), float(cloud.optimizer.state[cloud._xyz]["step"])], device=dev,
+                           dtype=torch.float64)
+    all_dropped = [dropped.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(all_dropped, dropped)
     if rank == 0:
+        print("dist_dropped per rank " + " ".join(str(int(d[0])) for d in all_dropped) + " xyz steps per rank " +
+              " ".join(str(int(d[1])) for d in all_dropped), flush=True)
         import hashlib
         hsh = hashlib.sha1()
         for p_ in tensors:
