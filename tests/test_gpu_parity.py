@@ -182,6 +182,35 @@ def test_binning_bit_exact(scene_states):
     assert hip["sort_bits"] == 32 + __import__("oracle.oracle", fromlist=["x"]).higher_msb(T * sc["K"])
 
 
+def test_depth_order_beyond_27_key_bits_through_the_forward(gpu):
+    """The depth order sorts bits(depth) - bits(0.2f) in three 9-bit passes and switches a fourth one on, on the device, when
+    a visible key needs more than 27 bits (depth >= 13107).  Here a third of the cloud sits between 2e4 and 2e6 scene units
+    deep (far beyond z_far: the reference has no far cull, auxiliary.h:159): sort keys, point lists and tile ranges of the
+    whole forward stay bit-identical to the reference's, images agree, with and without tile culling."""
+    sc = small_scene(P=2500, W=160, H=120, K=2, seed=12, sigma_px=2.5)
+    rng = np.random.default_rng(12)
+    far = np.arange(sc["P"]) % 3 == 0
+    sc["means3D"][far] *= rng.uniform(5e3, 2e5, size=(int(far.sum()), 1)).astype(np.float32)     # same pixel, deeper
+    sc["scales"][far] *= 3e4                                                                       # ... and still a few pixels wide
+    hip = hip_forward_state(sc, sc["K"])
+    ora = [oracle_forward(sc, k) for k in range(sc["K"])]
+    deep = np.concatenate([o["depths"][o["radii"] > 0] for o in ora])
+    assert (deep > 13107.0).sum() > 200 and (deep < 13107.0).sum() > 200, "both key ranges must be populated"
+    T, off = hip["T"], 0
+    for k, o in enumerate(ora):
+        R = o["num_rendered"]
+        assert np.array_equal(hip["radii"][k], o["radii"])
+        assert np.array_equal(hip["keys"][off:off + R] - (np.uint64(k * T) << np.uint64(32)), o["keys"]), "sort keys"
+        assert np.array_equal(hip["point_list"][off:off + R], o["point_list"]), "point_list"
+        un = unstable_pixels(o)
+        assert np.abs(hip["color"][k] - o["color"]).max(axis=0)[~un].max() <= IMG_TOL
+        off += R
+    assert hip["R"] == off
+    cul = hip_forward_state(sc, sc["K"], cull=True)
+    for key in ("radii", "color", "final_T"):       # (n_contrib is a position in the list, which culling shortens)
+        assert np.array_equal(cul[key], hip[key]), key
+
+
 def test_forward_images(scene_states):
     sc, hip, ora = scene_states
     for k, o in enumerate(ora):
@@ -592,12 +621,12 @@ def test_pd_fast_path_on_near_singular_conics(gpu):
     # orders of magnitude below what a pair blended on one side and skipped on the other shows (alpha ~ 0.3-0.9) -- and
     # n_contrib / final_T are held exactly as everywhere else.
     for cull in (True, False):
-        with tile_cull(cull):
-            hip = hip_forward_state(sc, 1)
+        hip = hip_forward_state(sc, 1, cull=cull)
         dc = np.abs(hip["color"][0] - o["color"]).max(axis=0)
         print(f"[needles] tile_cull {cull}: colour off the unstable pixels {dc[~un].max():.2e}, on them {dc[un].max():.2e}")
         assert dc[~un].max() <= 2e-3, f"colour (tile_cull {cull}): {dc[~un].max()}"
-        assert np.array_equal(hip["n_contrib"][0][s], o["n_contrib"][s]), f"n_contrib (tile_cull {cull})"
+        if not cull:      # (with culling n_contrib is a position in the shorter list)
+            assert np.array_equal(hip["n_contrib"][0][s], o["n_contrib"][s]), "n_contrib"
         assert np.abs(hip["final_T"][0][s] - o["final_T"][s]).max() <= 1e-3
     run = OracleRun(sc, 1)
     gC, gD = run.mask(*_grads(sc, 1))
