@@ -93,6 +93,7 @@ class TrainingLoop:
         self.retried = 0            # dropped fused steps that were re-run through the exact path
         self.dist_dropped = 0       # sharded runs: steps every rank dropped together (no make-up; counters corrected)
         self._dist_flags = []
+        self._flag_words = []
         self._last_iteration = None
         self._front_failed = False  # the captured front of sharded steps was refused once: stay eager
         self._fused = None
@@ -251,7 +252,7 @@ class TrainingLoop:
                 # iterations later (_drain_dist_flags), on every rank at the same iteration, so that Adam's step counters
                 # -- the bias-correction exponent, the value stored in checkpoints -- count applied updates only and stay
                 # identical on all replicas.
-                h = torch.zeros(1, dtype=torch.int32).pin_memory()
+                h = self._flag_words.pop() if self._flag_words else torch.zeros(1, dtype=torch.int32).pin_memory()
                 h.copy_(flag[:1], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(dev))
@@ -294,6 +295,7 @@ class TrainingLoop:
             if int(h[0]) != 0:
                 self.dist_dropped += 1
                 self.gaussians.optimizer.note_skipped_steps(1)
+            self._flag_words.append(h)          # (pinned words are recycled: allocating one costs a driver call)
 
     def flush(self):
         """Call at the end of training and before writing a checkpoint (on every rank of a sharded run at the same
