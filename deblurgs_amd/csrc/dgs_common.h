@@ -108,32 +108,6 @@ __device__ __forceinline__ float dgs_wave_sum63(float v) {
 
 __device__ __forceinline__ int dgs_lane() { return (int)(threadIdx.x & 63); }
 
-// ---- reduce-scatter building blocks (gfx950 v_permlane{32,16}_swap + row DPP) -------------------------------------
-typedef unsigned int dgs_u2 __attribute__((ext_vector_type(2)));
-// lanes 0..31 <- a[l] + a[l+32];  lanes 32..63 <- b[l-32] + b[l]
-__device__ __forceinline__ float dgs_fold32(float a, float b) {
-  const dgs_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-// per 16-lane row: rows (0,1,2,3) <- (a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3)
-__device__ __forceinline__ float dgs_fold16(float a, float b) {
-  const dgs_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-// Folds inside a 16-lane row with bank-masked DPP adds (bank = 4 consecutive lanes; the masked add writes only the
-// enabled banks and leaves the others as they are): 2 VALU ops per fold.
-// lanes 0-7 <- a[l] + a[l+8];  lanes 8-15 <- b[l] + b[l-8]
-__device__ __forceinline__ float dgs_fold8(float a, float b) {
-  float t = a + dgs_dpp<0x128, 0xf>(a);  // row_ror:8
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(t) : "v"(b));
-  return t;
-}
-// banks 0 and 2 <- a[l] + a[m(l)];  banks 1 and 3 <- b[l] + b[m(l)],  m = mirror inside the 8-lane half row
-__device__ __forceinline__ float dgs_fold4(float a, float b) {
-  float t = a + dgs_dpp<0x141, 0xf>(a);  // row_half_mirror
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(t) : "v"(b));
-  return t;
-}
 // every lane of a quad <- the sum over the quad
 __device__ __forceinline__ float dgs_quad_sum(float v) {
   v += dgs_dpp<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
