@@ -11,6 +11,10 @@
 //         rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES -- tools/valu_rate 8
 //     gives the counter-side figure  SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)  per class
 //     (profiles/make_valu_peak.py puts the two side by side).
+//   * CAVEAT found with that cross-check (round 4): s_memtime does not tick at the core clock on this chip under load --
+//     the tool's own "instr/cycle/SIMD" come out ~2.3x above the counter figures (1.03 for v_mul_f32 where the counters say
+//     0.44 and the SIMD-32 peak is 0.5).  The ABSOLUTE rates are the counters' (profiles/valu_peak_r04.json); this program's
+//     printed figures are good for comparing classes and occupancies with each other only.
 //   * operand forms are separated: v_fma_f32 with three distinct VGPR sources, v_fmac_f32 (two sources + the
 //     accumulator), v_mul_f32 / v_add_f32 (two sources), because the register-file read ports, not the ALU, set the rate.
 //
