@@ -359,9 +359,8 @@ def run_rank(args):
                              shard=(rank, world) if subframes_mode else None)
         Pv_tot = int((probe["radii_all"] > 0).sum().item())
         del probe
-    # (N ranks, "views": the step up to its first collective is replayed -- FusedStep.replay_front; "subframes": eager)
-    replaying = ((world == 1 or not subframes_mode) and loop.graph and loop._fused is not None and
-                 not args.autograd_path and not args.no_graph)
+    # (N ranks: the step up to its first collective is replayed -- FusedStep.replay_front)
+    replaying = loop.graph and loop._fused is not None and not args.autograd_path and not args.no_graph
     dt = timed(args.steps, profile=not replaying)
     allreduce_ms = None
     if ar_events:

@@ -275,7 +275,8 @@ class FusedStep:
         self.replayed += 1
         return ent["result"]
 
-    def replay_front(self, cam_idx, lambda_t, gt, subframe_indice, ar, background=None, uniform=None):
+    def replay_front(self, cam_idx, lambda_t, gt, subframe_indice, ar, background=None, uniform=None, shard=None,
+                     background_dev=None, uniform_dev=None):
         """A SHARDED step ("views" mode) with everything up to its first collective replayed as one hipGraph: alignment ->
         cameras -> dgs_forward (capacity sized ahead) -> loss -> the compositing half of the backward
         (dgs_backward_composite; the whole dgs_backward when the bucket is reduced in one piece) -- then, eagerly, what
@@ -284,15 +285,26 @@ class FusedStep:
         its optimiser step follow as after run().  Bit-identical to the eager step (the same launches in the same order on
         the same stream); what it saves is the ~20 ctypes calls and driver round trips of the front, 0.2-0.3 ms per step.
 
-        Returns run()'s result dict ('subframes', 'blur' and 'depths' are None: the images live in the graph's pool), or
-        None when the step cannot be replayed yet (no duplicate count learnt for the view)."""
+        shard = (rank, world): "subframes" sharding.  Its first collective is the loss block, so the captured front ends
+        with the forward of this rank's slice of the cameras; the background and the alignment jitter are rank 0's draws and
+        arrive as DEVICE tensors (background_dev, uniform_dev: TrainingLoop._shared_draws), copied into the graph's scalar
+        block on the stream.  A rank whose slice is empty is not captured (None).
+
+        Returns run()'s result dict ('subframes', 'blur' and 'depths' are None in "views" mode: the images live in the
+        graph's pool), or None when the step cannot be replayed yet (no duplicate count learnt for the view)."""
         cloud, m = self.cloud, self.motion
         dev = cloud._xyz.device
         f = m.n_subframes
         self._poll()
         K_total = f if (isinstance(subframe_indice, str) and subframe_indice == "all") else (
             int(subframe_indice) if isinstance(subframe_indice, int) else len(subframe_indice))
-        ckey = (int(cam_idx), K_total, 0)
+        k0 = 0
+        if shard is not None:
+            from .sharding import shard_range
+            k0, k1 = shard_range(K_total, int(shard[0]), int(shard[1]))
+            if k1 <= k0:
+                return None
+        ckey = (int(cam_idx), K_total, k0)
         cap = self._capacity(ckey) if self.speculative else None
         if cap is None or isinstance(subframe_indice, (list, tuple)) or torch.is_tensor(subframe_indice):
             return None
@@ -303,10 +315,11 @@ class FusedStep:
         chunks = 1 if ar is None else int(ar.get("chunks", 1))
         gkey = ("front", int(cam_idx), subframe_indice, int(cloud.active_sh_degree), bool(m.is_optimizing()),
                 bool(m.curve_random_sample), cap, self._generation, gt.data_ptr(), bool(cull), bool(dgr.WIDE_RECORDS),
-                tuple(p.data_ptr() for p in hot), chunks, float(self.lambda_hinge))
+                tuple(p.data_ptr() for p in hot), chunks, float(self.lambda_hinge),
+                None if shard is None else (int(shard[0]), int(shard[1])))
         ent = self._graphs.get(gkey)
         if ent is None:
-            ent = self._capture_front(gkey, cam_idx, gt, subframe_indice, cap, ar, K_total)
+            ent = self._capture_front(gkey, cam_idx, gt, subframe_indice, cap, ar, K_total, shard)
         slot = self._ring[self._ring_pos % len(self._ring)] if self._ring else None
         if slot is None or slot[0].numel() != ent["hyper"].numel():
             self._ring = [(torch.zeros(ent["hyper"].numel(), dtype=torch.float32).pin_memory(), torch.cuda.Event())
@@ -323,6 +336,10 @@ class FusedStep:
             hv[48:48 + f - 2] = (torch.rand(f - 2) if uniform is None else uniform.detach().float().cpu()).numpy()
         ent["hyper"].copy_(hbuf, non_blocking=True)
         hev.record(torch.cuda.current_stream(dev))
+        if background_dev is not None:               # (shared draws of a "subframes" step: device to device, stream-ordered)
+            ent["hyper"][1:4].copy_(background_dev.reshape(3))
+        if uniform_dev is not None and m.curve_random_sample and f > 2:
+            ent["hyper"][48:48 + f - 2].copy_(uniform_dev.reshape(f - 2))
         ent["graph"].replay()
         pnd = _Pending()
         pnd.host, pnd.speculative, pnd.key, pnd.generation = ent["host"], True, ckey, self._generation
@@ -333,9 +350,9 @@ class FusedStep:
         self._pending.append(pnd)
         self.last_capacity = cap
         self.replayed += 1
-        return ent["finish"]()
+        return ent["finish"](float(lambda_t))
 
-    def _capture_front(self, gkey, cam_idx, gt, subframe_indice, cap, ar, K_total):
+    def _capture_front(self, gkey, cam_idx, gt, subframe_indice, cap, ar, K_total, shard=None):
         cloud, m = self.cloud, self.motion
         dev = cloud._xyz.device
         f = m.n_subframes
@@ -366,7 +383,8 @@ class FusedStep:
                                   torch.zeros(1, dtype=torch.int32, device=dev))
         ent["work"] = torch.zeros(8, dtype=torch.float32, device=dev)
         cap_args = {"capacity": cap, "host": host, "lambda_ptr": hyper.data_ptr(), "work": ent["work"],
-                    "bucket": self._bucket[2], "split": True, "radii": self._front_shared[1],
+                    "bucket": self._bucket[2], "split": "composite" if shard is None else "forward",
+                    "radii": self._front_shared[1],
                     "means2D": self._front_shared[2], "skipw": self._front_shared[3], "tail": None}
         bg = hyper[1:4]
         uniform = hyper[48:48 + f - 2] if (m.curve_random_sample and f > 2) else None
@@ -375,11 +393,13 @@ class FusedStep:
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
-            front = self.run(cam_idx, 0.0, gt, bg, subframe_indice, uniform=uniform, _cap=cap_args, ar=ar)
+            front = self.run(cam_idx, 0.0, gt, bg, subframe_indice, uniform=uniform, _cap=cap_args, ar=ar, shard=shard)
         # the step's large buffers go back to the pool (the other views' captures re-use the blocks); finish() reaches them
         # through the raw pointers of its DgsProblem / DgsBackwardIO -- valid until the next replay of ANY graph of the pool,
         # which is enqueued after this step's eager part on the same stream
         front["big"][0] = None
+        if "fwd_big" in front:
+            front["fwd_big"][0] = None
         ent["graph"], ent["finish"], ent["keep"] = graph, front["finish"], front["_keep"]
         self._keep = None
         self._graphs[gkey] = ent
@@ -534,7 +554,7 @@ class FusedStep:
         # loss, lambda_depth_tv = 0, never looks at them: train.py:150-153)
         depth = torch.empty((K, 1, H, W), **f32) if (need_depth or lambda_depth_tv > 0.0) else None
         radii = (torch.empty((K, P), dtype=torch.int32, device=dev) if (_cap is None or "radii" not in _cap)
-                 else _cap["radii"])
+                 else _cap["radii"][:K])
         geom = torch.empty(L.dgs_geom_state_bytes(P, K), dtype=torch.uint8, device=dev)
         image = torch.empty(L.dgs_image_state_bytes(W, H, K), dtype=torch.uint8, device=dev)
         bg = background.to(dev, torch.float32).contiguous()
@@ -588,172 +608,194 @@ class FusedStep:
             self._pending.append(pnd)
         self.last_capacity = R
 
-        # ---- loss: blur, both values and dL/dsubframes in one pass (train.py:143-165 image terms)
-        gtc = gt.to(dev, torch.float32).contiguous()
-        blur = torch.empty((3, H, W), **f32)
-        dsub = torch.empty((K, 3, H, W), **f32)
-        # dgs_blur_loss_grad's work area: [l1, smooth | accumulators, counter]
-        work = torch.empty(8, **f32) if _cap is None else _cap["work"]
-        losses = work[:2]
-        if _cap is not None:      # the scheduled weight is read from device memory when the replayed kernel runs
-            _lib.check(L.dgs_blur_loss_grad_dev(_ptr(color), _ptr(gtc), K, 3, H * W, ctypes.c_void_p(_cap["lambda_ptr"]),
-                                                None, _ptr(blur), _ptr(dsub), _ptr(work), stream),
-                       "dgs_blur_loss_grad_dev")
-        elif shard is None:
-            _lib.check(L.dgs_blur_loss_grad(_ptr(color), _ptr(gtc), K, 3, H * W, float(lambda_t), None, _ptr(blur),
-                                            _ptr(dsub), _ptr(work), stream), "dgs_blur_loss_grad")
-        else:   # the loss block across the ranks holding the view's other subframes
-            from . import sharding
-            dsub, l1, sm = sharding.subframe_sharded_loss_grad(color, gtc, K_total, float(lambda_t))
-            dsub = dsub.contiguous()
-            losses = torch.stack([l1.reshape(()), sm.reshape(())]).float()
-            blur = None
-
-        # ---- backward: one flat gradient bucket in optimiser-group order (as _RasterizeCloudK.backward)
-        sizes = [3 * P, 3 * P, 3 * Mr * P, P, 3 * P, 4 * P]
-        offs = [0]
-        for n in sizes:
-            offs.append(offs[-1] + (n + 3) // 4 * 4)
-        flat = torch.empty(offs[-1], **f32) if _cap is None else _cap["bucket"]
-        assert flat.numel() == offs[-1]
-        seg = lambda i, shape: flat[offs[i]:offs[i] + sizes[i]].view(shape)
-        g_xyz, g_dc, g_op, g_sc, g_rot = (seg(0, (P, 3)), seg(1, cloud._features_dc.shape), seg(3, cloud._opacity.shape),
-                                          seg(4, (P, 3)), seg(5, (P, 4)))
-        g_rest = seg(2, cloud._features_rest.shape)
-        g_means2D = None if stats is not None else (torch.empty((K, P, 3), **f32) if (_cap is None or "means2D" not in _cap)
-                                                    else _cap["means2D"])
-        g_colors = torch.empty((P, 3), **f32)
-        g_cov3D = torch.empty((P, 6), **f32)
-        g_view, g_proj = torch.empty((K, 4, 4), **f32), torch.empty((K, 4, 4), **f32)
-        scratch = torch.empty(L.dgs_backward_scratch_bytes(R, P, K), dtype=torch.uint8, device=dev)
-        io = _lib.DgsBackwardIO()
-        io.num_rendered = R
-        depth_tv, g_depth = None, None
-        if lambda_depth_tv > 0.0:
-            from . import losses as _losses
-            # tv_loss is a mean over the view's K depth images of per-image terms (utils/loss_utils.py:66-78): a rank
-            # holding K of the K_total subframes contributes K / K_total of it and needs no other rank's depths
-            share = K / float(K_total)
-            with torch.enable_grad():
-                dleaf = depth.detach().requires_grad_(True)
-                depth_tv = _losses.tv_loss(dleaf) * share
-                g_depth, = torch.autograd.grad(float(lambda_depth_tv) * depth_tv, dleaf)
-            g_depth, depth_tv = g_depth.contiguous(), depth_tv.detach()
-            if shard is not None:
-                import torch.distributed as dist
-                dist.all_reduce(depth_tv)          # the value only (logging); the gradient is local
-        io.radii, io.dL_dout_color, io.dL_dout_depth = ctypes.c_void_p(radii.data_ptr()), _ptr(dsub), _ptr(g_depth)
-        io.scratch, io.scratch_bytes = ctypes.c_void_p(scratch.data_ptr()), scratch.numel()
-        io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh = _ptr(g_xyz), _ptr(g_means2D), _ptr(g_dc)
-        io.dL_dsh_rest = _ptr(g_rest) if Mr > 0 else None
-        io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations = _ptr(g_colors), _ptr(g_op), _ptr(g_sc), _ptr(g_rot)
-        io.dL_dcov3D, io.dL_dviewmatrix, io.dL_dprojmatrix = _ptr(g_cov3D), _ptr(g_view), _ptr(g_proj)
-        # sharded: the ranks' gradients are summed, so the hinge term is added by one of them only
-        io.opacity_hinge_scale = self.lambda_hinge / max(P, 1) if (shard is None or int(shard[0]) == 0) else 0.0
-        if stats is not None:
-            io.stats_max_radii2D, io.stats_grad_accum, io.stats_denom = (_ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]))
-            io.stats_K_total = int(K_total)
-        # ---- the launches up to the first collective ...
-        chunked = not (ar is None or int(ar.get("chunks", 1)) <= 1 or P < 512)
-        if chunked:
-            _lib.check(L.dgs_backward_composite(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_composite")
-        else:
-            _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward")
-        split = _cap is not None and bool(_cap.get("split"))
-        # the step's large buffers, held through a one-element list: a captured front (replay_front) empties it after the
-        # capture so that they go back to the graph pool, and finish() below touches them through prob / io only
-        big = [(geom, image, binning, scratch, color, depth, dsub, blur, g_colors, g_cov3D)]
-        skip_flag = None
+        # The forward's three state blobs and the skip word, held through one-element lists: a captured front empties the
+        # first after the capture, and what follows reaches them through the raw pointers of prob / io only.
+        fwd_big = [(geom, image, binning)]
+        fwd_skip = [None]
         if skip_ptr is not None:
             off = skip_ptr - geom.data_ptr()
-            skip_flag = geom[off:off + 4].view(torch.int32)
-            if split:          # a word of its own, outside the pool (the view above would pin the whole geometry blob)
+            fwd_skip[0] = geom[off:off + 4].view(torch.int32)
+            if _cap is not None and _cap.get("split") == "forward":     # (the view would pin the whole geometry blob)
+                _cap["skipw"].copy_(fwd_skip[0])
+                fwd_skip[0] = _cap["skipw"]
+        del geom, image, binning
+
+        # Everything after the forward.  Eager steps run it right away.  A "subframes"-sharded step replayed by replay_front
+        # captures only what precedes it (its first collective is the loss block) and calls it after every replay; a
+        # "views"-sharded one captures on, up to the cut inside (finish()).
+        def after_forward(lambda_now=None):
+            stream_obj = torch.cuda.current_stream(dev)       # (the stream of THIS call, not of a capture)
+            stream = ctypes.c_void_p(stream_obj.cuda_stream)
+            lam = float(lambda_t if lambda_now is None else lambda_now)     # (a replayed front hands in this step's weight)
+            # ---- loss: blur, both values and dL/dsubframes in one pass (train.py:143-165 image terms)
+            gtc = gt.to(dev, torch.float32).contiguous()
+            blur = torch.empty((3, H, W), **f32)
+            dsub = torch.empty((K, 3, H, W), **f32)
+            # dgs_blur_loss_grad's work area: [l1, smooth | accumulators, counter]
+            work = torch.empty(8, **f32) if _cap is None else _cap["work"]
+            losses = work[:2]
+            if _cap is not None and shard is None:      # the scheduled weight is read from device memory when the replayed kernel runs
+                _lib.check(L.dgs_blur_loss_grad_dev(_ptr(color), _ptr(gtc), K, 3, H * W, ctypes.c_void_p(_cap["lambda_ptr"]),
+                                                    None, _ptr(blur), _ptr(dsub), _ptr(work), stream),
+                           "dgs_blur_loss_grad_dev")
+            elif shard is None:
+                _lib.check(L.dgs_blur_loss_grad(_ptr(color), _ptr(gtc), K, 3, H * W, lam, None, _ptr(blur),
+                                                _ptr(dsub), _ptr(work), stream), "dgs_blur_loss_grad")
+            else:   # the loss block across the ranks holding the view's other subframes
+                from . import sharding
+                dsub, l1, sm = sharding.subframe_sharded_loss_grad(color, gtc, K_total, lam)
+                dsub = dsub.contiguous()
+                losses = torch.stack([l1.reshape(()), sm.reshape(())]).float()
+                blur = None
+
+            # ---- backward: one flat gradient bucket in optimiser-group order (as _RasterizeCloudK.backward)
+            sizes = [3 * P, 3 * P, 3 * Mr * P, P, 3 * P, 4 * P]
+            offs = [0]
+            for n in sizes:
+                offs.append(offs[-1] + (n + 3) // 4 * 4)
+            flat = torch.empty(offs[-1], **f32) if _cap is None else _cap["bucket"]
+            assert flat.numel() == offs[-1]
+            seg = lambda i, shape: flat[offs[i]:offs[i] + sizes[i]].view(shape)
+            g_xyz, g_dc, g_op, g_sc, g_rot = (seg(0, (P, 3)), seg(1, cloud._features_dc.shape), seg(3, cloud._opacity.shape),
+                                              seg(4, (P, 3)), seg(5, (P, 4)))
+            g_rest = seg(2, cloud._features_rest.shape)
+            g_means2D = None if stats is not None else (torch.empty((K, P, 3), **f32) if (_cap is None or "means2D" not in _cap)
+                                                        else _cap["means2D"][:K])
+            g_colors = torch.empty((P, 3), **f32)
+            g_cov3D = torch.empty((P, 6), **f32)
+            g_view, g_proj = torch.empty((K, 4, 4), **f32), torch.empty((K, 4, 4), **f32)
+            scratch = torch.empty(L.dgs_backward_scratch_bytes(R, P, K), dtype=torch.uint8, device=dev)
+            io = _lib.DgsBackwardIO()
+            io.num_rendered = R
+            depth_tv, g_depth = None, None
+            if lambda_depth_tv > 0.0:
+                from . import losses as _losses
+                # tv_loss is a mean over the view's K depth images of per-image terms (utils/loss_utils.py:66-78): a rank
+                # holding K of the K_total subframes contributes K / K_total of it and needs no other rank's depths
+                share = K / float(K_total)
+                with torch.enable_grad():
+                    dleaf = depth.detach().requires_grad_(True)
+                    depth_tv = _losses.tv_loss(dleaf) * share
+                    g_depth, = torch.autograd.grad(float(lambda_depth_tv) * depth_tv, dleaf)
+                g_depth, depth_tv = g_depth.contiguous(), depth_tv.detach()
+                if shard is not None:
+                    import torch.distributed as dist
+                    dist.all_reduce(depth_tv)          # the value only (logging); the gradient is local
+            io.radii, io.dL_dout_color, io.dL_dout_depth = ctypes.c_void_p(radii.data_ptr()), _ptr(dsub), _ptr(g_depth)
+            io.scratch, io.scratch_bytes = ctypes.c_void_p(scratch.data_ptr()), scratch.numel()
+            io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh = _ptr(g_xyz), _ptr(g_means2D), _ptr(g_dc)
+            io.dL_dsh_rest = _ptr(g_rest) if Mr > 0 else None
+            io.dL_dcolors, io.dL_dopacity, io.dL_dscales, io.dL_drotations = _ptr(g_colors), _ptr(g_op), _ptr(g_sc), _ptr(g_rot)
+            io.dL_dcov3D, io.dL_dviewmatrix, io.dL_dprojmatrix = _ptr(g_cov3D), _ptr(g_view), _ptr(g_proj)
+            # sharded: the ranks' gradients are summed, so the hinge term is added by one of them only
+            io.opacity_hinge_scale = self.lambda_hinge / max(P, 1) if (shard is None or int(shard[0]) == 0) else 0.0
+            if stats is not None:
+                io.stats_max_radii2D, io.stats_grad_accum, io.stats_denom = (_ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]))
+                io.stats_K_total = int(K_total)
+            # ---- the launches up to the first collective ...
+            chunked = not (ar is None or int(ar.get("chunks", 1)) <= 1 or P < 512)
+            if chunked:
+                _lib.check(L.dgs_backward_composite(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_composite")
+            else:
+                _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward")
+            split = _cap is not None and _cap.get("split") == "composite"
+            # the step's large buffers, held through a one-element list: a captured front (replay_front) empties it after the
+            # capture so that they go back to the graph pool, and finish() below touches them through prob / io only
+            big = [(tuple(fwd_big[0]) if fwd_big[0] is not None else (None, None, None)) +
+                   (scratch, color, depth, dsub, blur, g_colors, g_cov3D)]
+            skip_flag = fwd_skip[0]
+            if split and skip_flag is not None:   # a word of its own, outside the pool (the view would pin the whole geometry blob)
                 _cap["skipw"].copy_(skip_flag)
                 skip_flag = _cap["skipw"]
 
-        # ---- ... and everything after it (a sharded run's reduction of the bucket, overlapped with the per-Gaussian half
-        # of the backward when `chunked`; then the camera gradients).  Eager steps run it right away; a captured front
-        # (replay_front) replays the launches above as one hipGraph and calls this after every replay.
-        def finish():
-            # (the stream of THIS call: a captured front was recorded on torch's capture stream, its eager part runs on the
-            # caller's stream, behind the replay)
-            stream_obj = torch.cuda.current_stream(dev)
-            stream = ctypes.c_void_p(stream_obj.cuda_stream)
-            if chunked:
-                from . import sharding
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=dev)
-                side = self._side
-                flat.record_stream(side)
-                widths = [3, 3, 3 * Mr, 1, 3, 4]
-                t_ar = None
-                if self.time_allreduce:  # (bench.py: span of the side stream's reductions, first chunk ready -> last done)
-                    t_ar = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                for ci, (b0, b1) in enumerate(sharding.chunk_bounds(P, int(ar["chunks"]))):
-                    _lib.check(L.dgs_backward_geometry(ctypes.byref(prob), ctypes.byref(io), b0, b1, stream),
-                               "dgs_backward_geometry")
-                    ev = torch.cuda.Event()
-                    ev.record(stream_obj)
-                    with torch.cuda.stream(side):
-                        side.wait_event(ev)
-                        if t_ar is not None and ci == 0:
-                            t_ar[0].record(side)
-                        sharding.allreduce_slices([flat[offs[i] + b0 * c:offs[i] + b1 * c] for i, c in enumerate(widths)],
-                                                  bool(ar.get("average", False)), ar.get("group"))
-                _lib.check(L.dgs_backward_pose(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_pose")
-                done = torch.cuda.Event()
-                done.record(side)
-                if t_ar is not None:
-                    t_ar[1].record(side)
-                    self.ar_events = (self.ar_events + [t_ar])[-256:]
-                stream_obj.wait_event(done)
-            elif ar is not None and P > 0:
-                from . import sharding
-                sharding._allreduce(flat, bool(ar.get("average", False)), ar.get("group"))
-            if P == 0:
-                flat.zero_()
-                if g_means2D is not None:
-                    g_means2D.zero_()
-            cloud._xyz.grad, cloud._features_dc.grad, cloud._features_rest.grad = g_xyz, g_dc, g_rest
-            cloud._opacity.grad, cloud._scaling.grad, cloud._rotation.grad = g_op, g_sc, g_rot
+            # ---- ... and everything after it (a sharded run's reduction of the bucket, overlapped with the per-Gaussian half
+            # of the backward when `chunked`; then the camera gradients).  Eager steps run it right away; a captured front
+            # (replay_front) replays the launches above as one hipGraph and calls this after every replay.
+            def finish(lambda_now=None):
+                # (the stream of THIS call: a captured front was recorded on torch's capture stream, its eager part runs on the
+                # caller's stream, behind the replay)
+                stream_obj = torch.cuda.current_stream(dev)
+                stream = ctypes.c_void_p(stream_obj.cuda_stream)
+                if chunked:
+                    from . import sharding
+                    if self._side is None:
+                        self._side = torch.cuda.Stream(device=dev)
+                    side = self._side
+                    flat.record_stream(side)
+                    widths = [3, 3, 3 * Mr, 1, 3, 4]
+                    t_ar = None
+                    if self.time_allreduce:  # (bench.py: span of the side stream's reductions, first chunk ready -> last done)
+                        t_ar = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    for ci, (b0, b1) in enumerate(sharding.chunk_bounds(P, int(ar["chunks"]))):
+                        _lib.check(L.dgs_backward_geometry(ctypes.byref(prob), ctypes.byref(io), b0, b1, stream),
+                                   "dgs_backward_geometry")
+                        ev = torch.cuda.Event()
+                        ev.record(stream_obj)
+                        with torch.cuda.stream(side):
+                            side.wait_event(ev)
+                            if t_ar is not None and ci == 0:
+                                t_ar[0].record(side)
+                            sharding.allreduce_slices([flat[offs[i] + b0 * c:offs[i] + b1 * c] for i, c in enumerate(widths)],
+                                                      bool(ar.get("average", False)), ar.get("group"))
+                    _lib.check(L.dgs_backward_pose(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_pose")
+                    done = torch.cuda.Event()
+                    done.record(side)
+                    if t_ar is not None:
+                        t_ar[1].record(side)
+                        self.ar_events = (self.ar_events + [t_ar])[-256:]
+                    stream_obj.wait_event(done)
+                elif ar is not None and P > 0:
+                    from . import sharding
+                    sharding._allreduce(flat, bool(ar.get("average", False)), ar.get("group"))
+                if P == 0:
+                    flat.zero_()
+                    if g_means2D is not None:
+                        g_means2D.zero_()
+                cloud._xyz.grad, cloud._features_dc.grad, cloud._features_rest.grad = g_xyz, g_dc, g_rest
+                cloud._opacity.grad, cloud._scaling.grad, cloud._rotation.grad = g_op, g_sc, g_rot
 
-            # ---- cameras -> control points and alignment (only while the trajectory is being optimised)
-            if m.is_optimizing():
-                d_ct_all, d_cr_all = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
-                d_nu = torch.empty(K, **f32)
-                pscratch = torch.empty(L.dgs_pose_scratch_bytes(K), dtype=torch.uint8, device=dev)
-                _lib.check(L.dgs_pose_backward(_ptr(ct_all, row), _ptr(cr_all, rrow), _ptr(nu_loc), _ptr(proj), C, K, quat,
-                                               _ptr(g_view),
-                                               _ptr(g_proj), ctypes.c_void_p(pscratch.data_ptr()), _ptr(d_ct_all, row),
-                                               _ptr(d_cr_all, rrow), _ptr(d_nu), stream), "dgs_pose_backward")
-                m._trans._control_points.grad, m._rot._control_points.grad = d_ct_all, d_cr_all
-                if nrow > 0:
-                    d_raw_all = torch.zeros_like(nu_raw)
-                    if shard is not None:                    # this rank's slice of the view's subframe times
-                        d_all = torch.zeros(K_total, **f32)
-                        d_all[k0:k0 + K] = d_nu
-                        d_nu = d_all
-                    if sel is not None:                      # gradients of the selected subframes back to all f slots
-                        d_full = torch.zeros(f, **f32)
-                        d_full.index_add_(0, sel, d_nu)
-                        d_nu = d_full
-                    _lib.check(L.dgs_alignment_backward(raw_ptr, _ptr(uniform), f, f, _ptr(src), _ptr(d_nu),
-                                                        _ptr(d_raw_all, cam * nrow), stream), "dgs_alignment_backward")
-                    m._nu.grad = d_raw_all
-            held = big[0]
-            self._keep = (tuple(held[:7]) if held is not None else (None,) * 7) + (view, full, campos, nu, gtc, bg, flat, g_depth)
-            return {"losses": losses, "blur": held[7] if (need_blur and held is not None) else None, "radii": radii,
-                    "viewspace_grad": g_means2D, "K": K_total, "subframes": held[4] if held is not None else None,
-                    "depths": held[5] if held is not None else None, "skip_flag_ptr": skip_ptr, "skip_flag": skip_flag,
-                    "depth_tv": depth_tv}
+                # ---- cameras -> control points and alignment (only while the trajectory is being optimised)
+                if m.is_optimizing():
+                    d_ct_all, d_cr_all = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
+                    d_nu = torch.empty(K, **f32)
+                    pscratch = torch.empty(L.dgs_pose_scratch_bytes(K), dtype=torch.uint8, device=dev)
+                    _lib.check(L.dgs_pose_backward(_ptr(ct_all, row), _ptr(cr_all, rrow), _ptr(nu_loc), _ptr(proj), C, K, quat,
+                                                   _ptr(g_view),
+                                                   _ptr(g_proj), ctypes.c_void_p(pscratch.data_ptr()), _ptr(d_ct_all, row),
+                                                   _ptr(d_cr_all, rrow), _ptr(d_nu), stream), "dgs_pose_backward")
+                    m._trans._control_points.grad, m._rot._control_points.grad = d_ct_all, d_cr_all
+                    if nrow > 0:
+                        d_raw_all = torch.zeros_like(nu_raw)
+                        if shard is not None:                    # this rank's slice of the view's subframe times
+                            d_all = torch.zeros(K_total, **f32)
+                            d_all[k0:k0 + K] = d_nu
+                            d_nu = d_all
+                        if sel is not None:                      # gradients of the selected subframes back to all f slots
+                            d_full = torch.zeros(f, **f32)
+                            d_full.index_add_(0, sel, d_nu)
+                            d_nu = d_full
+                        _lib.check(L.dgs_alignment_backward(raw_ptr, _ptr(uniform), f, f, _ptr(src), _ptr(d_nu),
+                                                            _ptr(d_raw_all, cam * nrow), stream), "dgs_alignment_backward")
+                        m._nu.grad = d_raw_all
+                held = big[0]
+                self._keep = (tuple(held[:7]) if held is not None else (None,) * 7) + (view, full, campos, nu, gtc, bg, flat, g_depth)
+                return {"losses": losses, "blur": held[7] if (need_blur and held is not None) else None, "radii": radii,
+                        "viewspace_grad": g_means2D, "K": K_total, "subframes": held[4] if held is not None else None,
+                        "depths": held[5] if held is not None else None, "skip_flag_ptr": skip_ptr, "skip_flag": skip_flag,
+                        "depth_tv": depth_tv}
 
-        if split:
-            return {"finish": finish, "big": big,
-                    "_keep": (nu_all, src, proj, work, g_view, g_proj, sel, uniform, view, full, campos, nu, gtc, bg)}
-        fr = finish()
-        if _cap is not None:
-            fr["_keep"] = self._keep + (nu_all, src, proj, work, blur, g_colors, g_cov3D, g_view, g_proj, radii,
-                                        g_means2D, sel, uniform)
-            if _cap.get("tail") is not None:
-                _cap["tail"](fr)
-        return fr
+            if split:
+                return {"finish": finish, "big": big, "fwd_big": fwd_big,
+                        "_keep": (nu_all, src, proj, work, g_view, g_proj, sel, uniform, view, full, campos, nu, gtc, bg)}
+            fr = finish()
+            if _cap is not None:
+                fr["_keep"] = self._keep + (nu_all, src, proj, work, blur, g_colors, g_cov3D, g_view, g_proj, radii,
+                                            g_means2D, sel, uniform)
+                if _cap.get("tail") is not None:
+                    _cap["tail"](fr)
+            return fr
+
+        if _cap is not None and _cap.get("split") == "forward":
+            return {"finish": after_forward, "big": fwd_big,
+                    "_keep": (nu_all, src, proj, view, full, campos, nu, bg, color, depth, radii)}
+        return after_forward()

@@ -210,14 +210,16 @@ class TrainingLoop:
         if iteration < self.opt.densify_until_iter and not self.distributed:
             stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom)
         fr = None
-        if (self.graph and not exact and self.mode == "views" and not self._front_failed and
+        if (self.graph and not exact and self.distributed and not self._front_failed and
                 self._graphable(iteration, sharded=True)):
             # sharded step: everything up to the first collective as one hipGraph, the reductions and what depends on
             # them eagerly (FusedStep.replay_front); None = no duplicate count learnt for this view yet
             captured_before = self._fused.captured
             try:
                 fr = self._fused.replay_front(cam_idx, lambda_t_smooth, gt, subframe_indice, ar, background=bg_host,
-                                              uniform=uni_host)
+                                              uniform=uni_host, shard=shard,
+                                              background_dev=bg if shard is not None else None,
+                                              uniform_dev=uniform if shard is not None else None)
             except RuntimeError as ex:
                 # A capture that the runtime refuses (e.g. a collective library that does not tolerate a capturing
                 # stream next to it) must not take an N-rank run down: nothing of the step has been enqueued when a

@@ -974,17 +974,18 @@ def test_two_ranks_same_collective_order_on_a_rank_without_subframes(gpu):
     assert "identical: True" in out, out
 
 
-@pytest.mark.parametrize("chunks", [1, 4])
-def test_two_ranks_captured_front_equals_the_eager_sharded_step(gpu, chunks, tmp_path):
-    """Sharded "views" steps with everything up to the first collective replayed as one hipGraph (FusedStep.replay_front)
-    against the same run enqueued eagerly: parameters of both ranks bit-identical after 30 iterations that include
-    densifications (graphs dropped and re-captured), both with the bucket reduced in one piece and in four overlapped chunks;
-    and the graph run did replay."""
+@pytest.mark.parametrize("mode,chunks", [("views", 1), ("views", 4), ("subframes", 4)])
+def test_two_ranks_captured_front_equals_the_eager_sharded_step(gpu, mode, chunks, tmp_path):
+    """Sharded steps with everything up to the first collective replayed as one hipGraph (FusedStep.replay_front: "views"
+    through the compositing half of the backward, "subframes" through the forward) against the same run enqueued eagerly:
+    parameters of both ranks bit-identical after 30 iterations that include densifications (graphs dropped and re-captured),
+    with the bucket reduced in one piece and in four overlapped chunks; and the graph run did replay."""
     import sys
     import torch
     root, tool, env = _two_rank_env()
     a, b = str(tmp_path / "eager.pt"), str(tmp_path / "graph.pt")
-    common = ["--ranks", "2", "--mode", "views", "--iters", "30", "--ar-chunks", str(chunks), "--densify-interval", "12"]
+    common = ["--ranks", "2", "--mode", mode, "--iters", "30", "--ar-chunks", str(chunks), "--densify-interval", "12",
+              "--random-sample"]
     _run([sys.executable, tool] + common + ["--graph", "off", "--out", a], env)
     out = _run([sys.executable, tool] + common + ["--graph", "always", "--out", b], env)
     assert "identical: True" in out and "densified: True" in out, out
@@ -1031,5 +1032,5 @@ def test_two_ranks_bench_launcher(gpu, mode):
     assert line["scaling"] == ("weak" if mode == "views" else "strong") and line["config"]["sharding"] == mode
     assert line["config"]["allreduce_ms_per_step"] is not None and line["value"] > 0
     assert line["config"]["ar_chunks"] == 4
-    if mode == "views":      # the step up to its first collective was replayed as a captured hipGraph (FusedStep.replay_front)
-        assert line["config"]["graph"] is not None and line["config"]["graph"]["replayed"] > 0, line["config"]["graph"]
+    # the step up to its first collective was replayed as a captured hipGraph (FusedStep.replay_front)
+    assert line["config"]["graph"] is not None and line["config"]["graph"]["replayed"] > 0, line["config"]["graph"]
