@@ -40,7 +40,8 @@ class DgsProblem(ctypes.Structure):
 
 class DgsForwardOut(ctypes.Structure):
     _fields_ = [("out_color", ctypes.c_void_p), ("out_depth", ctypes.c_void_p), ("radii", ctypes.c_void_p),
-                ("num_rendered_host", ctypes.c_void_p), ("drop_counter", ctypes.c_void_p)]
+                ("num_rendered_host", ctypes.c_void_p), ("drop_counter", ctypes.c_void_p),
+                ("status_dev", ctypes.c_void_p)]
 
 
 class DgsBackwardIO(ctypes.Structure):
@@ -78,7 +79,7 @@ class DgsCloudArrays(ctypes.Structure):
 
 
 ADAM_MAX_GROUPS = 16
-ABI_VERSION = 10           # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
+ABI_VERSION = 11           # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
 
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {

@@ -668,7 +668,7 @@ static int forward_capacity_impl(const DgsProblem* p, const DgsForwardOut* out, 
     make_layout(p->P, p->W, p->H, p->K, 0, p->wide_records != 0, &L);
     DgsCarve c;
     carve(p, L, &c);
-    hipError_t e = dgs_launch_finalize_count(c, p->tile_cull != 0, capacity, out->drop_counter, s);
+    hipError_t e = dgs_launch_finalize_count(c, p->tile_cull != 0, capacity, out->drop_counter, out->status_dev, s);
     if (e == hipSuccess && out->drop_counter != nullptr)   // [4] = overflowed forwards so far (caller's running counter)
       e = hipMemcpyAsync(out->num_rendered_host + 4, out->drop_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess)   // [2] = overflow flag, [3] = the count the lists were built with (0 on overflow)

@@ -630,12 +630,20 @@ cull_emit_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __r
 // (tile_cull; [0], [1] stay 0 then), [4] the count
 // the sort / ranges kernels use = min(count, capacity), [5] overflow flag (the lists are truncated: every consumer that
 // indexes by duplicate offset returns early, the caller re-runs with a larger capacity).
-__global__ void finalize_count_kernel(uint32_t* __restrict__ nr, int cull, uint32_t cap, uint32_t* __restrict__ drops) {
+__global__ void finalize_count_kernel(uint32_t* __restrict__ nr, int cull, uint32_t cap, uint32_t* __restrict__ drops,
+                                      uint32_t* __restrict__ status) {
   const uint32_t n = cull ? nr[2] : nr[0];
-  const bool bad = ((cull ? nr[3] : nr[1]) != 0u) || (n > cap);
+  const uint32_t hi = cull ? nr[3] : nr[1];
+  const bool bad = (hi != 0u) || (n > cap);
   nr[4] = bad ? 0u : n;
   nr[5] = bad ? 1u : 0u;
   if (bad && drops != nullptr) drops[0] += 1u;   // the caller's running count of overflowed forwards (graph replays)
+  if (status != nullptr) {                       // DgsForwardOut.status_dev: the words of THIS forward, outside the blobs
+    status[0] = n;
+    status[1] = hi;
+    status[2] = bad ? 1u : 0u;
+    status[3] = bad ? 0u : n;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- ranges
@@ -1194,8 +1202,9 @@ PassPlan plan_passes(int begin_bit, int end_bit) {
 
 }  // namespace
 
-hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, uint32_t* drops, hipStream_t s) {
-  hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, s, c.num_rendered, cull, cap, drops);
+hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, uint32_t* drops, uint32_t* status,
+                                     hipStream_t s) {
+  hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, s, c.num_rendered, cull, cap, drops, status);
   return hipGetLastError();
 }
 

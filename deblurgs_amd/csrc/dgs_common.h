@@ -203,7 +203,8 @@ hipError_t dgs_launch_mark_visible(int P, const float* means3D, const float* vie
 hipError_t dgs_launch_cloud_activations(int P, const float* scales, const float* rotations, const float* opacities,
                                         float scale_lb, float* out_scales, float* out_rotations, float* out_opacities,
                                         hipStream_t s);
-hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, uint32_t* drops, hipStream_t s);
+hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, uint32_t* drops, uint32_t* status,
+                                     hipStream_t s);
 hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s,
                              const uint32_t* n_dev = nullptr, int tile_shift = 32);
 hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, uint32_t* total,

@@ -42,8 +42,14 @@ def _ptr(t, offset_elems=0):
     return None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * offset_elems)
 
 
+class CaptureRefused(RuntimeError):
+    """The runtime refused to capture a step into a hipGraph.  Raised only from inside the capture block: nothing of the
+    step has been enqueued, so the caller may run the step eagerly instead.  Errors of a cached graph's replay or of the
+    eager part behind it are NOT of this kind and propagate as they are."""
+
+
 class _Pending:
-    __slots__ = ("host", "event", "capacity", "speculative", "key", "generation", "request", "shared_host")
+    __slots__ = ("host", "event", "capacity", "speculative", "key", "generation", "request")
 
 
 class FusedStep:
@@ -67,7 +73,6 @@ class FusedStep:
         self.time_allreduce = False
         self.ar_events = []
         self._drops_dev = None      # device word: captured forwards that overflowed so far (DgsForwardOut.drop_counter)
-        self._drops_seen = 0        # ... and how many of them _poll has turned into retries
         self._bucket = None         # (generation, numel, tensor): the gradient bucket all captured steps write to
         self._front_shared = None   # (key, radii, screen gradients, skip word) of the captured sharded fronts
         self._graphs = {}           # captured steps by what they bake in (replay)
@@ -85,31 +90,35 @@ class FusedStep:
             if block:
                 pnd.event.synchronize()
             if pnd.event.query():
+                # Every entry owns its pinned words.  An eager step's are written by dgs_forward's own copies; a REPLAYED
+                # step's by a copy of the graph's DgsForwardOut.status_dev enqueued right behind that replay (_track_replay)
+                # -- the pinned block baked into a graph is rewritten by every later replay of the same view while the host
+                # runs several replays ahead, so it can never say which replay overflowed (with two views in
+                # flight a running drop counter read from those blocks went backwards and queued 2^32 - 1 retries).
                 R, hi, overflow = (int(x) & 0xFFFFFFFF for x in pnd.host[:3].tolist())
                 if hi != 0:
                     raise RuntimeError("num_rendered exceeds 32 bits: render fewer subframes per call")
-                if getattr(pnd, "shared_host", False):
-                    # a captured step: every replay of its graph copies its words into the SAME pinned block and the host
-                    # runs several replays ahead, so by now words [0..3] may already be a later replay's.  Drops are
-                    # therefore taken from the running counter all captured forwards share (DgsForwardOut.drop_counter ->
-                    # word [4]): it only grows, the entries are polled in launch order and a block belongs to one view,
-                    # so "what the counter gained since the last poll" is exactly the replays of THIS view that overflowed
-                    # and have not been made up for yet -- none lost, none counted twice.
-                    total = int(pnd.host[4]) & 0xFFFFFFFF
-                    new = (total - self._drops_seen) & 0xFFFFFFFF
-                    self._drops_seen = total
-                    self.dropped += new
-                    self.retry.extend([pnd.request] * new)
-                elif pnd.speculative and overflow:
+                if pnd.speculative and overflow:
                     self.dropped += 1
                     self.retry.append(pnd.request)
                 if pnd.generation == self._generation:
                     self._seen[pnd.key] = (self._seen.get(pnd.key, []) + [R])[-4:]
-                if not getattr(pnd, "shared_host", False):     # (a captured step's count words belong to its graph)
-                    self._free_hosts.append(pnd.host)
+                self._free_hosts.append(pnd.host)
             else:
                 still.append(pnd)
         self._pending = still
+
+    def _track_replay(self, ent, ckey, request, cap, dev):
+        """Behind a replay: this step's count / overflow words travel from the graph's status words (device, written by
+        the forward's finalize kernel) into a pinned slot of THIS step, and the step joins the pending list."""
+        pnd = _Pending()
+        pnd.host = self._host_words()
+        pnd.host[:4].copy_(ent["status"], non_blocking=True)
+        pnd.speculative, pnd.key, pnd.generation = True, ckey, self._generation
+        pnd.request, pnd.capacity = request, cap
+        pnd.event = torch.cuda.Event()
+        pnd.event.record(torch.cuda.current_stream(dev))
+        self._pending.append(pnd)
 
     def _capacity(self, key):
         seen = self._seen.get(key)
@@ -264,13 +273,7 @@ class FusedStep:
         ent["hyper"].copy_(hbuf, non_blocking=True)
         hev.record(torch.cuda.current_stream(dev))
         ent["graph"].replay()
-        pnd = _Pending()
-        pnd.host, pnd.speculative, pnd.key, pnd.generation = ent["host"], True, ckey, self._generation
-        pnd.request, pnd.capacity = (cam_idx, subframe_indice), cap
-        pnd.event = torch.cuda.Event()
-        pnd.event.record(torch.cuda.current_stream(dev))
-        pnd.shared_host = True
-        self._pending.append(pnd)
+        self._track_replay(ent, ckey, (cam_idx, subframe_indice), cap, dev)
         self.last_capacity = cap
         self.replayed += 1
         return ent["result"]
@@ -341,13 +344,7 @@ class FusedStep:
         if uniform_dev is not None and m.curve_random_sample and f > 2:
             ent["hyper"][48:48 + f - 2].copy_(uniform_dev.reshape(f - 2))
         ent["graph"].replay()
-        pnd = _Pending()
-        pnd.host, pnd.speculative, pnd.key, pnd.generation = ent["host"], True, ckey, self._generation
-        pnd.request, pnd.capacity = (cam_idx, subframe_indice), cap
-        pnd.event = torch.cuda.Event()
-        pnd.event.record(torch.cuda.current_stream(dev))
-        pnd.shared_host = True
-        self._pending.append(pnd)
+        self._track_replay(ent, ckey, (cam_idx, subframe_indice), cap, dev)
         self.last_capacity = cap
         self.replayed += 1
         return ent["finish"](float(lambda_t))
@@ -368,7 +365,7 @@ class FusedStep:
             torch.cuda.empty_cache()
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
-        ent = {"hyper": hyper, "host": host}
+        ent = {"hyper": hyper, "host": host, "status": torch.zeros(4, dtype=torch.int32, device=dev)}
         # What the eager part and the caller read after a replay lives OUTSIDE the capture pool, shared by all graphs of a
         # cloud generation (steps never overlap): the gradient bucket, the loss values, the skip word, and -- sharded runs
         # update the densification statistics in a launch of their own -- the radii and the screen-space gradients.
@@ -382,8 +379,8 @@ class FusedStep:
                                   torch.empty((K_total, P_, 3), dtype=torch.float32, device=dev),
                                   torch.zeros(1, dtype=torch.int32, device=dev))
         ent["work"] = torch.zeros(8, dtype=torch.float32, device=dev)
-        cap_args = {"capacity": cap, "host": host, "lambda_ptr": hyper.data_ptr(), "work": ent["work"],
-                    "bucket": self._bucket[2], "split": "composite" if shard is None else "forward",
+        cap_args = {"capacity": cap, "host": host, "status": ent["status"], "lambda_ptr": hyper.data_ptr(),
+                    "work": ent["work"], "bucket": self._bucket[2], "split": "composite" if shard is None else "forward",
                     "radii": self._front_shared[1],
                     "means2D": self._front_shared[2], "skipw": self._front_shared[3], "tail": None}
         bg = hyper[1:4]
@@ -392,8 +389,11 @@ class FusedStep:
             p.grad = None
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
-            front = self.run(cam_idx, 0.0, gt, bg, subframe_indice, uniform=uniform, _cap=cap_args, ar=ar, shard=shard)
+        try:
+            with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
+                front = self.run(cam_idx, 0.0, gt, bg, subframe_indice, uniform=uniform, _cap=cap_args, ar=ar, shard=shard)
+        except RuntimeError as ex:
+            raise CaptureRefused(str(ex)) from ex
         # the step's large buffers go back to the pool (the other views' captures re-use the blocks); finish() reaches them
         # through the raw pointers of its DgsProblem / DgsBackwardIO -- valid until the next replay of ANY graph of the pool,
         # which is enqueued after this step's eager part on the same stream
@@ -422,7 +422,7 @@ class FusedStep:
             torch.cuda.empty_cache()
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
-        ent = {"hyper": hyper, "host": host}
+        ent = {"hyper": hyper, "host": host, "status": torch.zeros(4, dtype=torch.int32, device=dev)}
         # Two things a replay leaves behind live OUTSIDE the capture pool (ordinary allocations made before the capture):
         # the loss kernel's work block -- `losses` handed to the caller is a view of it and holds a replay's two values until
         # the SAME graph is replayed again (in the pool it could be another graph's scratch: all graphs share the pool) --
@@ -434,8 +434,8 @@ class FusedStep:
         if self._bucket is None or self._bucket[0] != self._generation or self._bucket[1] != n_bucket:
             self._bucket = (self._generation, n_bucket, torch.empty(n_bucket, dtype=torch.float32, device=dev))
         ent["work"] = torch.zeros(8, dtype=torch.float32, device=dev)
-        cap_args = {"capacity": cap, "host": host, "lambda_ptr": hyper.data_ptr(), "work": ent["work"],
-                    "bucket": self._bucket[2],
+        cap_args = {"capacity": cap, "host": host, "status": ent["status"], "lambda_ptr": hyper.data_ptr(),
+                    "work": ent["work"], "bucket": self._bucket[2],
                     "tail": (lambda fr: tail(fr, hyper.data_ptr() + 4 * 8)) if tail is not None else None}
         bg = hyper[1:4]
         uniform = hyper[48:48 + f - 2] if (m.curve_random_sample and f > 2) else None
@@ -584,6 +584,7 @@ class FusedStep:
         else:
             host, cap, pnd = _cap["host"], int(_cap["capacity"]), None
             out.drop_counter = ctypes.c_void_p(self._drop_counter(dev).data_ptr())
+            out.status_dev = ctypes.c_void_p(_cap["status"].data_ptr())
         out.num_rendered_host = ctypes.c_void_p(host.data_ptr())
         if cap is not None:
             binning = torch.empty(L.dgs_binning_state_bytes(cap, W, H, K), dtype=torch.uint8, device=dev)

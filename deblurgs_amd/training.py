@@ -214,19 +214,19 @@ class TrainingLoop:
                 self._graphable(iteration, sharded=True)):
             # sharded step: everything up to the first collective as one hipGraph, the reductions and what depends on
             # them eagerly (FusedStep.replay_front); None = no duplicate count learnt for this view yet
-            captured_before = self._fused.captured
+            from .fused_step import CaptureRefused
             try:
                 fr = self._fused.replay_front(cam_idx, lambda_t_smooth, gt, subframe_indice, ar, background=bg_host,
                                               uniform=uni_host, shard=shard,
                                               background_dev=bg if shard is not None else None,
                                               uniform_dev=uniform if shard is not None else None)
-            except RuntimeError as ex:
+            except CaptureRefused as ex:
                 # A capture that the runtime refuses (e.g. a collective library that does not tolerate a capturing
                 # stream next to it) must not take an N-rank run down: nothing of the step has been enqueued when a
-                # CAPTURE fails, so the eager step below runs it, and the front is not tried again.  (A failure after a
-                # successful capture -- in the eager part -- is a real error and is re-raised.)
-                if self._fused.captured != captured_before:
-                    raise
+                # CAPTURE fails, so the eager step below runs it, and the front is not tried again.  Only the capture
+                # block raises this (FusedStep._capture_front); an error of a cached graph's replay or of the eager part
+                # behind it -- where this rank may already have issued collectives the others are waiting in --
+                # propagates.
                 import warnings
                 warnings.warn(f"captured front disabled for this run (falling back to the eager sharded step): {ex}")
                 self._front_failed = True

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 10
+#define DGS_ABI_VERSION 11
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -104,6 +104,12 @@ typedef struct DgsForwardOut {
   uint32_t* drop_counter;      /* dgs_forward only, optional device word owned by the caller: incremented by every
                                 * forward whose capacity overflowed and copied to num_rendered_host[4].  A caller that
                                 * replays a captured graph reads its running value instead of one flag per replay. */
+  uint32_t* status_dev;        /* dgs_forward only, optional DEVICE uint32[4] owned by the caller and outliving the state
+                                * blobs: receives the same four words as num_rendered_host[0..3] ({count, its high word,
+                                * overflow flag, count the lists were built with}).  Every replay of a captured graph copies
+                                * into the SAME pinned num_rendered_host block; a caller that runs several replays ahead
+                                * enqueues its own copy of status_dev into a per-step pinned slot right behind each replay
+                                * and so reads the words of exactly that replay. */
 } DgsForwardOut;
 
 typedef struct DgsBackwardIO {

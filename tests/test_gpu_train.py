@@ -694,12 +694,12 @@ def test_graph_replay_equals_eager_fused_step(gpu):
 
 
 def test_captured_step_that_overflows_is_counted_once_and_made_up_for(gpu):
-    """every replay of a captured graph copies its count words into the same pinned block while the host runs
-    several replays ahead, so the per-replay overflow word can be overwritten before it is read.  The drops are taken
-    from the running device counter instead (DgsForwardOut.drop_counter): ONE view stepped back to back through ONE graph,
-    the splats grown in place (same tensors: the same graph keeps replaying) until its capacity overflows -- every
-    overflowed replay must be counted exactly once, re-run through the exact path, and Adam's step counters must equal
-    the number of step() calls (each applied exactly once)."""
+    """every replay of a captured graph copies its count words into the same pinned block while the host
+    runs several replays ahead, so that block cannot say which replay overflowed.  Every replay therefore gets a pinned
+    slot of its own, filled from the graph's device status words (DgsForwardOut.status_dev) by a copy enqueued right
+    behind it.  ONE view stepped back to back through ONE graph, the splats grown in place (same tensors: the same graph
+    keeps replaying) until its capacity overflows -- every overflowed replay must be counted exactly once, re-run through
+    the exact path, and Adam's step counters must equal the number of step() calls (each applied exactly once)."""
     import torch
     from deblurgs_amd.training import TrainingLoop, default_optimization_params
     sc, cloud, m = _fused_fixture(seed=8, K=5, P=4000)
@@ -731,6 +731,52 @@ def test_captured_step_that_overflows_is_counted_once_and_made_up_for(gpu):
         loop.step(it, 0)
     loop.flush()
     assert fs.replayed > n and counter() == 23 and loop.retried == fs.dropped
+
+
+def test_overflow_of_one_view_among_several_in_flight_is_charged_to_that_view(gpu):
+    """with several views in flight the drop of view B must be made up for by re-running view B --
+    not charged to the view whose pinned block happened to be read first, and never turned into 2^32 - 1 retries by a
+    counter that seemed to run backwards.  Three views replay round-robin; view 1's learnt duplicate count is then
+    falsified to a fraction of the truth, so its next capture bakes in a capacity its replays overflow until the exact
+    make-up step has learnt the real count again.  Every make-up step must be view 1's, dropped == retried, and every
+    step() call must have been applied exactly once."""
+    import torch
+    from deblurgs_amd.training import TrainingLoop, default_optimization_params
+    sc, cloud, m = _fused_fixture(seed=8, K=5, P=4000)
+    opt = default_optimization_params(iterations=10 ** 6, curve_start_iter=1, densify_from_iter=10 ** 9,
+                                      densify_until_iter=0, opacity_reset_interval=10 ** 9)
+    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, graph="always")
+    fs = loop._fused
+    made_up = []
+    inner = loop._step_fused
+
+    def spy(iteration, cam_idx, *a, exact=False, **kw):
+        if exact:
+            made_up.append(int(cam_idx))
+        return inner(iteration, cam_idx, *a, exact=exact, **kw)
+    loop._step_fused = spy
+    it = 0
+    for _ in range(4):
+        for view in (0, 1, 2):
+            it += 1
+            loop.step(it, view)
+    loop.flush()
+    assert fs.dropped == 0 and fs.replayed >= 6 and not made_up, (fs.dropped, fs.replayed, made_up)
+    key = next(k for k in fs._seen if k[0] == 1)
+    true_count = max(fs._seen[key])
+    fs._seen[key] = [max(true_count // 8, 1)]          # view 1's next graph: a capacity its replays overflow
+    for _ in range(6):
+        for view in (0, 1, 2):                          # no flush in between: up to eight steps in flight
+            it += 1
+            loop.step(it, view)
+    loop.flush()
+    torch.cuda.synchronize()
+    assert fs.dropped >= 1, "view 1 never overflowed its falsified capacity: the test does not test"
+    assert made_up and set(made_up) == {1}, made_up
+    assert loop.retried == fs.dropped == len(made_up) and not fs.retry, (loop.retried, fs.dropped, made_up)
+    assert fs.dropped <= 6, fs.dropped                  # (at most view 1's own steps; never a wrapped difference)
+    assert float(cloud.optimizer.state[cloud._xyz]["step"]) == it
+    assert max(fs._seen[key]) >= true_count * 0.9      # the make-up step learnt the real count again
 
 
 def test_training_matches_the_cpu_reference_loop_on_a_toy_deblurring_scene(gpu):
@@ -872,6 +918,80 @@ def test_rccl_one_rank_smoke(gpu):
         env.pop(k, None)
     out = _run([sys.executable, os.path.join(root, "tools", "rccl_smoke.py")], env, timeout=600)
     assert "rccl smoke ok: backend nccl, world 1" in out, out
+
+
+def test_sharded_step_falls_back_only_when_the_capture_itself_is_refused(gpu):
+    """the eager fall-back of a sharded step is for a REFUSED CAPTURE only (FusedStep raises
+    CaptureRefused from inside the capture block: nothing has been enqueued).  A RuntimeError out of a cached graph's
+    replay or of the eager part behind it -- where this rank may already have issued collectives -- must propagate
+    instead of being answered with a second, eager run of the step.  One-rank gloo group in this process."""
+    import socket
+    import warnings
+    import torch
+    import torch.distributed as dist
+    from deblurgs_amd import fused_step
+    from deblurgs_amd.training import TrainingLoop, default_optimization_params
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        opt = default_optimization_params(iterations=10 ** 6, curve_start_iter=1, densify_from_iter=10 ** 9,
+                                          densify_until_iter=0, opacity_reset_interval=10 ** 9)
+        # (a) the capture is refused: warning, eager step, never tried again, every step applied once
+        sc, cloud, m = _fused_fixture(seed=8, K=5, P=3000)
+        loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed="views", graph="always")
+        fs = loop._fused
+        real_graph = torch.cuda.graph
+
+        class Refusing:
+            def __init__(self, *a, **kw):
+                pass
+
+            def __enter__(self):
+                raise RuntimeError("hipErrorStreamCaptureUnsupported (injected)")
+
+            def __exit__(self, *a):
+                return False
+        torch.cuda.graph = Refusing
+        try:
+            with warnings.catch_warnings(record=True) as seen:
+                warnings.simplefilter("always")
+                for it in range(1, 7):
+                    loop.step(it, 0)
+        finally:
+            torch.cuda.graph = real_graph
+        loop.flush()
+        assert loop._front_failed and fs.captured == 0 and fs.replayed == 0
+        assert any("captured front disabled" in str(w.message) for w in seen)
+        assert float(cloud.optimizer.state[cloud._xyz]["step"]) == 6
+        # (b) an error behind a successful capture is NOT a refused capture: it propagates, nothing is re-run
+        sc, cloud, m = _fused_fixture(seed=8, K=5, P=3000)
+        loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed="views", graph="always")
+        fs = loop._fused
+        for it in range(1, 5):
+            loop.step(it, 0)
+        assert fs.captured >= 1 and fs.replayed >= 1 and not loop._front_failed
+        eager_runs = []
+        real_run = fs.run
+        fs.run = lambda *a, **kw: (eager_runs.append(1), real_run(*a, **kw))[1]
+        def boom(*_a, **_k):
+            raise RuntimeError("collective failed (injected)")
+        for ent in fs._graphs.values():
+            ent["finish"] = boom
+        real_capture = fs._capture_front
+
+        def capture_then_boom(*a, **kw):          # (a count drift may re-capture: that graph's eager part fails too)
+            ent = real_capture(*a, **kw)
+            ent["finish"] = boom
+            return ent
+        fs._capture_front = capture_then_boom
+        with pytest.raises(RuntimeError, match="collective failed"):
+            loop.step(5, 0)
+        assert not eager_runs and not loop._front_failed
+        assert not issubclass(RuntimeError, fused_step.CaptureRefused)
+    finally:
+        dist.destroy_process_group()
 
 
 # The N-rank code path end to end with two ranks sharing this box's GPU (gloo collectives staged through the host: a

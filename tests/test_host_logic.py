@@ -291,3 +291,35 @@ def test_bench_launcher_does_not_wait_for_a_dead_rank(how):
     assert r.returncode == 1, (r.returncode, r.stderr[-500:])
     assert time.time() - t0 < 60
     assert ("exited non-zero" in r.stderr) if how != "timeout" else ("timeout" in r.stderr)
+
+
+def test_poll_charges_every_overflow_to_its_own_step():
+    """ADVICE r4 (high), host side only: FusedStep._poll with several views in flight.  Every pending entry owns its
+    pinned words, so the order [A1 ok, B1 overflowed, A2 ok, B2 overflowed, A3 ok] -- all complete at one poll -- yields
+    exactly two retries, both view B's, and each view learns only its own counts.  (The round-4 code read a running
+    drop counter from per-GRAPH blocks: this sequence charged B's drop to A, and a counter that seemed to run backwards
+    became 2^32 - 1 queued retries.)"""
+    from deblurgs_amd.fused_step import FusedStep, _Pending
+
+    class Cloud:
+        fused_activations = True
+
+    class Done:
+        def query(self):
+            return True
+
+        def synchronize(self):
+            pass
+
+    fs = FusedStep(Cloud(), motion=None)
+    seq = [("A", 100, 0), ("B", 900, 1), ("A", 101, 0), ("B", 901, 1), ("A", 102, 0)]
+    for view, count, over in seq:
+        p = _Pending()
+        p.host = torch.tensor([count, 0, over, 0 if over else count, 0, 0, 0, 0], dtype=torch.int32)
+        p.event, p.capacity, p.speculative = Done(), 500, True
+        p.key, p.generation, p.request = (view, 5, 0), fs._generation, (view, "all")
+        fs._pending.append(p)
+    fs._poll()
+    assert fs.dropped == 2 and fs.retry == [("B", "all"), ("B", "all")]
+    assert fs._seen[("A", 5, 0)] == [100, 101, 102] and fs._seen[("B", 5, 0)] == [900, 901]
+    assert not fs._pending and len(fs._free_hosts) == 5
