@@ -44,6 +44,57 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+SAN_LIB = os.path.join(HERE, "libdgs_hip_san.so")
+SAN_OBJ = os.path.join(CSRC, "obj_san")
+# Host-side AddressSanitizer + UndefinedBehaviorSanitizer build of the WHOLE library: the same sources, the
+# host code of every translation unit -- argument checks, blob carving, size arithmetic, launch sequencing --
+# instrumented, the device code left as it is (-fno-gpu-sanitize; GPU-side ASan needs xnack+ code objects, which the pool
+# does not run).  For the CPU box only: tests/test_sanitize.py runs tests/test_abi.py and cfg5-size size queries against
+# it under the sanitizer runtime.  Never loaded by the product (DGS_LIB_PATH selects it explicitly).
+SAN_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan",
+             "-fno-sanitize-recover=undefined"]
+
+
+def asan_runtime():
+    """The shared ASan runtime of hipcc's clang (to LD_PRELOAD into a python that loads libdgs_hip_san.so)."""
+    r = subprocess.run([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    path = r.stdout.strip()
+    if os.path.isabs(path) and os.path.exists(path):
+        return path
+    import glob
+    hits = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    return hits[0] if hits else None
+
+
+def build_sanitized(force=False, verbose=False):
+    os.makedirs(SAN_OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, "dgs_common.h"), os.path.join(HERE, "..", "include", "dgs_hip.h")]
+    hipcc = _hipcc()
+    common = [f for f in COMMON if f != "-O3"] + SAN_FLAGS
+    jobs, objs = [], []
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(SAN_OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([hipcc] + common + extra + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(SAN_LIB, objs):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fsanitize=address,undefined", "-shared-libsan",
+             "-o", SAN_LIB] + objs)
+    return SAN_LIB
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, "dgs_common.h"), os.path.join(HERE, "..", "include", "dgs_hip.h")]
@@ -73,4 +124,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--sanitize" in sys.argv:
+        print(build_sanitized(force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

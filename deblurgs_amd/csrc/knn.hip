@@ -200,7 +200,8 @@ KnnCarve carve_knn(int P, char* base) {
   KnnCarve c;
   size_t o = 0;
   const size_t n = (size_t)P;
-  auto take = [&](size_t bytes) { char* p = base + o; o += up(bytes); return p; };
+  // (offsets are added as integers: the size query carves from a null base, and pointer arithmetic on null is undefined)
+  auto take = [&](size_t bytes) { char* p = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(base) + o); o += up(bytes); return p; };
   c.keys = reinterpret_cast<uint64_t*>(take(n * 8));
   c.keys_alt = reinterpret_cast<uint64_t*>(take(n * 8));
   c.vals = reinterpret_cast<uint32_t*>(take(n * 4));

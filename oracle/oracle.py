@@ -16,7 +16,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdgs_oracle.so")
+# DGS_ORACLE_LIB: another build of the single-thread oracle -- tests/test_sanitize.py points it at the ASan + UBSan build
+_LIB_PATH = os.environ.get("DGS_ORACLE_LIB") or os.path.join(_HERE, "libdgs_oracle.so")
 _LIB_OMP_PATH = os.path.join(_HERE, "libdgs_oracle_omp.so")   # bench.py cpu_baseline, full-size parity tests
 _LIB_FMA_PATH = os.path.join(_HERE, "libdgs_oracle_fma.so")   # the OpenMP build with FMA contraction (as nvcc --fmad=true)
 _lib = None
