@@ -183,60 +183,103 @@ def _p2p(sends, recvs, group=None):
         torch.cuda.current_stream(dev).synchronize()
 
 
-def p2p_allreduce_(flat, average=False, group=None, align=256, force=False):
-    """In-place sum (or mean) of the 1-D fp32 tensor `flat` over the ranks without a collective: the buffer is cut into
-    one shard per rank (boundaries on multiples of `align` elements); rank r receives its shard from every peer (one
-    batch of point-to-point operations = one RCCL group), adds the G contributions IN RANK ORDER (so the result is a
-    fixed function of the inputs and bit-identical on every rank), and sends the reduced shard back to every peer.
-    2 (G-1)/G of the buffer leave and enter each rank, as in a ring, but over G-1 links at once.
-    force: in a ONE-rank group, run both phases as a send to / receive from this rank itself (RCCL accepts a self
-    send + receive inside one group; values unchanged) -- tools/rccl_smoke.py puts the RCCL point-to-point path under
-    the product code on a one-GPU box this way."""
+def _rank_ordered_sum_(recv, own, rank, world, average):
+    """own <- sum over the ranks of (own on row `rank`, recv[s] elsewhere), added in rank order, / world if average.
+    Device tensors: ONE launch (dgs_rank_ordered_sum); CPU tensors (the gloo tests): the same arithmetic in torch."""
+    if own.is_cuda:
+        import ctypes
+        from . import _lib
+        stream = ctypes.c_void_p(torch.cuda.current_stream(own.device).cuda_stream)
+        _lib.check(_lib.lib().dgs_rank_ordered_sum(ctypes.c_void_p(recv.data_ptr()), recv.stride(0),
+                                                   ctypes.c_void_p(own.data_ptr()), own.numel(), world, rank,
+                                                   float(world) if average else 1.0, stream), "dgs_rank_ordered_sum")
+        return
+    n = own.numel()
+    acc = (own if rank == 0 else recv[0, :n]).clone()
+    for s in range(1, world):
+        acc += own if s == rank else recv[s, :n]
+    if average:
+        acc /= world
+    own.copy_(acc)
+
+
+_recv_blocks = {}     # (device, stream, numel) -> receive block of p2p_allreduce_multi_ (one per stream: calls on a stream are ordered)
+
+
+def _recv_block(device, numel):
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    buf = _recv_blocks.get(key)
+    if buf is None or buf.numel() < numel:
+        buf = _recv_blocks[key] = torch.empty(max(numel, 1), dtype=torch.float32, device=device)
+    return buf
+
+
+def p2p_allreduce_multi_(tensors, average=False, group=None, align=256, force=False):
+    """In-place sum (or mean) of several 1-D contiguous fp32 tensors over the ranks without a collective: every tensor is
+    cut into one shard per rank (boundaries on multiples of `align` elements); rank r receives its shards from every peer
+    -- ONE batch of point-to-point operations = one RCCL group for all tensors --, adds the G contributions IN RANK ORDER
+    (one fused launch per tensor, dgs_rank_ordered_sum: the result is a fixed function of the inputs and bit-identical on
+    every rank), and sends the reduced shards back to every peer (a second batch).  2 (G-1)/G of the data leave and enter
+    each rank, as in a ring, but over G-1 links at once.  The receive block is kept per stream (no allocation per call).
+    force: in a ONE-rank group, run both phases as a send to / receive from this rank itself (RCCL accepts a self send +
+    receive inside one group; values unchanged) -- tools/rccl_smoke.py puts the RCCL point-to-point path under the product
+    code on a one-GPU box this way."""
     W = dist.get_world_size(group)
-    if flat.numel() == 0 or (W == 1 and not force):
+    tensors = [t for t in tensors if t.numel() > 0]
+    if not tensors or (W == 1 and not force):
         return
     r = dist.get_rank(group)
-    n = flat.numel()
-    if W == 1:      # (force) the shard goes through a self send / receive and comes back as it was, twice
+    if W == 1:      # (force) every tensor goes through a self send / receive and comes back as it was, twice
         for _phase in range(2):
-            tmp = torch.empty_like(flat)
-            _p2p([(flat, r)], [(tmp, r)], group)
-            flat.copy_(tmp)
+            tmps = [torch.empty_like(t) for t in tensors]
+            _p2p([(t, r) for t in tensors], [(tmp, r) for tmp in tmps], group)
+            for t, tmp in zip(tensors, tmps):
+                t.copy_(tmp)
         return
-    per = -(-n // W)
-    per = -(-per // align) * align
-    bounds = [(min(i * per, n), min((i + 1) * per, n)) for i in range(W)]
-    b0, b1 = bounds[r]
-    mine = b1 - b0
-    recv = torch.empty((W, mine), dtype=flat.dtype, device=flat.device)
+    plans = []
+    for t in tensors:
+        n = t.numel()
+        per = -(-n // W)
+        per = -(-per // align) * align
+        plans.append([(min(i * per, n), min((i + 1) * per, n)) for i in range(W)])
+    mines = [b[r][1] - b[r][0] for b in plans]
+    block = _recv_block(tensors[0].device, W * sum(-(-m // 4) * 4 for m in mines))
+    recvs_of, o = [], 0
+    for m in mines:
+        m4 = -(-m // 4) * 4                   # (rows start on 16-byte boundaries: float4 accesses in the sum kernel)
+        recvs_of.append(block[o:o + W * m4].view(W, m4))
+        o += W * m4
     sends, recvs = [], []
-    for s in range(W):
-        if s == r:
-            continue
-        s0, s1 = bounds[s]
-        if s1 > s0:
-            sends.append((flat[s0:s1], s))
-        if mine > 0:
-            recvs.append((recv[s], s))
+    for t, bounds, mine, rv in zip(tensors, plans, mines, recvs_of):
+        for s in range(W):
+            if s == r:
+                continue
+            s0, s1 = bounds[s]
+            if s1 > s0:
+                sends.append((t[s0:s1], s))
+            if mine > 0:
+                recvs.append((rv[s, :mine], s))
     _p2p(sends, recvs, group)
-    if mine > 0:
-        recv[r].copy_(flat[b0:b1])
-        acc = recv[0].clone()
-        for s in range(1, W):
-            acc += recv[s]
-        if average:
-            acc /= W
-        flat[b0:b1].copy_(acc)
+    for t, bounds, mine, rv in zip(tensors, plans, mines, recvs_of):
+        if mine > 0:
+            _rank_ordered_sum_(rv, t[bounds[r][0]:bounds[r][1]], r, W, average)
     sends, recvs = [], []
-    for s in range(W):
-        if s == r:
-            continue
-        s0, s1 = bounds[s]
-        if mine > 0:
-            sends.append((flat[b0:b1], s))
-        if s1 > s0:
-            recvs.append((flat[s0:s1], s))
+    for t, bounds, mine in zip(tensors, plans, mines):
+        b0, b1 = bounds[r]
+        for s in range(W):
+            if s == r:
+                continue
+            s0, s1 = bounds[s]
+            if mine > 0:
+                sends.append((t[b0:b1], s))
+            if s1 > s0:
+                recvs.append((t[s0:s1], s))
     _p2p(sends, recvs, group)
+
+
+def p2p_allreduce_(flat, average=False, group=None, align=256, force=False):
+    """p2p_allreduce_multi_ for one 1-D fp32 tensor."""
+    p2p_allreduce_multi_([flat], average, group, align, force)
 
 
 def _allreduce(flat, average, group):
@@ -257,9 +300,12 @@ def allreduce_slices(tensors, average=False, group=None):
     tensors = [t for t in tensors if t.numel() > 0]
     if not tensors:
         return
-    if ALLREDUCE_MODE == "p2p":
+    if ALLREDUCE_MODE == "p2p":      # the chunk's slices in ONE pair of point-to-point batches
+        big = [t.reshape(-1) for t in tensors if t.is_contiguous() and t.numel() >= P2P_MIN_NUMEL]
+        p2p_allreduce_multi_(big, average, group, force=FORCE_COLLECTIVES)
         for t in tensors:
-            _allreduce(t.reshape(-1), average, group)
+            if not (t.is_contiguous() and t.numel() >= P2P_MIN_NUMEL):
+                _allreduce(t, average, group)
         return
     if dist.get_backend(group) == "nccl" and hasattr(dist, "_coalescing_manager"):
         op = dist.ReduceOp.AVG if average else dist.ReduceOp.SUM

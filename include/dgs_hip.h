@@ -346,6 +346,14 @@ int dgs_adam_scalars(const DgsAdamGroup* groups, int32_t n_groups, double beta1,
 int dgs_adam_step_dev(const DgsAdamGroup* groups, int32_t n_groups, double beta1, double beta2, double eps,
                       double clip_value, const uint32_t* skip_flag, const float* dev_scalars, dgs_stream_t stream);
 
+/* Multi-GPU runs (new work, the reference is single-GPU): the local half of a direct reduce-scatter over
+ * point-to-point transfers.  `own` [n] is this rank's shard of the gradient bucket, `recv` [world, stride] holds the copy
+ * received from every peer in row s = its rank (row `rank` is not read); own <- ((row_0 + row_1) + row_2) + ... with `own`
+ * standing in for row `rank`, added IN RANK ORDER so every rank computes the same bits for a given set of inputs, then
+ * divided by `divisor` (1 = sum, world = mean).  stride >= n, world <= 64. */
+int dgs_rank_ordered_sum(const float* recv, uint64_t stride, float* own, uint64_t n, int32_t world, int32_t rank,
+                         float divisor, dgs_stream_t stream);
+
 size_t dgs_densify_tmp_bytes(int32_t P);
 /* plan: per Gaussian, grads = xyz_gradient_accum / denom (NaN -> 0); clone if |grads| >= grad_threshold and
  * max(exp(scaling)+scale_lb) <= size_threshold (= percent_dense * extent); split if grads >= grad_threshold and

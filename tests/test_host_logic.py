@@ -198,6 +198,16 @@ def _worker_p2p_allreduce(rank, world, port, out):
         dist.all_reduce(w_)
     sharding.flat_allreduce_grads(params, average=False)
     res["bucket"] = ([p.grad.clone() for p in params], want)
+    # a chunk's six row ranges in ONE pair of point-to-point batches (allreduce_slices -> p2p_allreduce_multi_); the small
+    # slice (below P2P_MIN_NUMEL) takes the collective
+    torch.manual_seed(50 + rank)
+    flat = torch.randn(400_000)
+    cuts = [(0, 70_001), (70_004, 140_005), (140_008, 340_000), (340_000, 340_100), (340_100, 399_999)]
+    ref = flat.clone()
+    dist.all_reduce(ref)
+    ref /= world
+    sharding.allreduce_slices([flat[a:b] for a, b in cuts], average=True)
+    res["slices"] = (torch.cat([flat[a:b] for a, b in cuts]), torch.cat([ref[a:b] for a, b in cuts]))
     sharding.ALLREDUCE_MODE = "collective"
     torch.save(res, out + f".{rank}")
     dist.barrier()
@@ -211,6 +221,11 @@ def test_p2p_allreduce_equals_the_collective_and_is_identical_on_every_rank(tmp_
     mp.spawn(_worker_p2p_allreduce, args=(3, 29677, out), nprocs=3, join=True)
     got = [torch.load(out + f".{r}") for r in range(3)]
     for key in got[0]:
+        if key == "slices":
+            for r in range(3):
+                assert torch.allclose(got[r][key][0], got[r][key][1], atol=1e-5)
+                assert torch.equal(got[r][key][0], got[0][key][0]), f"slices: rank {r} holds different bits"
+            continue
         if key == "bucket":
             for r in range(3):
                 for a, b in zip(*got[r]["bucket"]):
