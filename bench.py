@@ -67,6 +67,14 @@ def parse_args(argv=None):
                          "reduce-scatter + all-gather over point-to-point sends (deblurgs_amd.sharding.p2p_allreduce_)")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--emulate-shard", default=None, metavar="r/G",
+                    help="ONE GPU: time rank r's share of a G-GPU step of --shard mode with every collective degenerate "
+                         "(one-rank process group): 'subframes' = its slice of the view's K subframes, 'views' = a whole "
+                         "view through the sharded code path.  Prints an 'emulated_shard' line, not the metric line; "
+                         "tools/predict_scaling.py turns these into DESIGN.md's predicted scaling table")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N > 1 GPUs: skip the extra regions behind the headline one (other sharding mode, collective vs "
+                         "point-to-point all-reduce A/B)")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="time query + loss + backward (+ all-reduce) only, without densification stats and Adam")
     return ap.parse_args(argv)
@@ -112,6 +120,7 @@ def launch_ranks(args):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.setdefault("DGS_BENCH_JOB", str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
     deadline = time.time() + float(os.environ.get("DGS_BENCH_TIMEOUT_S", "1500"))
@@ -231,6 +240,64 @@ def cpu_baseline_torch_naive(scene, k, side=96):
             "full_frame_equivalent_renders_per_sec_extrapolated": 1.0 / (dt * ratio)}
 
 
+# ------------------------------------------------------------------------------------------------ RCCL's own log
+NCCL_ALGOS = {0: "Tree", 1: "Ring", 2: "CollNetDirect", 3: "CollNetChain", 4: "NVLS", 5: "NVLSTree", 6: "PAT"}
+NCCL_PROTOS = {0: "LL", 1: "LL128", 2: "Simple"}
+
+
+def rccl_log_setup(rank):
+    """"verify which algorithm RCCL picks".  BEFORE init_process_group (environment only, no exec): this rank's
+    RCCL log (INFO; init, collective calls, the tuner's algorithm / protocol choices) goes to a file of its own, which
+    rank 0 parses after the run (parse_rccl_log).  Anything the caller already set wins."""
+    if os.environ.get("DGS_DIST_BACKEND", "nccl") != "nccl" or os.environ.get("DGS_BENCH_NO_RCCL_LOG", "0") == "1":
+        return None
+    import tempfile
+    job = os.environ.get("DGS_BENCH_JOB") or os.environ.get("MASTER_PORT", "0")
+    d = os.path.join(tempfile.gettempdir(), f"dgs_rccl_{job}")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, f"rank{rank}.log")
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
+    os.environ.setdefault("NCCL_DEBUG_FILE", path)
+    return os.environ["NCCL_DEBUG_FILE"]
+
+
+def parse_rccl_log(path, max_lines=8):
+    """What the library said about itself: version, the rings / trees / channels it built, and -- per message size -- the
+    algorithm and protocol its tuner chose ("<n> Bytes -> Algo <a> proto <p> time <t>")."""
+    import re
+    if not path or not os.path.exists(path):
+        return None
+    try:
+        text = open(path, errors="replace").read()
+    except OSError:
+        return None
+    out = {"file": path, "bytes_logged": len(text)}
+    m = re.search(r"\b(RCCL|NCCL) version ([^\n]+)", text)
+    if m:
+        out["version"] = (m.group(1) + " " + m.group(2)).strip()[:120]
+    chosen = {}
+    for nb, a, pr in re.findall(r"(\d+) Bytes -> Algo (\d+) proto (\d+)", text):
+        key = int(nb)
+        name = f"{NCCL_ALGOS.get(int(a), a)}/{NCCL_PROTOS.get(int(pr), pr)}"
+        chosen.setdefault(key, {})
+        chosen[key][name] = chosen[key].get(name, 0) + 1
+    if chosen:      # the largest messages are the gradient bucket (or its chunks)
+        out["algo_proto_by_message_bytes"] = {str(k): chosen[k] for k in sorted(chosen, reverse=True)[:6]}
+    calls = {}
+    for name in re.findall(r"\b(AllReduce|Broadcast|AllGather|ReduceScatter|Send|Recv): opCount", text):
+        calls[name] = calls.get(name, 0) + 1
+    if calls:
+        out["calls_logged"] = calls
+    topo = [ln.strip()[-200:] for ln in text.splitlines()
+            if re.search(r"Init COMPLETE|Channel \d+/\d+ *:|\bRing \d+ *:|Trees? \[|nRanks \d+|via P2P|threadThresholds|"
+                         r"channels? per|Connected all (rings|trees)", ln)]
+    if topo:
+        out["init_lines"] = topo[:max_lines]
+        out["init_lines_total"] = len(topo)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     import numpy as np
@@ -244,6 +311,22 @@ def run_rank(args):
 
     if args.allreduce is not None:
         sharding.ALLREDUCE_MODE = args.allreduce
+    emu = None
+    if args.emulate_shard:
+        # one GPU, a ONE-rank process group (the real backend), the sharded step of rank r of G with degenerate collectives
+        er, eg = (int(x) for x in args.emulate_shard.split("/"))
+        if not (0 <= er < eg) or args.gpus != 1 or "RANK" in os.environ:
+            raise SystemExit("bench.py: --emulate-shard r/G needs 0 <= r < G, --gpus 1 and a plain (single-process) start")
+        emu = (er, eg)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            free_port = sk.getsockname()[1]
+        os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port),
+                          DGS_DIST_FORCE_INIT="1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rccl_log = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        rccl_log = rccl_log_setup(int(os.environ.get("RANK", "0")))
     rank, world_env, local_rank = sharding.init_distributed("cuda")
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world != max(args.gpus, 1):
@@ -256,7 +339,8 @@ def run_rank(args):
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
         assert int(ones.item()) == world, "all-reduce did not reach every rank"
-    subframes_mode = world > 1 and args.shard == "subframes"
+    subframes_mode = (world > 1 or emu is not None) and args.shard == "subframes"
+    shard_id = emu if emu is not None else (rank, world)       # (rank, world) of the slice this process computes
 
     over = {} if args.K is None else {"K": args.K}
     if args.P is not None:
@@ -268,15 +352,19 @@ def run_rank(args):
     C = synthetic.CONFIGS[args.config]["C"]
     cloud = GaussianCloud.from_scene(scene, dev)
     ref_cam = RefCamera(W, H, scene["FoVx"], scene["FoVy"], device=dev)
-    view_seed = 0 if subframes_mode else rank        # "subframes": every rank works on the SAME view
-    gen = torch.Generator(device="cpu").manual_seed(1234 + view_seed)
-    gt = torch.rand((1, 3, H, W), generator=gen).to(dev)
-    motion = CameraMotionModule(ref_cam, gt, curve_order=C, num_subframes=K, device=dev)
-    traj = synthetic.make_trajectory(K, C, scene["projection_matrix"], seed=view_seed)
-    with torch.no_grad():
-        motion._trans._control_points.copy_(torch.from_numpy(traj["ctrl_trans"])[None].to(dev))
-        motion._rot._control_points.copy_(torch.from_numpy(traj["ctrl_rot"])[None].to(dev))
-    motion.link_gaussian(cloud)
+    def make_view(view_seed):
+        gen = torch.Generator(device="cpu").manual_seed(1234 + view_seed)
+        gt_ = torch.rand((1, 3, H, W), generator=gen).to(dev)
+        mo = CameraMotionModule(ref_cam, gt_, curve_order=C, num_subframes=K, device=dev)
+        traj = synthetic.make_trajectory(K, C, scene["projection_matrix"], seed=view_seed)
+        with torch.no_grad():
+            mo._trans._control_points.copy_(torch.from_numpy(traj["ctrl_trans"])[None].to(dev))
+            mo._rot._control_points.copy_(torch.from_numpy(traj["ctrl_rot"])[None].to(dev))
+        mo.link_gaussian(cloud)
+        return mo
+
+    # "subframes": every rank works on the SAME view; "views": rank g on its own
+    motion = make_view(0 if subframes_mode else (rank if emu is None else emu[0]))
     params = cloud.hot_parameters()
     # The timed step is the PRODUCT's training iteration, deblurgs_amd.training.TrainingLoop.step (train.py:104-208):
     # scheduled hyper-parameters, the view's K subframes rendered and back-propagated (by default through
@@ -293,17 +381,25 @@ def run_rank(args):
                                       densify_until_iter=far if not args.no_optimizer else 0,
                                       opacity_reset_interval=far, curve_rotation_lr=1e-3, curve_controlpoints_lr=1e-2,
                                       curve_alignment_lr=0.0)
-    mode = False if world == 1 else args.shard
-    loop = TrainingLoop(cloud, motion, opt, cameras_extent=1.0, spatial_lr_scale=1.0, distributed=mode,
-                        fused_step=False if args.autograd_path else "auto", log_losses=False,
-                        graph=False if args.no_graph else "always", ar_chunks=args.ar_chunks)
-    # The ground truth is noise, so real learning rates would pull the cloud away from the configured workload within
-    # the timed region (opacities collapse and the step gets ~5 % cheaper).  The Adam kernel does the same work for
-    # any learning rate; scale the rates down so that every timed step renders the workload BASELINE.json names.
     LR_SCALE = 1e-6
-    for group in cloud.optimizer.param_groups:
-        group["lr"] *= LR_SCALE
-    cloud.xyz_scheduler_args = lambda it: 0.00016 * LR_SCALE
+
+    def make_loop(mode_, motion_):
+        lp = TrainingLoop(cloud, motion_, opt, cameras_extent=1.0, spatial_lr_scale=1.0, distributed=mode_,
+                          fused_step=False if args.autograd_path else "auto", log_losses=False,
+                          graph=False if args.no_graph else "always", ar_chunks=args.ar_chunks,
+                          emulate_shard=emu if mode_ else None)
+        # The ground truth is noise, so real learning rates would pull the cloud away from the configured workload within
+        # the timed region (opacities collapse and the step gets ~5 % cheaper).  The Adam kernel does the same work for
+        # any learning rate; scale the rates down so that every timed step renders the workload BASELINE.json names.
+        for group in cloud.optimizer.param_groups:
+            group["lr"] *= LR_SCALE
+        cloud.xyz_scheduler_args = lambda it: 0.00016 * LR_SCALE
+        if (world > 1 or emu is not None) and lp._fused is not None:
+            lp._fused.time_allreduce = True
+        return lp
+
+    mode = args.shard if (world > 1 or emu is not None) else False
+    loop = make_loop(mode, motion)
 
     stats = {"it": 0}
     ar_events = []
@@ -319,9 +415,6 @@ def run_rank(args):
             return r
         sharding.flat_allreduce_grads = timed_allreduce
 
-    if world > 1 and loop._fused is not None:
-        loop._fused.time_allreduce = True
-
     def step():
         stats["it"] += 1
         loop.step(stats["it"], 0)
@@ -331,7 +424,8 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(nsteps, profile):
+    def timed(nsteps, profile, step_fn=None):
+        step_fn = step_fn or step
         sync()
         if profile:
             _lib.profile_reset()
@@ -340,7 +434,9 @@ def run_rank(args):
         sync()
         t0 = time.time()
         for _ in range(nsteps):
-            step()
+            step_fn()
+        torch.cuda.synchronize()
+        stats["dt_local"] = time.time() - t0       # this rank's own time, before it waits for the others
         sync()
         dt = time.time() - t0
         if profile:
@@ -355,13 +451,20 @@ def run_rank(args):
         step()
     sync()
     with torch.no_grad():       # measured Pv of this rank's workload (an output of the forward)
-        probe = motion.query(0, "all", compute_blurred=False,
-                             shard=(rank, world) if subframes_mode else None)
+        probe = motion.query(0, "all", compute_blurred=False, shard=shard_id if subframes_mode else None)
         Pv_tot = int((probe["radii_all"] > 0).sum().item())
         del probe
     # (N ranks: the step up to its first collective is replayed -- FusedStep.replay_front)
     replaying = loop.graph and loop._fused is not None and not args.autograd_path and not args.no_graph
     dt = timed(args.steps, profile=not replaying)
+    per_rank = None
+    if world > 1:       # every rank's own time for the region (the headline divides by the slowest)
+        mine = torch.tensor([stats["dt_local"]], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        ms = [float(x.item()) / args.steps * 1e3 for x in every]
+        per_rank = {"min_ms_per_step": round(min(ms), 3), "max_ms_per_step": round(max(ms), 3),
+                    "ms_per_step_by_rank": [round(x, 3) for x in ms]}
     allreduce_ms = None
     if ar_events:
         allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
@@ -387,8 +490,75 @@ def run_rank(args):
 
     # the same step on the reference's duplicate lists (tile_cull = 0: sort keys / point lists bit-identical to the
     # reference's), reported beside the headline value
+    # ---- N > 1 only: what makes ONE multi-GPU run decisive -- the other sharding mode's value and a
+    # collective-vs-point-to-point A/B of the gradient bucket's all-reduce, in the same invocation on the same ranks
+    extras = None
+    if world > 1 and not args.no_extras and not args.autograd_path:
+        extras = {}
+        n_bucket = sum(p.numel() for p in params)
+
+        def ab_allreduce(kind, iters=8):
+            buf = torch.full((n_bucket,), 1.0 / 1024.0, dtype=torch.float32, device=dev)
+            keep_mode = sharding.ALLREDUCE_MODE
+            sharding.ALLREDUCE_MODE = kind
+            try:
+                for _ in range(2):
+                    sharding._allreduce(buf, True, None)
+                sync()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    sharding._allreduce(buf, True, None)      # (a mean: the values stay put however often it runs)
+                e1.record()
+                torch.cuda.synchronize()
+                t = torch.tensor([e0.elapsed_time(e1) / iters], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ok = bool(torch.all(buf == buf[0]).item()) and abs(float(buf[0].item()) - 1.0 / 1024.0) < 1e-9
+            finally:
+                sharding.ALLREDUCE_MODE = keep_mode
+            ms_ = float(t.item())
+            nbytes = 4 * n_bucket
+            return {"ms": round(ms_, 4), "bytes": nbytes, "algbw_GBps": round(nbytes / (ms_ * 1e-3) / 1e9, 1),
+                    "busbw_GBps": round(2.0 * (world - 1) / world * nbytes / (ms_ * 1e-3) / 1e9, 1), "values_ok": ok}
+        try:
+            extras["allreduce_ab"] = {"collective": ab_allreduce("collective"), "p2p": ab_allreduce("p2p"),
+                                      "note": "the whole gradient bucket (P * (11 + 3 M) floats), in-place mean, alone on the "
+                                              "stream: HIP events around 8 back-to-back calls, max over ranks; busbw = "
+                                              "2 (G-1)/G * bytes / time"}
+        except Exception as ex:            # (never lose the headline line to a secondary region)
+            extras["allreduce_ab"] = {"error": repr(ex)}
+        other = "subframes" if args.shard == "views" else "views"
+        try:
+            if loop._fused is not None:
+                loop._fused._poll(block=True)
+                loop._fused.invalidate()           # the headline loop's graphs and pool go back to the driver
+            motion2 = make_view(0 if other == "subframes" else rank)
+            loop2 = make_loop(other, motion2)
+            it2 = {"it": 10 ** 6}
+
+            def step2():
+                it2["it"] += 1
+                loop2.step(it2["it"], 0)
+            for _ in range(max(args.warmup, 4)):
+                step2()
+            n2 = max(10, args.steps // 4)
+            dt2 = timed(n2, profile=False, step_fn=step2)
+            extras["other_mode"] = {
+                "sharding": other, "scaling": "strong" if other == "subframes" else "weak", "steps": n2,
+                "value": round((K if other == "subframes" else world * K) * n2 / dt2, 2),
+                "ms_per_step": round(dt2 / n2 * 1e3, 3),
+                "graph": None if loop2._fused is None else {"captured": loop2._fused.captured,
+                                                            "replayed": loop2._fused.replayed},
+                "note": ("strong scaling: ONE view per step, its K subframes split over the GPUs (BASELINE.json cfg4's "
+                         "wording; the reference's single-view step exactly)" if other == "subframes" else
+                         "weak scaling: one view per GPU per step (a G-view mini-batch)")}
+            del loop2, motion2
+        except Exception as ex:
+            extras["other_mode"] = {"sharding": other, "error": repr(ex)}
+        sync()
+
     ref_lists = None
-    if world == 1 and not args.no_reference_lists and dgr.TILE_CULL:
+    if world == 1 and emu is None and not args.no_reference_lists and dgr.TILE_CULL:
         dgr.TILE_CULL = False
         if loop._fused is not None:
             loop._fused._poll(block=True)
@@ -422,7 +592,7 @@ def run_rank(args):
         s = (args.sh_degree + 1) ** 2
         frac_k = 1.0
         if subframes_mode:       # this rank's share of the K subframes
-            k0, k1 = sharding.shard_range(K, rank, world)
+            k0, k1 = sharding.shard_range(K, shard_id[0], shard_id[1])
             frac_k = (k1 - k0) / K
         bytes_by_stage = stage_bytes(P, Pv_tot, R_tot * frac_k, N, K * frac_k, s)
         stages = {}
@@ -486,11 +656,31 @@ def run_rank(args):
         }
         if ref_lists is not None:
             result["value_reference_lists"] = ref_lists
+        if per_rank is not None:
+            result["config"]["per_rank"] = per_rank
+        if extras is not None:
+            result["extras"] = extras
+        if world > 1:
+            result["config"]["rccl"] = parse_rccl_log(rccl_log)
+            result["config"]["backend"] = dist.get_backend()
+        if emu is not None:
+            # not the metric line: one rank's share of a G-GPU step, measured alone on one GPU with degenerate collectives
+            k0e, k1e = sharding.shard_range(K, emu[0], emu[1]) if subframes_mode else (0, K)
+            result = {"emulated_shard": {"rank": emu[0], "world": emu[1], "sharding": args.shard,
+                                         "subframes_of_this_rank": k1e - k0e, "K": K,
+                                         "ms_per_step": round(ms_per_step, 3), "steps": args.steps,
+                                         "graph": graph_info,
+                                         "eager_ms_per_step": None if graph_info is None else graph_info.get("eager_ms_per_step"),
+                                         "bucket_bytes": 4 * sum(p.numel() for p in params),
+                                         "blur_bytes": 12 * H * W,
+                                         "note": "one rank's launches between its exchanges (one-rank process group on the "
+                                                 "real backend: every collective is degenerate); NOT a throughput figure"},
+                      "config": result["config"], "stages": stages}
         # PMC counters cannot be collected inside this run (rocprofv3 wraps the process): traffic / VALU figures are the
         # committed measurements of the same command, with their provenance, or null
         for fname, key in (("traffic_r04.json", "traffic"), ("valu_r04.json", "valu")):
             path = os.path.join(ROOT, "profiles", fname)
-            if not os.path.exists(path) or world != 1:
+            if not os.path.exists(path) or world != 1 or emu is not None:
                 continue
             try:
                 doc = json.load(open(path))
@@ -515,7 +705,7 @@ def run_rank(args):
                             "source": f"profiles/{fname}: {doc.get('_source', '')}"}
             except Exception:
                 pass
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and emu is None and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_port(scene, K // 2)
             try:
                 result["cpu_baseline_torch_naive"] = cpu_baseline_torch_naive(scene, K // 2)

@@ -29,7 +29,7 @@ def default_optimization_params(**overrides):
 class TrainingLoop:
     def __init__(self, gaussians, cam_motion_module, opt, cameras_extent, white_background=False, spatial_lr_scale=None,
                  distributed=False, tone_mapping=None, fused_step="auto", speculative=True, log_losses=True, graph="auto",
-                 ar_chunks=1, graph_min_reuse=8):
+                 ar_chunks=1, graph_min_reuse=8, emulate_shard=None):
         """distributed = "views" (or True): every rank steps on its own view (the caller passes each rank its cam_idx);
         the per-Gaussian AND trajectory gradients are averaged over ranks (one flat all-reduce + one few-KB one) before
         the Adam step and the densification statistics are combined before every densify_and_prune, so the replicas
@@ -58,6 +58,11 @@ class TrainingLoop:
         before the next densification: densification_interval / number of views >= graph_min_reuse (the reference's
         defaults, 100 iterations and tens of views, stay eager until densify_until_iter and replay afterwards).
         log_losses=False skips forming the scalar "loss" entry of step()'s result (two tiny launches).
+        emulate_shard=(rank, world) (measurement only, bench.py --emulate-shard): in a ONE-rank process group, run the
+        sharded step of `distributed` mode as rank `rank` of `world` would -- in "subframes" mode its slice of the view's
+        subframes (shard_range), in "views" mode the whole view through the sharded code path -- with every collective
+        degenerate (one rank): what a rank computes between its exchanges, timed on one GPU.  The loss couples the
+        subframes, so the values of an emulated "subframes" step are meaningless; its launches are the real rank's.
         Not carried over from train.py: logging / visualiser / checkpoint-saving calls and `args.flag`."""
         self.gaussians, self.motion, self.opt, self.extent = gaussians, cam_motion_module, opt, cameras_extent
         self.mode = {True: "views", False: None, None: None}.get(distributed, distributed)
@@ -96,6 +101,7 @@ class TrainingLoop:
         self._flag_words = []
         self._last_iteration = None
         self._front_failed = False  # the captured front of sharded steps was refused once: stay eager
+        self.emulate_shard = None if emulate_shard is None else (int(emulate_shard[0]), int(emulate_shard[1]))
         self._fused = None
         if fused_step:
             try:
@@ -199,7 +205,7 @@ class TrainingLoop:
             self._drain_dist_flags(lag=2)
         if self.mode == "subframes":
             import torch.distributed as dist
-            shard = (dist.get_rank(), dist.get_world_size())
+            shard = self.emulate_shard or (dist.get_rank(), dist.get_world_size())
             bg, uniform = self._shared_draws(bg, uniform)
         ar = None
         if self.distributed and self.ar_chunks > 1:      # the bucket is reduced inside run(), chunk by chunk
@@ -372,7 +378,7 @@ class TrainingLoop:
         import torch.distributed as dist
         from . import sharding
         g, opt = self.gaussians, self.opt
-        rank, world = dist.get_rank(), dist.get_world_size()
+        rank, world = self.emulate_shard or (dist.get_rank(), dist.get_world_size())
         # one view, one background, one alignment jitter: every rank uses rank 0's draws (the fused path does the same)
         bg, uniform = self._shared_draws(self._bg_host.to(g._xyz.device),
                                          None if self._uni_host is None else self._uni_host.to(g._xyz.device))

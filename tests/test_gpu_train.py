@@ -1154,3 +1154,59 @@ def test_two_ranks_bench_launcher(gpu, mode):
     assert line["config"]["ar_chunks"] == 4
     # the step up to its first collective was replayed as a captured hipGraph (FusedStep.replay_front)
     assert line["config"]["graph"] is not None and line["config"]["graph"]["replayed"] > 0, line["config"]["graph"]
+
+
+def test_two_ranks_bench_in_the_drivers_launch_form(gpu):
+    """The driver's scaling run starts bench.py as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`: bench.py is then ONE OF the ranks
+    (RANK / LOCAL_RANK / WORLD_SIZE from the environment, no self-launch).  Two ranks on this box's one GPU over gloo.
+    The line must carry what makes one multi-GPU run decisive: both sharding modes' values, the collective-vs-p2p
+    all-reduce A/B of the gradient bucket, every rank's own step time."""
+    import json
+    import os
+    import socket
+    import sys
+    root, tool, env = _two_rank_env()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--config",
+                "cfg2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], env)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, out[-2000:]                       # rank 0 prints, the others stay silent
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["sharding"] == "views"
+    assert line["config"]["ranks_in_process_group"] == 2 and line["config"]["backend"] == "gloo"
+    pr = line["config"]["per_rank"]
+    assert len(pr["ms_per_step_by_rank"]) == 2 and pr["min_ms_per_step"] <= pr["max_ms_per_step"] <= line["ms_per_step"] * 1.01
+    ex = line["extras"]
+    assert ex["other_mode"]["sharding"] == "subframes" and ex["other_mode"]["scaling"] == "strong"
+    assert ex["other_mode"]["value"] > 0, ex["other_mode"]
+    ab = ex["allreduce_ab"]
+    assert ab["collective"]["values_ok"] and ab["p2p"]["values_ok"], ab
+    assert ab["collective"]["bytes"] == ab["p2p"]["bytes"] == 4 * 100_000 * (11 + 27)
+    assert ab["collective"]["busbw_GBps"] > 0 and ab["p2p"]["busbw_GBps"] > 0
+    assert line["config"]["rccl"] is None                     # (gloo here; the RCCL log exists on the driver's node only)
+
+
+def test_emulated_shard_slice_of_the_bench(gpu):
+    """bench.py --emulate-shard r/G: rank r's share of a G-GPU step on ONE GPU, one-rank RCCL group, collectives
+    degenerate -- the measured input of DESIGN.md's predicted scaling table (tools/predict_scaling.py)."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DGS_DIST_BACKEND", "DGS_DIST_ONE_DEVICE"):
+        env.pop(k, None)
+    got = {}
+    for mode, shard in (("subframes", "1/4"), ("views", "1/4")):
+        out = _run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg2", "--steps", "6", "--warmup", "2",
+                    "--shard", mode, "--emulate-shard", shard], env)
+        line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+        assert "metric" not in line, "an emulated slice must not look like the metric line"
+        got[mode] = line["emulated_shard"]
+        assert got[mode]["world"] == 4 and got[mode]["rank"] == 1 and got[mode]["ms_per_step"] > 0
+    assert got["subframes"]["subframes_of_this_rank"] == 2 and got["views"]["subframes_of_this_rank"] == 9   # K = 9: [2, 4)
+    assert got["subframes"]["ms_per_step"] < got["views"]["ms_per_step"]

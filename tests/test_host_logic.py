@@ -338,3 +338,43 @@ def test_poll_charges_every_overflow_to_its_own_step():
     assert fs.dropped == 2 and fs.retry == [("B", "all"), ("B", "all")]
     assert fs._seen[("A", 5, 0)] == [100, 101, 102] and fs._seen[("B", 5, 0)] == [900, 901]
     assert not fs._pending and len(fs._free_hosts) == 5
+
+
+def test_rccl_log_parser_reads_version_algorithm_and_topology(tmp_path):
+    """bench.py --gpus N writes every rank's RCCL log to a file (NCCL_DEBUG=INFO, set before init) and reports what the
+    library chose ("verify which algorithm it picks").  The parser on a log in NCCL's / RCCL's INFO format."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dgs_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    log = tmp_path / "rank0.log"
+    log.write_text(
+        "host:1:1 [0] NCCL INFO RCCL version 2.22.3+hip6.4 HEAD:abc\n"
+        "host:1:9 [0] NCCL INFO Channel 00/16 :    0   1   2   3   4   5   6   7\n"
+        "host:1:9 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 1/-1/-1->0->-1\n"
+        "host:1:9 [0] NCCL INFO Connected all rings\n"
+        "host:1:9 [0] NCCL INFO comm 0x1 rank 0 nRanks 8 nNodes 1 localRanks 8 localRank 0 MNNVL 0\n"
+        "host:1:9 [0] NCCL INFO ncclCommInitRankConfig comm 0x1 rank 0 nranks 8 cudaDev 0 - Init COMPLETE\n"
+        "host:1:1 [0] NCCL INFO AllReduce: opCount 5 sendbuff 0x1 recvbuff 0x1 count 38000000 datatype 7 op 4 root 0\n"
+        "host:1:1 [0] NCCL INFO 152000000 Bytes -> Algo 1 proto 2 time 901.5\n"
+        "host:1:1 [0] NCCL INFO AllReduce: opCount 6 sendbuff 0x1 recvbuff 0x1 count 1 datatype 2 op 2 root 0\n"
+        "host:1:1 [0] NCCL INFO 4 Bytes -> Algo 0 proto 0 time 8.1\n"
+        "host:1:1 [0] NCCL INFO 152000000 Bytes -> Algo 1 proto 2 time 901.5\n")
+    got = bench.parse_rccl_log(str(log))
+    assert got["version"].startswith("RCCL 2.22.3")
+    assert got["algo_proto_by_message_bytes"]["152000000"] == {"Ring/Simple": 2}
+    assert got["algo_proto_by_message_bytes"]["4"] == {"Tree/LL": 1}
+    assert got["calls_logged"] == {"AllReduce": 2}
+    assert any("Init COMPLETE" in ln for ln in got["init_lines"]) and got["init_lines_total"] >= 5
+    assert bench.parse_rccl_log(str(tmp_path / "missing.log")) is None
+    # a rank only redirects its log for the real backend
+    keep = {k: os.environ.get(k) for k in ("DGS_DIST_BACKEND", "NCCL_DEBUG", "NCCL_DEBUG_FILE", "NCCL_DEBUG_SUBSYS")}
+    try:
+        os.environ["DGS_DIST_BACKEND"] = "gloo"
+        assert bench.rccl_log_setup(0) is None and os.environ.get("NCCL_DEBUG") == keep["NCCL_DEBUG"]
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
