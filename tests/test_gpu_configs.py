@@ -97,11 +97,17 @@ def forward_against_oracle(st_color, st_depth, st_ncontrib, st_finalT, run, sc, 
     return worst_frac
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "metric", "cfg3"])
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg2_sh3", "metric", "cfg3"])
 def test_config_as_benchmarked(gpu, cfg):
+    """cfg2_sh3: SURVEY 8's secondary variant (D = 3, M = 16, the upstream-3DGS default; SH paths forward.cu:20-82,
+    backward.cu:20-140) at cfg2's size -- preprocess_fwd_kernel<3> and geometry_bwd_kernel<16> as profiles/bench_r05_metric_sh3.json
+    times them."""
     import torch
     t0 = time.time()
-    sc = synthetic.make_config(cfg)
+    sh3 = cfg.endswith("_sh3")
+    cfg = cfg.split("_")[0]
+    sc = synthetic.make_config(cfg, sh_degree=3) if sh3 else synthetic.make_config(cfg)
+    assert sc["sh"].shape[1] == (16 if sh3 else 9) and sc["sh_degree"] == (3 if sh3 else 2)
     K, P, W, H = sc["K"], sc["P"], sc["W"], sc["H"]
     assert K == (9 if cfg == "cfg2" else 15)
     act = kernel_activated_scene(sc)

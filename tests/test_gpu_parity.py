@@ -811,6 +811,68 @@ def test_fused_pose_kernel_matches_torch_path(gpu, K, C, curve):
         assert np.abs(a - b).max() <= tol, f"{n}: {np.abs(a - b).max()} vs tol {tol}"
 
 
+def test_pose_kernel_on_the_reference_golden_vectors(gpu):
+    """The reference-generated fixture (tests/golden/pose_golden.npz: se3_exp_map of the imported reference,
+    utils/pytorch3d_functions.py:373-457) fed STRAIGHT to dgs_pose_forward -- no torch pose path in between (VERDICT r4,
+    weak 8): every golden twist as a curve of order 0 (one control point: the Bezier is that point for every nu), K = 2.
+    world_view, full_proj and the camera centre must be the reference's c2w turned into MiniCam's tensors
+    (scene/motion.py:248-252,277-282, scene/cameras.py:73-74): exact zero rotation, near-zero rotation (the eps clamp)
+    and a large angle are among the 24 rows."""
+    import ctypes
+    import torch
+    from deblurgs_amd import _lib
+    L = _lib.lib()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_golden.npz"))
+    proj = synthetic.projection_matrix(0.01, 100.0, 1.0, 0.7).T.astype(np.float32)      # transposed, as RefCamera stores it
+    projT = torch.from_numpy(np.ascontiguousarray(proj)).to(gpu)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    worst = 0.0
+    for i in range(g["se3"].shape[0]):
+        ct = torch.from_numpy(g["se3"][i:i + 1, :3].copy()).to(gpu)
+        cr = torch.from_numpy(g["se3"][i:i + 1, 3:].copy()).to(gpu)
+        nu = torch.tensor([0.25, 0.875], device=gpu)
+        view = torch.empty((2, 4, 4), device=gpu)
+        full = torch.empty((2, 4, 4), device=gpu)
+        cam = torch.empty((2, 3), device=gpu)
+        _lib.check(L.dgs_pose_forward(ct.data_ptr(), cr.data_ptr(), nu.data_ptr(), projT.data_ptr(), 0, 2, 0,
+                                      view.data_ptr(), full.data_ptr(), cam.data_ptr(), st), "dgs_pose_forward")
+        torch.cuda.synchronize()
+        c2w = g["exp64"][i]                           # row-vector [[R, 0], [T, 1]]
+        R, T = c2w[:3, :3].T, c2w[3, :3]
+        want = np.eye(4)
+        want[:3, :3] = R
+        want[3, :3] = -T @ R
+        for k in range(2):
+            v = view[k].cpu().double().numpy()
+            assert np.abs(v - want).max() <= 2e-6, (i, np.abs(v - want).max())
+            assert np.abs(v - want).max() <= np.abs(g["exp32"][i] - g["exp64"][i]).max() + 1e-6   # no worse than the fp32 reference
+            assert np.abs(cam[k].cpu().double().numpy() - T).max() <= 2e-6
+            assert np.abs(full[k].cpu().double().numpy() - want @ proj.astype(np.float64)).max() <= 2e-5
+            worst = max(worst, np.abs(v - want).max())
+    print(f"dgs_pose_forward vs the reference's se3_exp_map (float64 golden): max |diff| {worst:.2e}")
+
+
+def test_cfg1_exact_shape_on_the_device(gpu):
+    """BASELINE.json configs[0] (1k Gaussians, 256 x 256, K = 1: the vanilla-3DGS plumbing case the CPU suite runs through
+    the oracle) at its exact shape through the HIP path: lists bit-exact, image and gradients against the oracle."""
+    sc = synthetic.make_config("cfg1")
+    assert (sc["P"], sc["W"], sc["H"], sc["K"]) == (1000, 256, 256, 1)
+    hipst = hip_forward_state(sc, 1)
+    ora0 = oracle_forward(sc, 0)
+    assert np.array_equal(hipst["radii"][0], ora0["radii"])
+    gC, gD = _grads(sc, 1, depth=True)
+    hip = hip_forward_backward(sc, 1, gC, gD)
+    ora = oracle_forward_backward(sc, 1, gC, gD)
+    un = unstable_pixels(ora["states"][0])
+    assert un.mean() < 0.01
+    assert np.abs(hip["color"][0] - ora["color"][0]).max(axis=0)[~un].max() <= IMG_TOL
+    assert np.array_equal(hip["radii"], ora["radii"])
+    for key in GRAD_KEYS:
+        e = relerr(hip[key].reshape(ora[key].shape), ora[key])
+        assert e <= GRAD_TOL, f"{key}: rel err {e:.3e}"
+    sharp_backward_check(sc, 1, depth=True)
+
+
 def test_densification_stats_match_reference_loop(gpu):
     """dgs_densify_stats against the reference's per-subframe Python loop (train.py:188-193,
     scene/gaussian_model.py:456-458) written with torch ops."""
