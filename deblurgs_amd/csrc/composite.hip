@@ -74,6 +74,25 @@ __device__ __forceinline__ float dgs_power2(float A, float B, float C, float dx,
   return fmaf(C * dy, dy, dx * u);
 }
 
+// DGS_EXACT_POWER=1 (A/B build only, tools/r05_calls/parity_ab.sh; never the shipped library): the three places where the
+// per-pair arithmetic departs from the letter of the reference are put back --
+//   * `power` in the natural domain with the reference's own expression and term order, every operation rounded on its
+//     own (forward.cu:351 / backward.cu:572: -0.5f * (a dx dx + c dy dy) - b dx dy), then ONE multiply by log2(e) in front
+//     of v_exp_f32 (instead of the conic pre-scaled into the log2 domain: one more rounding per term);
+//   * T / (1 - alpha) divided (backward.cu:579) instead of multiplied by v_rcp_f32's 1-ulp reciprocal;
+//   * the `power > 0` skip kept for every entry (forward.cu:354, backward.cu:573), also for positive definite conics.
+// DESIGN.md 5 has the measured effect on the unstable-pixel mask, on dL_dconic and on the step time.
+#ifndef DGS_EXACT_POWER
+#define DGS_EXACT_POWER 0
+#endif
+#if DGS_EXACT_POWER
+__device__ __forceinline__ float dgs_power_ref(float a, float b, float c, float dx, float dy) {
+  const float t0 = __fmul_rn(__fmul_rn(a, dx), dx), t1 = __fmul_rn(__fmul_rn(c, dy), dy);
+  const float t2 = __fmul_rn(__fmul_rn(b, dx), dy);
+  return __fsub_rn(__fmul_rn(-0.5f, __fadd_rn(t0, t1)), t2);
+}
+#endif
+
 // v_min_f32 without the canonicalising v_max_f32 x, x that fminf() of a value merged from two control-flow paths gets
 // (au is never a signalling NaN: it comes out of v_mul / v_cndmask)
 __device__ __forceinline__ float dgs_min_raw(float c, float x) {
@@ -81,6 +100,16 @@ __device__ __forceinline__ float dgs_min_raw(float c, float x) {
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(c), "v"(x));
   return r;
 }
+
+// DGS_TIMELINE=1 (diagnostic build only, tools/tile_timeline.py): every wave of the compositing backward leaves its
+// start and end time (s_memrealtime, 100 MHz) in a caller-provided buffer, [K*T][2] u64 by tile -- how many waves are
+// resident over the launch, i.e. how long the tail of the wave-per-tile schedule is.
+#ifndef DGS_TIMELINE
+#define DGS_TIMELINE 0
+#endif
+#if DGS_TIMELINE
+__device__ unsigned long long* g_timeline = nullptr;
+#endif
 
 using CullGauss = DgsCull;
 #define make_cull dgs_make_cull
@@ -156,8 +185,13 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     }
     // the conic goes to LDS pre-multiplied by -0.5 log2(e) (-log2(e) for the cross term): the per-pair exponent is
     // then a 5-instruction quadratic form that feeds v_exp_f32 directly (forward and backward use the same bits)
+#if DGS_EXACT_POWER
+    s_row[w][3 * lane] = make_float4(A.x, A.y, A.z, A.w);
+    s_row[w][3 * lane + 1] = make_float4(B.x, B.y, B.z, B.w);
+#else
     s_row[w][3 * lane] = make_float4(A.x, A.y, A.z * K_HALF_LOG2E, A.w * K_LOG2E);
     s_row[w][3 * lane + 1] = make_float4(B.x * K_HALF_LOG2E, B.y, B.z, B.w);
+#endif
     s_row[w][3 * lane + 2] = make_float4(Cc.x, Cc.y, 0.0f, 0.0f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -187,9 +221,15 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         if ((m[q] >> j) & 1ull) {  // wave-uniform: this Gaussian can reach quadrant q
           const float dx = a.x - ((q & 1) ? pxf1 : pxf0);
           const float dy = a.y - ((q >> 1) ? pyf1 : pyf0);
+#if DGS_EXACT_POWER
+          const float power = dgs_power_ref(a.z, a.w, b.x, dx, dy);
+          const float alpha_raw = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power * 1.4426950408889634f));
+          const bool ok = (power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
+#else
           const float power = dgs_power2(a.z, a.w, b.x, dx, dy);  // log2(e) * the reference's `power`
           const float alpha_raw = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(power));
           const bool ok = (!CHECK || power <= 0.0f) && (alpha_raw >= 1.0f / 255.0f);
+#endif
           const float alpha = ok ? alpha_raw : 0.0f;
           const float test_T = T[q] * (1.0f - alpha);
           const bool stop = test_T < 0.0001f;      // also every pair of a pixel that is already done (T < 0)
@@ -250,6 +290,9 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   __shared__ __attribute__((aligned(16))) float s_part[CW][10][68];
   TileCtx t;
   if (!load_tile_ctx(v, ranges, per_xcd, t)) return;
+#if DGS_TIMELINE
+  const unsigned long long t_begin = wall_clock64();
+#endif
   const int lane = dgs_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lx = lane & 7, ly = lane >> 3;
   const int px0 = t.tx * DGS_TILE + lx, py0 = t.ty * DGS_TILE + ly;
@@ -350,8 +393,13 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
         const bool hit = has && (base + lane < maxq[q]) && cull_hit(cg, ex - 7.0f, ex, ey - 7.0f, ey);
         m[q] = __ballot(hit);
       }
+#if DGS_EXACT_POWER
+      s_row[w][3 * lane] = make_float4(A.x, A.y, A.z, A.w);
+      s_row[w][3 * lane + 1] = make_float4(B.x, B.y, B.z, B.w);
+#else
       s_row[w][3 * lane] = make_float4(A.x, A.y, A.z * K_HALF_LOG2E, A.w * K_LOG2E);
       s_row[w][3 * lane + 1] = make_float4(B.x * K_HALF_LOG2E, B.y, B.z, B.w);
+#endif
       // the duplicate's contribution-row slot rides in the row (after the colour's third channel, where the depth sits
       // when a depth gradient is asked for): the entry loop gets it with the row's own LDS read instead of a v_readlane
       s_row[w][3 * lane + 2] = HASDEPTH ? make_float4(Cc.x, Cc.y, __uint_as_float(u), 0.0f)
@@ -412,13 +460,23 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           // so the results are bit-identical to skipping.  The recurrence is applied eagerly (right after the pair is
           // used) instead of one pair late with a remembered last_alpha / last_color as in the reference: same
           // operations in the same order, 5 fewer live registers per pixel.
+#if DGS_EXACT_POWER
+          const float power = dgs_power_ref(a.z, a.w, b.x, dx, dy);
+          const float au_any = b.y * __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+          const bool ok = (pos < last[q]) && (power <= 0.0f) && (au_any >= 1.0f / 255.0f);
+#else
           const float power = dgs_power2(a.z, a.w, b.x, dx, dy);  // log2(e) * the reference's `power`
           const float au_any = b.y * __builtin_amdgcn_exp2f(power);
           const bool ok = (pos < last[q]) && (!CHECK || power <= 0.0f) && (au_any >= 1.0f / 255.0f);
+#endif
           const float au = ok ? au_any : 0.0f;  // opacity * G: the unclamped alpha the backward differentiates
           const float alpha = dgs_min_raw(0.99f, au);
+#if DGS_EXACT_POWER
+          T[q] = T[q] / (1.0f - alpha);
+#else
           const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
           T[q] = T[q] * inv1ma;
+#endif
           const float dchannel_dcolor = alpha * T[q];
           // dL_dalpha = sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch] (backward.cu:590-600) only ever uses the
           // colour behind the pair through its dot product with dL_dpixel, and that dot product obeys the same
@@ -519,9 +577,23 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+#if DGS_TIMELINE
+  if (lane == 0 && g_timeline != nullptr) {
+    const size_t gw = (size_t)t.k * v.T + (size_t)t.ty * v.gx + t.tx;
+    g_timeline[2 * gw] = t_begin;
+    g_timeline[2 * gw + 1] = wall_clock64();
+  }
+#endif
 }
 
 }  // namespace
+
+#if DGS_TIMELINE
+extern "C" int dgs_debug_set_timeline(void* buffer) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buffer);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 static uint32_t per_xcd_blocks(const DgsView& v) {
   const uint64_t KT = (uint64_t)v.K * v.T;

@@ -78,12 +78,24 @@ def check_fused_binning_properties(st, cull, name):
     assert st["sort_bits"] == 32 + oracle.higher_msb(K * T), name
 
 
+DISAGREE = {}      # per call: pixels whose colour / n_contrib differ from the oracle's, masked or not (the parity A/B's figure)
+
+
 def forward_against_oracle(st_color, st_depth, st_ncontrib, st_finalT, run, sc, ks):
     worst_frac = 0.0
+    DISAGREE.clear()
+    DISAGREE.update(pixels=0, colour_off=0, colour_off_unmasked=0, n_contrib_off=0, masked=0)
     for k in ks:
         o, un = run.states[k], run.unstable[k]
         frac = float(un.mean())
         worst_frac = max(worst_frac, frac)
+        off = np.abs(st_color[k] - o["color"]).max(axis=0) > IMG_TOL
+        DISAGREE["pixels"] += int(un.size)
+        DISAGREE["masked"] += int(un.sum())
+        DISAGREE["colour_off"] += int(off.sum())
+        DISAGREE["colour_off_unmasked"] += int((off & ~un).sum())
+        if st_ncontrib is not None:
+            DISAGREE["n_contrib_off"] += int((st_ncontrib[k] != o["n_contrib"]).sum())
         assert frac < 0.01, f"unstable pixel fraction {frac}"          # exempted pixels are counted, not assumed rare
         dc = np.abs(st_color[k] - o["color"]).max(axis=0)
         dd = np.abs(st_depth[k][0] - o["depth"][0]) / sc["z_far"]
@@ -149,6 +161,7 @@ def test_config_as_benchmarked(gpu, cfg):
     frac = forward_against_oracle(st1["color"].cpu().numpy(), st1["depth"].cpu().numpy(),
                                   st0["n_contrib"].cpu().numpy().view(np.uint32), st1["final_T"].cpu().numpy(), run, sc,
                                   range(K))
+    fwd_stats = dict(DISAGREE)
     del st0, st1
     torch.cuda.empty_cache()
 
@@ -164,7 +177,11 @@ def test_config_as_benchmarked(gpu, cfg):
     hip0 = hip_cloud_forward_backward(sc, K, gC, cull=False)
     for key in CLOUD_KEYS + ["color", "depth"]:
         assert np.array_equal(hip0[key], hip[key]), f"tile_cull 0 vs 1: {key}"
-    print(f"\n[{cfg}] unstable fraction {frac:.2e}; errors (key, hip, oracle-fp32-noise):")
+    print(f"\n[{cfg}{'_sh3' if sh3 else ''}] lib {os.path.basename(os.environ.get('DGS_LIB_PATH', 'libdgs_hip.so'))}: of "
+          f"{fwd_stats['pixels']} pixels {fwd_stats['masked']} are masked (oracle within its own margins), "
+          f"{fwd_stats['colour_off']} differ from the oracle by more than {IMG_TOL} in colour ({fwd_stats['colour_off_unmasked']} "
+          f"of them unmasked), {fwd_stats['n_contrib_off']} in n_contrib")
+    print(f"[{cfg}] unstable fraction {frac:.2e}; errors (key, hip, oracle-fp32-noise):")
     for r in report:
         print("   ", r)
     print(f"[{cfg}] {time.time() - t0:.0f} s")
