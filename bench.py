@@ -176,6 +176,10 @@ def stage_bytes(P, Pv_tot, R_tot, N, K, s):
         "composite_fwd": (28 + 16) * R_tot + 24 * N * K,
         "composite_bwd": 44 * R_tot + 24 * N * K + 2 * 48 * Pv_tot,
         "geometry_bwd": Pv_tot * (100 + 12 * s + 48) + P * (40 + 12 * s),
+        # second stage of the atomics-free reduction (48-byte contribution rows -> per-pair totals): work the reference does
+        # with atomics inside its render backward, so SURVEY 8d's model gives it no bytes of its own (the 2 * 48 Pv term of
+        # composite_bwd is the algorithmic cost of those sums); the stage's own traffic is 48 R + 64 Pv
+        "contrib_reduce": 0,
         "depth_order": 24 * P * K,   # ideal one-read-one-write sort of the K*P (key, index) pairs
         # tile_cull: the per-slot test in natural order (tiles_touched in, 16-byte record + count out per pair, 36 B of
         # each visible pair's row), the counts gathered into depth order (order, flag, count in, count out) and their scan
@@ -457,6 +461,7 @@ def run_rank(args):
     # (N ranks: the step up to its first collective is replayed -- FusedStep.replay_front)
     replaying = loop.graph and loop._fused is not None and not args.autograd_path and not args.no_graph
     dt = timed(args.steps, profile=not replaying)
+    stats["profiled_steps"] = args.steps
     per_rank = None
     if world > 1:       # every rank's own time for the region (the headline divides by the slowest)
         mine = torch.tensor([stats["dt_local"]], dtype=torch.float64, device=dev)
@@ -484,6 +489,7 @@ def run_rank(args):
             step()
         n_prof = max(10, min(args.steps, 30))
         dt_eager = timed(n_prof, profile=True)
+        stats["profiled_steps"] = n_prof
         graph_info["eager_ms_per_step"] = round(dt_eager / n_prof * 1e3, 3)
         loop.graph = True
     prof = _lib.profile_read()
@@ -602,7 +608,11 @@ def run_rank(args):
             avg_ms = ms / calls
             gbs = bytes_by_stage[name] / (avg_ms * 1e-3) / 1e9
             stages[name] = {"avg_ms": round(avg_ms, 4), "launches": calls, "alg_bytes": int(bytes_by_stage[name]),
-                            "GBps": round(gbs, 1)}
+                            "GBps": round(gbs, 1), "ms_per_step": round(ms / max(stats["profiled_steps"], 1), 4)}
+            if name == "contrib_reduce":
+                moved = 48 * R_tot * frac_k + 64 * Pv_tot
+                stages[name]["moved_bytes"] = int(moved)
+                stages[name]["moved_GBps"] = round(moved / (avg_ms * 1e-3) / 1e9, 1)
         dom = max(stages, key=lambda n: stages[n]["avg_ms"])
         total_bytes = sum(bytes_by_stage.values())
         ms_per_step = dt / args.steps * 1e3

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DGS_LIB_PATH") or os.path.join(_HERE, "libdgs_hip.so"
 
 DGS_MAX_K = 128
 STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "composite_fwd", "composite_bwd", "geometry_bwd",
-          "depth_order", "tile_cull"]
+          "depth_order", "tile_cull", "contrib_reduce"]
 
 _c_f32p = ctypes.c_void_p  # device pointers are passed as integers
 

@@ -731,8 +731,12 @@ static int backward_impl(const DgsProblem* p, const DgsBackwardIO* io, int which
   if (which & 1)
     DGS_STAGE(DGS_STAGE_COMPOSITE_BWD, "composite backward",
               dgs_launch_composite_bwd(v, c, p->bg, io->dL_dout_color, io->dL_dout_depth, contrib, s));
-  DGS_STAGE(DGS_STAGE_GEOMETRY_BWD, "geometry backward",
-            dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s, which, g_begin, g_end));
+  if (which & 1)
+    DGS_STAGE(DGS_STAGE_CONTRIB_REDUCE, "contribution-row totals",
+              dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s, 1, 0, 0));
+  if (which & 6)
+    DGS_STAGE(DGS_STAGE_GEOMETRY_BWD, "geometry backward",
+              dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s, which & 6, g_begin, g_end));
   return DGS_OK;
 }
 

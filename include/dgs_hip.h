@@ -425,7 +425,9 @@ int dgs_cloud_activations(int32_t P, const float* scaling, const float* rotation
 #define DGS_STAGE_GEOMETRY_BWD 7
 #define DGS_STAGE_DEPTH_ORDER 8 /* sort of the (k, Gaussian) pairs by depth that precedes the duplication */
 #define DGS_STAGE_TILE_CULL 9   /* tile_cull: per-slot ellipse test + count, and the scan of the counts */
-#define DGS_STAGE_COUNT 10
+#define DGS_STAGE_CONTRIB_REDUCE 10 /* backward: per-(subframe, Gaussian) totals of the contribution rows (the second
+                                     * stage of the atomics-free reduction; no counterpart in the reference) */
+#define DGS_STAGE_COUNT 11
 int dgs_profile_enable(int32_t on);
 int dgs_profile_reset(void);
 /* Synchronises on the recorded events; ms[i] = summed duration of stage i, calls[i] = launches timed. */

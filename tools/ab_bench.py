@@ -39,7 +39,7 @@ def main():
             d = json.loads(line[-1])
             rows.setdefault(lib, []).append(d)
     names = ["preprocess", "depth_order", "tile_cull", "duplicate", "sort", "ranges", "composite_fwd", "composite_bwd",
-             "geometry_bwd", "scan"]
+             "contrib_reduce", "geometry_bwd", "scan"]
     print(f"{'lib':28s} {'ms/step':>8s} " + " ".join(f"{n[:9]:>9s}" for n in names))
     for lib, ds in rows.items():
         for d in ds:

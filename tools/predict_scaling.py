@@ -62,7 +62,8 @@ def main():
            "rows": []}
     views = run_bench(common + ["--shard", "views", "--ar-chunks", str(a.chunks), "--emulate-shard", "0/8"])
     ev = views["emulated_shard"]
-    t_geom = views["stages"].get("geometry_bwd", {}).get("avg_ms", 0.0)
+    # what the chunked all-reduce can hide behind: the per-Gaussian kernel's chunks of one step (the pose sums follow them)
+    t_geom = views["stages"].get("geometry_bwd", {}).get("ms_per_step", 0.0)
     B, blur = ev["bucket_bytes"], ev["blur_bytes"]
     doc["views_slice"] = {"ms_per_step": ev["ms_per_step"], "eager_ms_per_step": ev.get("eager_ms_per_step"),
                           "geometry_bwd_ms": t_geom, "graph": ev.get("graph")}
