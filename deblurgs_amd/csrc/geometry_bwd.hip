@@ -116,8 +116,100 @@ contrib_reduce_kernel(uint64_t n, const uint32_t* __restrict__ status, const uin
   reinterpret_cast<float4*>(sums + (size_t)dst * DGS_SUMS_F)[part] = a;
 }
 
+// computeColorFromSH backward (backward.cu:20-140) of subframe k: adds to a_sh and to (dmean_x, dmean_y, dmean_z).  PS = pointer
+// to the pair's three pre-activation colour values.  A macro, expanded in the single-loop kernels exactly where the block
+// always stood (their code is unchanged) and in the second loop of the SPLIT kernel.
+#define DGS_SH_BACKWARD(PS)  \
+  {  \
+        const float* cam = campos + 3 * k;  \
+        const float dox = mx - cam[0], doy = my - cam[1], doz = mz - cam[2];  \
+        const float len = sqrtf(dox * dox + doy * doy + doz * doz);  \
+        const float x = dox / len, y = doy / len, z = doz / len;  \
+        float dRGB[3];  \
+_Pragma("unroll")  \
+        for (int ch = 0; ch < 3; ch++) {  \
+          const float psv = (PS)[ch];  \
+          float f = psv;  \
+          if (v.use_sigmoid) {  \
+            const float sg = sigmoidf_(psv);  \
+            f = sg * (1.0f - sg);  \
+          }  \
+          dRGB[ch] = dcol[ch] * f;  \
+        }  \
+        float ddir[3] = {0, 0, 0};  /* dL/ddir = sum_ch dRGBd{x,y,z}[ch] * dRGB[ch] */  \
+        float cf[MAXC];  /* dRGB/dsh_j (same for the three channels) */  \
+        cf[0] = SH_C0;  \
+        if (MAXC > 1 && ncoef > 1) {  \
+          cf[1] = -SH_C1 * y;  \
+          cf[2] = SH_C1 * z;  \
+          cf[3] = -SH_C1 * x;  \
+_Pragma("unroll")  \
+          for (int ch = 0; ch < 3; ch++) {  \
+            ddir[0] += (-SH_C1 * sh[9 + ch]) * dRGB[ch];  \
+            ddir[1] += (-SH_C1 * sh[3 + ch]) * dRGB[ch];  \
+            ddir[2] += (SH_C1 * sh[6 + ch]) * dRGB[ch];  \
+          }  \
+        }  \
+        if (MAXC > 4 && ncoef > 4) {  \
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;  \
+          cf[4] = SH_C2[0] * xy;  \
+          cf[5] = SH_C2[1] * yz;  \
+          cf[6] = SH_C2[2] * (2.f * zz - xx - yy);  \
+          cf[7] = SH_C2[3] * xz;  \
+          cf[8] = SH_C2[4] * (xx - yy);  \
+_Pragma("unroll")  \
+          for (int ch = 0; ch < 3; ch++) {  \
+            const float s4 = sh[12 + ch], s5 = sh[15 + ch], s6 = sh[18 + ch], s7 = sh[21 + ch], s8 = sh[24 + ch];  \
+            ddir[0] += (SH_C2[0] * y * s4 + SH_C2[2] * 2.f * -x * s6 + SH_C2[3] * z * s7 + SH_C2[4] * 2.f * x * s8) *  \
+                       dRGB[ch];  \
+            ddir[1] += (SH_C2[0] * x * s4 + SH_C2[1] * z * s5 + SH_C2[2] * 2.f * -y * s6 + SH_C2[4] * 2.f * -y * s8) *  \
+                       dRGB[ch];  \
+            ddir[2] += (SH_C2[1] * y * s5 + SH_C2[2] * 2.f * 2.f * z * s6 + SH_C2[3] * x * s7) * dRGB[ch];  \
+          }  \
+          if (MAXC > 9 && ncoef > 9) {  \
+            cf[9] = SH_C3[0] * y * (3.f * xx - yy);  \
+            cf[10] = SH_C3[1] * xy * z;  \
+            cf[11] = SH_C3[2] * y * (4.f * zz - xx - yy);  \
+            cf[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);  \
+            cf[13] = SH_C3[4] * x * (4.f * zz - xx - yy);  \
+            cf[14] = SH_C3[5] * z * (xx - yy);  \
+            cf[15] = SH_C3[6] * x * (xx - 3.f * yy);  \
+_Pragma("unroll")  \
+            for (int ch = 0; ch < 3; ch++) {  \
+              const float s9 = sh[27 + ch], s10 = sh[30 + ch], s11 = sh[33 + ch], s12 = sh[36 + ch],  \
+                          s13 = sh[39 + ch], s14 = sh[42 + ch], s15 = sh[45 + ch];  \
+              ddir[0] += (SH_C3[0] * s9 * 3.f * 2.f * xy + SH_C3[1] * s10 * yz + SH_C3[2] * s11 * -2.f * xy +  \
+                          SH_C3[3] * s12 * -3.f * 2.f * xz + SH_C3[4] * s13 * (-3.f * xx + 4.f * zz - yy) +  \
+                          SH_C3[5] * s14 * 2.f * xz + SH_C3[6] * s15 * 3.f * (xx - yy)) * dRGB[ch];  \
+              ddir[1] += (SH_C3[0] * s9 * 3.f * (xx - yy) + SH_C3[1] * s10 * xz +  \
+                          SH_C3[2] * s11 * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * s12 * -3.f * 2.f * yz +  \
+                          SH_C3[4] * s13 * -2.f * xy + SH_C3[5] * s14 * -2.f * yz +  \
+                          SH_C3[6] * s15 * -3.f * 2.f * xy) * dRGB[ch];  \
+              ddir[2] += (SH_C3[1] * s10 * xy + SH_C3[2] * s11 * 4.f * 2.f * yz +  \
+                          SH_C3[3] * s12 * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * s13 * 4.f * 2.f * xz +  \
+                          SH_C3[5] * s14 * (xx - yy)) * dRGB[ch];  \
+            }  \
+          }  \
+        }  \
+_Pragma("unroll")  \
+        for (int j = 0; j < MAXC; j++)  \
+          if (j < ncoef) {  \
+            a_sh[3 * j + 0] += cf[j] * dRGB[0];  \
+            a_sh[3 * j + 1] += cf[j] * dRGB[1];  \
+            a_sh[3 * j + 2] += cf[j] * dRGB[2];  \
+          }  \
+  /* dnormvdv (auxiliary.h:107-117) */  \
+        const float sum2 = dox * dox + doy * doy + doz * doz;  \
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);  \
+        dmean_x += ((+sum2 - dox * dox) * ddir[0] - doy * dox * ddir[1] - doz * dox * ddir[2]) * invsum32;  \
+        dmean_y += (-dox * doy * ddir[0] + (sum2 - doy * doy) * ddir[1] - doz * doy * ddir[2]) * invsum32;  \
+        dmean_z += (-dox * doz * ddir[0] - doy * doz * ddir[1] + (sum2 - doz * doz) * ddir[2]) * invsum32;  \
+  }
+
+// waves per SIMD the register allocation must leave room for: the degree-3 instantiation came out at 255 VGPRs + 3 AGPRs,
+// i.e. ONE wave per SIMD, without a bound (two waves = 256 registers in all); the others are left alone
 template <int MAXC>  // MAXC = SH coefficients held in registers: 1, 4, 9 or 16
-__global__ void __launch_bounds__(GB_THREADS)
+__global__ void __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(MAXC > 9 ? 2 : 1)))
 geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* __restrict__ shs,
                     const float* __restrict__ shs_rest, const float* __restrict__ opacities_raw,
                     const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -155,24 +247,32 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
   float a_cov[6] = {0, 0, 0, 0, 0, 0};
   float a_col[3] = {0, 0, 0};
   float a_op = 0;
-  float a_sh[MAXC * 3];
-#pragma unroll
-  for (int i = 0; i < MAXC * 3; i++) a_sh[i] = 0.0f;
   // SH coefficients are read once per Gaussian and stay in registers across the K subframes (only the first
-  // (D+1)^2 are touched, MAXC >= (D+1)^2 by construction of the launch)
+  // (D+1)^2 are touched, MAXC >= (D+1)^2 by construction of the launch).
+  // SPLIT (MAXC = 16, SH degree 3): 48 coefficients + 48 gradient sums live across the subframe loop next to the
+  // covariance / projection chain need the whole 256-VGPR budget and more (round 5: 256 VGPRs + AGPR copies, ONE wave per
+  // SIMD, 1.24 ms against 0.63 ms for MAXC = 9).  The SH part then runs as a second loop over the subframes after the first
+  // one has retired its temporaries: it re-reads the pair's colour-gradient totals (two 16-byte loads) and the activation
+  // mask, and adds its direction term to dL/dmean afterwards.  MAXC <= 9 keeps the single loop (and its exact sums).
+  constexpr bool SPLIT = MAXC > 9;
+  float a_sh[MAXC * 3];
   float sh[MAXC * 3];
-  if (shs != nullptr) {
-    if (shs_rest == nullptr) {
-      const float* shp = shs + (size_t)gi * v.M * 3;
-#pragma unroll
-      for (int i = 0; i < MAXC * 3; i++) sh[i] = (i < ncoef * 3) ? shp[i] : 0.0f;
-    } else {
-      const float* dcp = shs + (size_t)gi * 3;
-      const float* rsp = shs_rest + (size_t)gi * (v.M - 1) * 3;
-#pragma unroll
-      for (int i = 0; i < MAXC * 3; i++) sh[i] = (i < ncoef * 3) ? ((i < 3) ? dcp[i] : rsp[i - 3]) : 0.0f;
-    }
+#define DGS_LOAD_SH()                                                                                               \
+  {                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < MAXC * 3; i++) a_sh[i] = 0.0f;                                           \
+    if (shs != nullptr) {                                                                                          \
+      if (shs_rest == nullptr) {                                                                                   \
+        const float* shp = shs + (size_t)gi * v.M * 3;                                                             \
+        _Pragma("unroll") for (int i = 0; i < MAXC * 3; i++) sh[i] = (i < ncoef * 3) ? shp[i] : 0.0f;              \
+      } else {                                                                                                     \
+        const float* dcp = shs + (size_t)gi * 3;                                                                   \
+        const float* rsp = shs_rest + (size_t)gi * (v.M - 1) * 3;                                                  \
+        _Pragma("unroll") for (int i = 0; i < MAXC * 3; i++)                                                       \
+            sh[i] = (i < ncoef * 3) ? ((i < 3) ? dcp[i] : rsp[i - 3]) : 0.0f;                                      \
+      }                                                                                                            \
+    }                                                                                                              \
   }
+  if (!SPLIT) DGS_LOAD_SH()
 
   // Software pipeline over the subframes (this kernel runs at two waves per SIMD): the loads of one (subframe, Gaussian)
   // -- tiles_touched, the geometry row, the 48-byte total at the natural index -- and this kernel runs at two
@@ -333,90 +433,8 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
       dmean_y += (F[4] * m_w - F[7] * mul1) * g2x + (F[5] * m_w - F[7] * mul2) * g2y + ddepth * V[6];
       dmean_z += (F[8] * m_w - F[11] * mul1) * g2x + (F[9] * m_w - F[11] * mul2) * g2y + ddepth * V[10];
 
-      if (shs != nullptr) {  // computeColorFromSH backward (backward.cu:20-140)
-        const float* cam = campos + 3 * k;
-        const float dox = mx - cam[0], doy = my - cam[1], doz = mz - cam[2];
-        const float len = sqrtf(dox * dox + doy * doy + doz * doz);
-        const float x = dox / len, y = doy / len, z = doz / len;
-        float dRGB[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-          const float ps = pre_sigmoid[3 * o + ch];
-          float f = ps;
-          if (v.use_sigmoid) {
-            const float sg = sigmoidf_(ps);
-            f = sg * (1.0f - sg);
-          }
-          dRGB[ch] = dcol[ch] * f;
-        }
-        float ddir[3] = {0, 0, 0};  // dL/ddir = sum_ch dRGBd{x,y,z}[ch] * dRGB[ch]
-        float cf[MAXC];             // dRGB/dsh_j (same for the three channels)
-        cf[0] = SH_C0;
-        if (MAXC > 1 && ncoef > 1) {
-          cf[1] = -SH_C1 * y;
-          cf[2] = SH_C1 * z;
-          cf[3] = -SH_C1 * x;
-#pragma unroll
-          for (int ch = 0; ch < 3; ch++) {
-            ddir[0] += (-SH_C1 * sh[9 + ch]) * dRGB[ch];
-            ddir[1] += (-SH_C1 * sh[3 + ch]) * dRGB[ch];
-            ddir[2] += (SH_C1 * sh[6 + ch]) * dRGB[ch];
-          }
-        }
-        if (MAXC > 4 && ncoef > 4) {
-          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-          cf[4] = SH_C2[0] * xy;
-          cf[5] = SH_C2[1] * yz;
-          cf[6] = SH_C2[2] * (2.f * zz - xx - yy);
-          cf[7] = SH_C2[3] * xz;
-          cf[8] = SH_C2[4] * (xx - yy);
-#pragma unroll
-          for (int ch = 0; ch < 3; ch++) {
-            const float s4 = sh[12 + ch], s5 = sh[15 + ch], s6 = sh[18 + ch], s7 = sh[21 + ch], s8 = sh[24 + ch];
-            ddir[0] += (SH_C2[0] * y * s4 + SH_C2[2] * 2.f * -x * s6 + SH_C2[3] * z * s7 + SH_C2[4] * 2.f * x * s8) *
-                       dRGB[ch];
-            ddir[1] += (SH_C2[0] * x * s4 + SH_C2[1] * z * s5 + SH_C2[2] * 2.f * -y * s6 + SH_C2[4] * 2.f * -y * s8) *
-                       dRGB[ch];
-            ddir[2] += (SH_C2[1] * y * s5 + SH_C2[2] * 2.f * 2.f * z * s6 + SH_C2[3] * x * s7) * dRGB[ch];
-          }
-          if (MAXC > 9 && ncoef > 9) {
-            cf[9] = SH_C3[0] * y * (3.f * xx - yy);
-            cf[10] = SH_C3[1] * xy * z;
-            cf[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
-            cf[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
-            cf[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
-            cf[14] = SH_C3[5] * z * (xx - yy);
-            cf[15] = SH_C3[6] * x * (xx - 3.f * yy);
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-              const float s9 = sh[27 + ch], s10 = sh[30 + ch], s11 = sh[33 + ch], s12 = sh[36 + ch],
-                          s13 = sh[39 + ch], s14 = sh[42 + ch], s15 = sh[45 + ch];
-              ddir[0] += (SH_C3[0] * s9 * 3.f * 2.f * xy + SH_C3[1] * s10 * yz + SH_C3[2] * s11 * -2.f * xy +
-                          SH_C3[3] * s12 * -3.f * 2.f * xz + SH_C3[4] * s13 * (-3.f * xx + 4.f * zz - yy) +
-                          SH_C3[5] * s14 * 2.f * xz + SH_C3[6] * s15 * 3.f * (xx - yy)) * dRGB[ch];
-              ddir[1] += (SH_C3[0] * s9 * 3.f * (xx - yy) + SH_C3[1] * s10 * xz +
-                          SH_C3[2] * s11 * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * s12 * -3.f * 2.f * yz +
-                          SH_C3[4] * s13 * -2.f * xy + SH_C3[5] * s14 * -2.f * yz +
-                          SH_C3[6] * s15 * -3.f * 2.f * xy) * dRGB[ch];
-              ddir[2] += (SH_C3[1] * s10 * xy + SH_C3[2] * s11 * 4.f * 2.f * yz +
-                          SH_C3[3] * s12 * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * s13 * 4.f * 2.f * xz +
-                          SH_C3[5] * s14 * (xx - yy)) * dRGB[ch];
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < MAXC; j++)
-          if (j < ncoef) {
-            a_sh[3 * j + 0] += cf[j] * dRGB[0];
-            a_sh[3 * j + 1] += cf[j] * dRGB[1];
-            a_sh[3 * j + 2] += cf[j] * dRGB[2];
-          }
-        // dnormvdv (auxiliary.h:107-117)
-        const float sum2 = dox * dox + doy * doy + doz * doz;
-        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-        dmean_x += ((+sum2 - dox * dox) * ddir[0] - doy * dox * ddir[1] - doz * dox * ddir[2]) * invsum32;
-        dmean_y += (-dox * doy * ddir[0] + (sum2 - doy * doy) * ddir[1] - doz * doy * ddir[2]) * invsum32;
-        dmean_z += (-dox * doz * ddir[0] - doy * doz * ddir[1] + (sum2 - doz * doz) * ddir[2]) * invsum32;
+      if (!SPLIT && shs != nullptr) {  // computeColorFromSH backward (backward.cu:20-140)
+        DGS_SH_BACKWARD(pre_sigmoid + 3 * o)
       }
       a_col[0] += dcol[0];
       a_col[1] += dcol[1];
@@ -479,6 +497,49 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
         __builtin_amdgcn_wave_barrier();
       } else if (lane < 21) {
         sp[lane] = 0.0f;
+      }
+    }
+  }
+
+  if (SPLIT && shs != nullptr) {
+    // second loop over the subframes: the SH part alone (see SPLIT above).  The loads of subframe k + 1 are issued
+    // before subframe k computes.
+    DGS_LOAD_SH()
+    struct ShPf {
+      uint32_t nt;
+      float4 r1, r2;
+      float ps[3];
+    };
+    auto load_pf = [&](int k) {
+      ShPf f;
+      const size_t o = (size_t)k * v.P + gi;
+      f.nt = valid ? tiles_touched[o] : 0u;
+      const float4* cp = reinterpret_cast<const float4*>(contrib + o * DGS_SUMS_F);
+      f.r1 = cp[1];
+      f.r2 = cp[2];
+      f.ps[0] = pre_sigmoid[3 * o];
+      f.ps[1] = pre_sigmoid[3 * o + 1];
+      f.ps[2] = pre_sigmoid[3 * o + 2];
+      return f;
+    };
+#ifndef DGS_SH_PREFETCH
+#define DGS_SH_PREFETCH 0
+#endif
+    ShPf nxt = load_pf(0);
+    for (int k = 0; k < v.K; k++) {
+#if DGS_SH_PREFETCH
+      const ShPf cur = nxt;
+      if (k + 1 < v.K) nxt = load_pf(k + 1);
+#else
+      const ShPf cur = load_pf(k);
+#endif
+      if (cur.nt > 0) {
+        const float dcol[3] = {cur.r1.z, cur.r1.w, cur.r2.x};
+        float dmean_x = 0.0f, dmean_y = 0.0f, dmean_z = 0.0f;
+        DGS_SH_BACKWARD(cur.ps)
+        a_mean[0] += dmean_x;
+        a_mean[1] += dmean_y;
+        a_mean[2] += dmean_z;
       }
     }
   }

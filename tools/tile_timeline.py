@@ -60,7 +60,7 @@ def main():
     cloud.xyz_scheduler_args = lambda it: 0.00016 * 1e-6
     gx, gy = (W + 15) // 16, (H + 15) // 16
     T = gx * gy
-    buf = torch.zeros(2 * K * T, dtype=torch.int64, device=dev)
+    buf = torch.zeros(3 * K * T, dtype=torch.int64, device=dev)
     for it in range(1, 5):
         loop.step(it, 0)
     torch.cuda.synchronize()
@@ -68,7 +68,7 @@ def main():
     loop.step(5, 0)
     torch.cuda.synchronize()
     L.dgs_debug_set_timeline(None)
-    tl = buf.cpu().numpy().reshape(K * T, 2).astype(np.int64)
+    tl = buf.cpu().numpy().reshape(K * T, 3).astype(np.int64)
     ok = tl[:, 1] > 0
     st, en = tl[ok, 0], tl[ok, 1]
     t0 = st.min()
@@ -83,11 +83,13 @@ def main():
     ramp = float(ev[np.argmax(hi), 0])
     last_hi = float(ev[len(hi) - 1 - np.argmax(hi[::-1]), 0])
     dur = en - st
-    # tiles -> XCD (composite.hip, xcd_remap: a contiguous run of blocks per XCD, four tiles per block)
+    # which XCD ran the tile (XCC_ID register) against the one the block index implies (block b -> XCD b % 8), and the tile
+    # run it belongs to (composite.hip: eight contiguous runs, XCD x starts on run x and helps with the others afterwards)
+    hw_xcc, by_block = (tl[ok, 2] >> 8) & 0xF, tl[ok, 2] & 0xFF
     nblk = (K * T + 3) // 4
-    per_xcd = (nblk + 7) // 8
-    xcd = (np.nonzero(ok)[0] // 4) // per_xcd
-    xcd_end = [float(en[xcd == x].max()) for x in range(8) if (xcd == x).any()]
+    per_run = (nblk + 7) // 8 * 4
+    run = np.nonzero(ok)[0] // per_run
+    xcd_end = [float(en[hw_xcc == x].max()) for x in range(16) if (hw_xcc == x).any()]
     out = {"config": a.config, "waves": int(ok.sum()), "span_us": round(span, 1), "busy_wave_us": round(busy, 1),
            "peak_resident_waves": int(peak), "mean_resident_waves": round(busy / span, 1),
            "efficiency_busy_over_peak_times_span": round(busy / (peak * span), 4),
@@ -96,6 +98,8 @@ def main():
            "lost_fraction_of_span": round((span - busy / peak) / span, 4),
            "wave_duration_us": {"mean": round(float(dur.mean()), 1), "p50": round(float(np.median(dur)), 1),
                                 "p99": round(float(np.quantile(dur, 0.99)), 1), "max": round(float(dur.max()), 1)},
+           "xcc_id_equals_block_index_mod_8": float((hw_xcc == by_block).mean()),
+           "tiles_composited_by_their_home_xcd": float((by_block == run).mean()),
            "xcd_finish_us": [round(x, 1) for x in xcd_end],
            "xcd_finish_spread_us": round(max(xcd_end) - min(xcd_end), 1)}
     print(json.dumps(out, indent=1))
