@@ -40,7 +40,7 @@ void make_layout(int P, int W, int H, int K, uint64_t R, bool wide_records, DgsL
   L->tiles_touched = o;  o += up(KP * 4);
   L->point_offsets = o;  o += up(KP * 4);
   L->scan_tmp = o;       o += up(dgs_scan_tmp_words(KP) * 4);
-  L->num_rendered = o;   o += up(256 + 2 * 8 * 64);   // 8 status words | the compositing kernels' tile-ticket counters
+  L->num_rendered = o;   o += up(32);
   L->gsort_keys = o;     o += up(KP * 4);
   L->gsort_keys_alt = o; o += up(KP * 4);
   L->gsort_vals = o;     o += up(KP * 4);

@@ -37,47 +37,18 @@ struct TileCtx {
   uint32_t r0, r1;
 };
 
-// Persistent waves, dynamic tile fetch (round 5).  The launch holds as many blocks as fit on the chip at once; every WAVE
-// then takes tiles one at a time from a ticket counter until none is left.  Round 4 launched one block per four tiles and
-// let the hardware deal them out: per-wave timestamps (tools/tile_timeline.py) showed 9.6 % of the backward's wave slots
-// idle over the launch -- a block's four slots are refilled only when all four of its waves (whose lists differ in length)
-// have ended, every refill is a block launch, and each XCD received a fixed eighth of the blocks, so the XCDs ended up to
-// 0.23 ms apart.
-// XCD-aware: the hardware places block b on XCD b % 8 and a persistent block stays there; the tiles are cut into eight
-// contiguous runs with a ticket counter each (its own 64-byte line), XCD x works through run x -- consecutive tickets are
-// neighbouring tiles, which share Gaussians: same L2 -- and, when its run is exhausted, helps with runs x + 1, x + 2, ...
-// Which wave composites which tile does not touch the results.
-constexpr int TICKET_STRIDE = 16;   // uint32 words between two counters (one counter per 64-byte line)
+// XCD-aware block -> tile-group map: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+// run of tiles so that neighbouring tiles, which share Gaussians, hit the same L2.  Speed only.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t per_xcd) { return (b & 7u) * per_xcd + (b >> 3); }
 
-struct TileSched {
-  uint32_t* tickets;   // [8 * TICKET_STRIDE], zeroed before the launch
-  uint32_t per;        // tiles per run
-  uint32_t KT;
-  uint32_t run;        // the run this wave is drawing from
-  uint32_t visited;    // runs this wave has seen the end of
-  uint32_t pend;       // lane 0: the ticket requested ahead for `run`
-};
-
-__device__ __forceinline__ void sched_request(TileSched& sc) {
-  // (issued ahead: the atomic's round trip overlaps the tile being composited; the value is read in sched_next)
-  if (dgs_lane() == 0) sc.pend = atomicAdd(&sc.tickets[sc.run * TICKET_STRIDE], 1u);
-}
-
-__device__ __forceinline__ bool sched_next(TileSched& sc, uint32_t& gw) {
-  for (;;) {
-    const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.pend);
-    const uint32_t g = sc.run * sc.per + tk;
-    if (tk < sc.per && g < sc.KT) {
-      gw = g;
-      return true;
-    }
-    if (++sc.visited >= 8u) return false;
-    sc.run = (sc.run + 1u) & 7u;
-    sched_request(sc);
-  }
-}
-
-__device__ __forceinline__ void tile_ctx_of(const DgsView& v, const uint2* __restrict__ ranges, uint32_t gw, TileCtx& t) {
+__device__ __forceinline__ bool load_tile_ctx(const DgsView& v, const uint2* __restrict__ ranges, uint32_t per_xcd,
+                                              TileCtx& t) {
+  const uint32_t logical = xcd_remap(blockIdx.x, per_xcd);
+  // threadIdx.x >> 6 is wave-uniform, but the compiler only knows that through readfirstlane: without it the
+  // tile range, every loop bound and the ballot masks end up in VGPRs under exec-mask control flow.
+  const uint32_t gw = logical * CW + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t KT = (uint32_t)v.K * (uint32_t)v.T;
+  if (gw >= KT) return false;
   t.k = (int)(gw / (uint32_t)v.T);
   const uint32_t tile = gw - (uint32_t)t.k * (uint32_t)v.T;
   t.ty = (int)(tile / (uint32_t)v.gx);
@@ -85,6 +56,7 @@ __device__ __forceinline__ void tile_ctx_of(const DgsView& v, const uint2* __res
   const uint2 r = ranges[gw];
   t.r0 = r.x;
   t.r1 = r.y;
+  return true;
 }
 
 // Conservative-but-tight test: can Gaussian (x, y, conic a/b/c, opacity op) reach alpha >= 1/255 at some pixel
@@ -130,7 +102,7 @@ __device__ __forceinline__ float dgs_min_raw(float c, float x) {
 }
 
 // DGS_TIMELINE=1 (diagnostic build only, tools/tile_timeline.py): every wave of the compositing backward leaves its
-// start and end time (s_memrealtime, 100 MHz) in a caller-provided buffer, [K*T][2] u64 by tile -- how many waves are
+// start and end time (s_memrealtime, 100 MHz) and where it ran in a caller-provided buffer, [K*T][3] u64 by tile -- how many waves are
 // resident over the launch, i.e. how long the tail of the wave-per-tile schedule is.
 #ifndef DGS_TIMELINE
 #define DGS_TIMELINE 0
@@ -148,26 +120,17 @@ using CullGauss = DgsCull;
 // loss never reads it): the depth channel drops out of the per-pair math and nothing is stored for it.
 template <bool WITHDEPTH>
 __global__ void __launch_bounds__(64 * CW)
-composite_fwd_kernel(DgsView v, uint32_t per_tiles, uint32_t* __restrict__ tickets, const uint2* __restrict__ ranges,
+composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
                      const uint32_t* __restrict__ point_list, const uint64_t* __restrict__ keys,
                      const DgsRow* __restrict__ rows,
                      const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                      float* __restrict__ out_color, float* __restrict__ out_depth) {
   // one 48-byte LDS row per list entry: (x, y, A, B | C, op, r, g | b, depth, -, -): one address per read
   __shared__ float4 s_row[CW][64 * 3];
-  // threadIdx.x >> 6 is wave-uniform, but the compiler only knows that through readfirstlane: without it the
-  // tile range, every loop bound and the ballot masks end up in VGPRs under exec-mask control flow.
+  TileCtx t;
+  if (!load_tile_ctx(v, ranges, per_xcd, t)) return;
   const int lane = dgs_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lx = lane & 7, ly = lane >> 3;
-  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  const size_t N = (size_t)v.W * v.H;
-  TileSched sc = {tickets, per_tiles, (uint32_t)v.K * (uint32_t)v.T, blockIdx.x & 7u, 0u, 0u};
-  sched_request(sc);
-  uint32_t gw_tile;
-  while (sched_next(sc, gw_tile)) {
-  sched_request(sc);   // the ticket of the tile after this one
-  TileCtx t;
-  tile_ctx_of(v, ranges, gw_tile, t);
   const int px0 = t.tx * DGS_TILE + lx, py0 = t.ty * DGS_TILE + ly;  // quadrant 0 pixel; +8 for the others
   const float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
   const float qx0 = (float)(t.tx * DGS_TILE), qy0 = (float)(t.ty * DGS_TILE);
@@ -290,6 +253,8 @@ composite_fwd_kernel(DgsView v, uint32_t per_tiles, uint32_t* __restrict__ ticke
     __builtin_amdgcn_wave_barrier();  // LDS rows are rewritten by the next batch
   }
 
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const size_t N = (size_t)v.W * v.H;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
@@ -305,8 +270,6 @@ composite_fwd_kernel(DgsView v, uint32_t per_tiles, uint32_t* __restrict__ ticke
       if (WITHDEPTH) out_depth[(size_t)t.k * N + pix] = Dd[q] + Tf * v.z_far;
     }
   }
-  __builtin_amdgcn_wave_barrier();   // the next tile's first batch rewrites this wave's LDS rows
-  }  // tiles
 }
 
 // ----------------------------------------------------------------------------------------------- backward
@@ -314,7 +277,7 @@ composite_fwd_kernel(DgsView v, uint32_t per_tiles, uint32_t* __restrict__ ticke
 // default training loss does not use the depth output: the depth channel then drops out of the per-pair math)
 template <bool TIGHT, bool HASDEPTH>
 __global__ void __launch_bounds__(64 * CW)
-composite_bwd_kernel(DgsView v, uint32_t per_tiles, uint32_t* __restrict__ tickets, const uint2* __restrict__ ranges,
+composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
                      const uint32_t* __restrict__ point_list, const uint64_t* __restrict__ keys,
                      const DgsRow* __restrict__ rows,
                      const float* __restrict__ bg, const float* __restrict__ final_T,
@@ -325,8 +288,16 @@ composite_bwd_kernel(DgsView v, uint32_t per_tiles, uint32_t* __restrict__ ticke
   // the ten per-lane sums of a list entry, value-major (row stride 68 floats: the 16-byte column reads of the rows start
   // in different banks)
   __shared__ __attribute__((aligned(16))) float s_part[CW][10][68];
+  TileCtx t;
+  if (!load_tile_ctx(v, ranges, per_xcd, t)) return;
+#if DGS_TIMELINE
+  const unsigned long long t_begin = wall_clock64();
+#endif
   const int lane = dgs_lane(), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lx = lane & 7, ly = lane >> 3;
+  const int px0 = t.tx * DGS_TILE + lx, py0 = t.ty * DGS_TILE + ly;
+  const float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
+  const float qx0 = (float)(t.tx * DGS_TILE), qy0 = (float)(t.ty * DGS_TILE);
   const size_t N = (size_t)v.W * v.H;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   // contribution-row slots: [S_wx, S_wy, S_xx, S_xy, S_yy, S_w, r, g, b, depth]
@@ -338,20 +309,7 @@ composite_bwd_kernel(DgsView v, uint32_t per_tiles, uint32_t* __restrict__ ticke
   static_assert(sizeof(float) * 68 == 272, "the store offsets below are multiples of one s_part row");
   // LDS byte offset of this wave's s_part block (the low half of a flat LDS address is the offset inside the LDS)
   const uint32_t part_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(&s_part[w][0][0]));
-
-  TileSched sc = {tickets, per_tiles, (uint32_t)v.K * (uint32_t)v.T, blockIdx.x & 7u, 0u, 0u};
-  sched_request(sc);
-  uint32_t gw_tile;
-  while (sched_next(sc, gw_tile)) {
-  sched_request(sc);   // the ticket of the tile after this one
-  TileCtx t;
-  tile_ctx_of(v, ranges, gw_tile, t);
-#if DGS_TIMELINE
-  const unsigned long long t_begin = wall_clock64();
-#endif
-  const int px0 = t.tx * DGS_TILE + lx, py0 = t.ty * DGS_TILE + ly;
-  const float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
-  const float qx0 = (float)(t.tx * DGS_TILE), qy0 = (float)(t.ty * DGS_TILE);
+  
 
   // per-pixel channel state kept as (r,g) and (b,depth) pairs so the channel arithmetic issues as packed fp32
   float T[4];
@@ -621,14 +579,16 @@ composite_bwd_kernel(DgsView v, uint32_t per_tiles, uint32_t* __restrict__ ticke
   }
 #if DGS_TIMELINE
   if (lane == 0 && g_timeline != nullptr) {
-    g_timeline[3 * (size_t)gw_tile] = t_begin;
-    g_timeline[3 * (size_t)gw_tile + 1] = wall_clock64();
-    // which XCD really ran the tile (XCC_ID, hardware register 20, bits [3:0]) next to the one its block index implies
-    g_timeline[3 * (size_t)gw_tile + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 8) |
-                                          (unsigned long long)(blockIdx.x & 7u);
+    const size_t gw = (size_t)t.k * v.T + (size_t)t.ty * v.gx + t.tx;
+    g_timeline[3 * gw] = t_begin;
+    g_timeline[3 * gw + 1] = wall_clock64();
+    // the wave's slot (block, wave), the XCD that really ran it (XCC_ID, hardware register 20, bits [3:0]) and the one its
+    // block index implies
+    g_timeline[3 * gw + 2] = ((unsigned long long)(blockIdx.x * CW + w) << 16) |
+                             ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 8) |
+                             (unsigned long long)(blockIdx.x & 7u);
   }
 #endif
-  }  // tiles
 }
 
 }  // namespace
@@ -640,80 +600,32 @@ extern "C" int dgs_debug_set_timeline(void* buffer) {
 }
 #endif
 
-// tiles per XCD run (a multiple of CW, as the round-4 block map had it) and the persistent grid: as many blocks as are
-// resident at once (occupancy x CUs, a multiple of 8 so that every XCD gets the same number), never more than there are
-// groups of CW tiles
-static uint32_t tiles_per_run(const DgsView& v) {
+static uint32_t per_xcd_blocks(const DgsView& v) {
   const uint64_t KT = (uint64_t)v.K * v.T;
   const uint64_t nblk = (KT + CW - 1) / CW;
-  return (uint32_t)((nblk + 7) / 8) * CW;
+  return (uint32_t)((nblk + 7) / 8);
 }
-
-template <typename Kern>
-static uint32_t persistent_blocks(Kern kernel, const DgsView& v) {
-  static int cus = 0;
-  int dev = 0;
-  if (cus == 0) {
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    cus = prop.multiProcessorCount;
-  }
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * CW, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-  const uint64_t KT = (uint64_t)v.K * v.T;
-  const uint64_t want = (KT + CW - 1) / CW;
-  uint64_t grid = (uint64_t)cus * (uint64_t)per_cu;
-  if (grid > want) grid = want;
-  grid = (grid + 7) / 8 * 8;
-  return (uint32_t)grid;
-}
-
-// ticket counters of the two compositing launches: 8 counters, one 64-byte line each, behind the status words
-uint32_t* dgs_fwd_tickets(const DgsCarve& c) { return c.num_rendered + 64; }
-uint32_t* dgs_bwd_tickets(const DgsCarve& c) { return c.num_rendered + 64 + 8 * TICKET_STRIDE; }
 
 hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,
                                     float* out_depth, hipStream_t s) {
-  const uint32_t per = tiles_per_run(v);
+  const uint32_t per = per_xcd_blocks(v);
   if (per == 0) return hipSuccess;
-  uint32_t* tk = dgs_fwd_tickets(c);
-  hipError_t e = hipMemsetAsync(tk, 0, 8 * TICKET_STRIDE * sizeof(uint32_t), s);
-  if (e != hipSuccess) return e;
-  if (out_depth != nullptr) {
-    static uint32_t grid = 0, grid_kt = 0;
-    const uint32_t kt = (uint32_t)v.K * (uint32_t)v.T;
-    if (grid == 0 || grid_kt != kt) { grid = persistent_blocks(composite_fwd_kernel<true>, v); grid_kt = kt; }
-    if (grid == 0) return hipErrorUnknown;
-    hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(grid), dim3(64 * CW), 0, s, v, per, tk, c.ranges, c.point_list,
+  if (out_depth != nullptr)
+    hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
                        c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth);
-  } else {
-    static uint32_t grid = 0, grid_kt = 0;
-    const uint32_t kt = (uint32_t)v.K * (uint32_t)v.T;
-    if (grid == 0 || grid_kt != kt) { grid = persistent_blocks(composite_fwd_kernel<false>, v); grid_kt = kt; }
-    if (grid == 0) return hipErrorUnknown;
-    hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(grid), dim3(64 * CW), 0, s, v, per, tk, c.ranges, c.point_list,
+  else
+    hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
                        c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth);
-  }
   return hipGetLastError();
 }
 
 hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const float* bg, const float* dL_dpix,
                                     const float* dL_ddepth, float* contrib, hipStream_t s) {
-  const uint32_t per = tiles_per_run(v);
+  const uint32_t per = per_xcd_blocks(v);
   if (per == 0) return hipSuccess;
-  uint32_t* tk = dgs_bwd_tickets(c);
-  hipError_t e = hipMemsetAsync(tk, 0, 8 * TICKET_STRIDE * sizeof(uint32_t), s);
-  if (e != hipSuccess) return e;
-#define DGS_CBWD(TI, HD)                                                                                              \
-  do {                                                                                                                \
-    static uint32_t grid = 0, grid_kt = 0;                                                                            \
-    const uint32_t kt = (uint32_t)v.K * (uint32_t)v.T;                                                                \
-    if (grid == 0 || grid_kt != kt) { grid = persistent_blocks(composite_bwd_kernel<TI, HD>, v); grid_kt = kt; }      \
-    if (grid == 0) return hipErrorUnknown;                                                                            \
-    hipLaunchKernelGGL((composite_bwd_kernel<TI, HD>), dim3(grid), dim3(64 * CW), 0, s, v, per, tk, c.ranges,         \
-                       c.point_list, c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth,           \
-                       c.point_offsets, contrib);                                                                     \
-  } while (0)
+#define DGS_CBWD(TI, HD)                                                                                            \
+  hipLaunchKernelGGL((composite_bwd_kernel<TI, HD>), dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list, \
+                     c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth, c.point_offsets, contrib)
   if (v.tile_cull) {
     if (dL_ddepth != nullptr) DGS_CBWD(true, true); else DGS_CBWD(true, false);
   } else {

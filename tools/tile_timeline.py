@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--config", default="metric")
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
-    if "timeline" not in os.environ.get("DGS_LIB_PATH", ""):
+    if "timeline" not in os.environ.get("DGS_LIB_PATH", ""):   # (any build with -DDGS_TIMELINE=1)
         raise SystemExit("set DGS_LIB_PATH=variants/libdgs_timeline.so (tools/build_variant.sh timeline composite.hip "
                          "deblurgs_amd/csrc/composite.hip -DDGS_TIMELINE=1)")
     import numpy as np
@@ -85,7 +85,17 @@ def main():
     dur = en - st
     # which XCD ran the tile (XCC_ID register) against the one the block index implies (block b -> XCD b % 8), and the tile
     # run it belongs to (composite.hip: eight contiguous runs, XCD x starts on run x and helps with the others afterwards)
-    hw_xcc, by_block = (tl[ok, 2] >> 8) & 0xF, tl[ok, 2] & 0xFF
+    hw_xcc, by_block, slot = (tl[ok, 2] >> 8) & 0xF, tl[ok, 2] & 0xFF, tl[ok, 2] >> 16
+    # per wave slot: the tiles it composited in time order -> the gaps between them (ticket latency the wave sat through)
+    order = np.lexsort((st, slot))
+    s_sorted, st_s, en_s = slot[order], st[order], en[order]
+    same = s_sorted[1:] == s_sorted[:-1]
+    gaps = (st_s[1:] - en_s[:-1])[same]
+    tiles_per_slot = np.bincount(slot.astype(np.int64))
+    tiles_per_slot = tiles_per_slot[tiles_per_slot > 0]
+    # durations by when the tile started (tenths of the span)
+    decile = np.minimum((st / span * 10).astype(int), 9)
+    dur_by_decile = [round(float(dur_all.mean()), 1) if (dur_all := (en - st)[decile == d]).size else None for d in range(10)]
     nblk = (K * T + 3) // 4
     per_run = (nblk + 7) // 8 * 4
     run = np.nonzero(ok)[0] // per_run
@@ -98,12 +108,19 @@ def main():
            "lost_fraction_of_span": round((span - busy / peak) / span, 4),
            "wave_duration_us": {"mean": round(float(dur.mean()), 1), "p50": round(float(np.median(dur)), 1),
                                 "p99": round(float(np.quantile(dur, 0.99)), 1), "max": round(float(dur.max()), 1)},
+           "gap_between_a_waves_tiles_us": ({"mean": round(float(gaps.mean()), 2), "p50": round(float(np.median(gaps)), 2),
+                                             "p99": round(float(np.quantile(gaps, 0.99)), 2), "max": round(float(gaps.max()), 2),
+                                             "sum_over_busy": round(float(gaps.sum() / busy), 4)} if gaps.size else None),
+           "tiles_per_wave_slot": {"min": int(tiles_per_slot.min()), "mean": round(float(tiles_per_slot.mean()), 1),
+                                   "max": int(tiles_per_slot.max()), "slots": int(tiles_per_slot.size)},
+           "mean_wave_duration_us_by_start_decile": dur_by_decile,
            "xcc_id_equals_block_index_mod_8": float((hw_xcc == by_block).mean()),
            "tiles_composited_by_their_home_xcd": float((by_block == run).mean()),
            "xcd_finish_us": [round(x, 1) for x in xcd_end],
            "xcd_finish_spread_us": round(max(xcd_end) - min(xcd_end), 1)}
     print(json.dumps(out, indent=1))
     if a.json:
+        os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
         json.dump(out, open(a.json, "w"), indent=1)
 
 
