@@ -688,10 +688,13 @@ def run_rank(args):
                       "config": result["config"], "stages": stages}
         # PMC counters cannot be collected inside this run (rocprofv3 wraps the process): traffic / VALU figures are the
         # committed measurements of the same command, with their provenance, or null
-        for fname, key in (("traffic_r04.json", "traffic"), ("valu_r04.json", "valu")):
-            path = os.path.join(ROOT, "profiles", fname)
-            if not os.path.exists(path) or world != 1 or emu is not None:
+        import glob
+        for stem, key in (("traffic", "traffic"), ("valu", "valu")):
+            found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{stem}_r[0-9][0-9].json")))    # the newest round's
+            if not found or world != 1 or emu is not None:
                 continue
+            path = found[-1]
+            fname = os.path.basename(path)
             try:
                 doc = json.load(open(path))
                 if doc.get("_config") != args.config:

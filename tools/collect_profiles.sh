@@ -2,7 +2,7 @@
 # Collects the round's committed evidence on the GPU box into gpurun_out/profiles_<round>/ (copy what is to be judged into
 # profiles/ afterwards): kernel-trace summary, VALU counters, FETCH / WRITE counters (separate passes, kernel-trace only),
 # the per-class issue costs, and the derived json files.   usage: tools/collect_profiles.sh [round]
-rnd=${1:-r04}
+rnd=${1:-r05}
 root=$(cd "$(dirname "$0")/.." && pwd)
 cd $root
 export TMPDIR=/tmp

@@ -2,7 +2,7 @@
 # Everything the round's DESIGN / profiles quote, produced in one GPU session into gpurun_out/profiles_<round>/:
 #   profiles (tools/collect_profiles.sh), bench lines per config, the config tests' own parity report, the CU-mask
 #   overlap probe (round 3), soak + list stress + p2p repeats, the RCCL smoke test.   usage: tools/final_evidence.sh [round]
-rnd=${1:-r04}
+rnd=${1:-r05}
 root=$(cd "$(dirname "$0")/.." && pwd)
 cd $root
 out=$root/gpurun_out/profiles_$rnd
@@ -15,6 +15,13 @@ for cfg in metric cfg2 cfg1 cfg3 cfg5; do
   if [ "$cfg" == "cfg5" ]; then steps=20; fi
   python3 bench.py --config $cfg --steps $steps --warmup 5 $extra > $out/bench_${rnd}_$cfg.json 2> $out/bench_${rnd}_$cfg.err
 done
+# SURVEY 8's secondary variant: D = 3, M = 16 (bench line + kernel stats)
+python3 bench.py --config metric --sh-degree 3 --steps 100 --warmup 5 --no-cpu-baseline > $out/bench_${rnd}_metric_sh3.json 2> $out/bench_${rnd}_metric_sh3.err
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $out/trace_sh3 -o trace --output-format csv -- python3 $root/bench.py --sh-degree 3 --steps 20 --warmup 3 --no-cpu-baseline --no-reference-lists --no-graph > $out/trace_sh3.log 2>&1 )
+cp $(find $out/trace_sh3 -name "*kernel_stats.csv" | head -1) $out/${rnd}_kernel_stats_sh3.csv 2>/dev/null; rm -rf $out/trace_sh3
+# one GPU's view of the N-GPU step: emulated shard slices -> predicted scaling table
+python3 tools/predict_scaling.py --out $out/predicted_scaling_${rnd}.json > $out/predicted_scaling_${rnd}.txt 2>&1
+DGS_LIB_PATH=$root/variants/libdgs_timeline.so python3 tools/tile_timeline.py --json $out/tile_timeline_${rnd}.json > $out/tile_timeline_${rnd}.log 2>&1
 python3 bench.py --config metric --steps 50 --warmup 5 --no-cpu-baseline --no-reference-lists --no-graph > $out/bench_${rnd}_metric_eager.json 2>/dev/null
 python3 bench.py --config cfg2 --steps 50 --warmup 5 --no-cpu-baseline --no-reference-lists --no-graph > $out/bench_${rnd}_cfg2_eager.json 2>/dev/null
 python3 bench.py --config metric --steps 30 --warmup 5 --no-cpu-baseline --no-reference-lists --autograd-path > $out/bench_${rnd}_metric_autograd.json 2>/dev/null
