@@ -123,6 +123,10 @@ EXPORTS = {
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "dgs_rank_ordered_sum": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p]),
+    "dgs_blur_loss_slice_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p]),
     "dgs_adam_scalars": (ctypes.c_int, [ctypes.POINTER(DgsAdamGroup), ctypes.c_int32, ctypes.c_double, ctypes.c_double,
                                         ctypes.POINTER(ctypes.c_float)]),
     "dgs_adam_step_dev": (ctypes.c_int, [ctypes.POINTER(DgsAdamGroup), ctypes.c_int32, ctypes.c_double, ctypes.c_double,

@@ -410,6 +410,75 @@ blur_loss_all_kernel(const float* __restrict__ sub, const float* __restrict__ gt
   }
 }
 
+// The loss block of ONE RANK of a subframe-sharded view (deblurgs_amd/sharding.py; new work: the reference is
+// single-GPU).  The rank holds Kl consecutive subframes of the view's K; `blur` is the view's blur image (mean over all K
+// subframes: the ranks' partial sums were all-reduced), prev / next the neighbouring ranks' boundary subframes (NULL at
+// the ends of the view).  Same arithmetic as blur_loss_all_kernel for the subframes held here:
+//   dL/dsub_k = sign(blur - gt) / (E K) + lambda_t [sign(sub_k - sub_{k-1}) - sign(sub_{k+1} - sub_k)] / (E (K - 1)),
+// losses[0] = mean |blur - gt| (the same on every rank), losses[1] = this rank's share of the smoothness value: the
+// differences whose LEFT frame it holds, / (E (K - 1)) -- the caller sums the shares over the ranks.
+template <int KMAX, int V>
+__global__ void __launch_bounds__(256)
+blur_loss_slice_kernel(const float* __restrict__ sub, const float* __restrict__ prev, const float* __restrict__ next,
+                       const float* __restrict__ blur, const float* __restrict__ gt, int Kl, int K, size_t E,
+                       float lambda_t, float* __restrict__ dsub, float* __restrict__ losses) {
+  __shared__ float red[2][4];
+  typedef float vec __attribute__((ext_vector_type(V)));
+  float l1 = 0.0f, sm = 0.0f;
+  for (size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * V; e < E; e += (size_t)gridDim.x * 256 * V) {
+    vec x[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+      if (k < Kl) x[k] = *reinterpret_cast<const vec*>(sub + (size_t)k * E + e);
+    const vec d = *reinterpret_cast<const vec*>(blur + e) - *reinterpret_cast<const vec*>(gt + e);
+    const float c_l1 = 1.0f / ((float)E * (float)K);
+    const float ws = (K > 1) ? lambda_t / ((float)E * (float)(K - 1)) : 0.0f;
+    vec g_l1;
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+      l1 += fabsf(d[i]);
+      g_l1[i] = c_l1 * sgn(d[i]);
+    }
+    vec s_prev = (vec)(0.0f);
+    if (prev != nullptr) {   // the difference across the lower rank boundary belongs to the rank below: sign only
+      const vec dd = x[0] - *reinterpret_cast<const vec*>(prev + e);
+#pragma unroll
+      for (int i = 0; i < V; i++) s_prev[i] = sgn(dd[i]);
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+      if (k < Kl) {
+        vec s_next = (vec)(0.0f);
+        const bool inner = k + 1 < Kl;
+        if (inner || next != nullptr) {
+          const vec nx = inner ? x[k + 1 < KMAX ? k + 1 : k] : *reinterpret_cast<const vec*>(next + e);
+          const vec dd = nx - x[k];
+#pragma unroll
+          for (int i = 0; i < V; i++) {
+            sm += fabsf(dd[i]);
+            s_next[i] = sgn(dd[i]);
+          }
+        }
+        *reinterpret_cast<vec*>(dsub + (size_t)k * E + e) = g_l1 + ws * (s_prev - s_next);
+        s_prev = s_next;
+      }
+    }
+  }
+  l1 = dgs_wave_sum63(l1);
+  sm = dgs_wave_sum63(sm);
+  const int lane = dgs_lane(), w = threadIdx.x >> 6;
+  if (lane == 63) {
+    red[0][w] = l1;
+    red[1][w] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // deterministic fixed-point totals
+    const float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const float c = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    loss_totals_publish(a, c, losses, E, K);
+  }
+}
+
 // train.py:188-193 + scene/gaussian_model.py:456-458 for the K subframes of one step, in subframe order
 __global__ void __launch_bounds__(256)
 densify_stats_kernel(const float* __restrict__ vgrad, const int32_t* __restrict__ radii, int K, int K_total, int P,
@@ -834,6 +903,36 @@ int dgs_blur_loss_grad_dev(const float* subframes, const float* gt, int32_t K, i
                            float* losses, dgs_stream_t stream) {
   if (lambda_t_dev == nullptr) return fail(DGS_E_ARG, "blur_loss_grad_dev: lambda_t_dev is null");
   return blur_loss_impl(subframes, gt, K, C, HW, 0.0f, lambda_t_dev, upstream, blur, dL_dsubframes, losses, stream);
+}
+
+int dgs_blur_loss_slice_grad(const float* subframes, const float* prev_last, const float* next_first, const float* blur,
+                             const float* gt, int32_t K_local, int32_t K_total, int32_t C, int32_t HW, float lambda_t,
+                             float* dL_dsubframes, float* losses, dgs_stream_t stream) {
+  if (subframes == nullptr || blur == nullptr || gt == nullptr || dL_dsubframes == nullptr || losses == nullptr ||
+      K_local < 1 || K_total < K_local || K_local > 32 || C < 1 || HW < 1)
+    return fail(DGS_E_ARG, "blur_loss_slice_grad: bad argument (1 <= K_local <= 32, K_local <= K_total)");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t E = (size_t)C * HW;
+  hipError_t e = hipMemsetAsync(losses, 0, 8 * sizeof(float), s);
+  if (e != hipSuccess) return fail_hip(e, "blur_loss_slice_grad");
+  const uintptr_t align = reinterpret_cast<uintptr_t>(subframes) | reinterpret_cast<uintptr_t>(blur) |
+                          reinterpret_cast<uintptr_t>(gt) | reinterpret_cast<uintptr_t>(dL_dsubframes) |
+                          reinterpret_cast<uintptr_t>(prev_last) | reinterpret_cast<uintptr_t>(next_first);
+  const bool v4 = (E % 4 == 0) && (align % 16 == 0);
+  const size_t per = v4 ? 4 : 1;
+  const size_t want = (E / per + 255) / 256;
+  const dim3 grid((uint32_t)(want < 512 ? (want == 0 ? 1 : want) : 512));   // (as dgs_launch_blur_loss: few blocks, few atomics)
+#define DGS_BLS(KMAX, V)                                                                                              \
+  hipLaunchKernelGGL((blur_loss_slice_kernel<KMAX, V>), grid, dim3(256), 0, s, subframes, prev_last, next_first, blur, gt, \
+                     K_local, K_total, E, lambda_t, dL_dsubframes, losses)
+  if (v4) {
+    if (K_local <= 4) DGS_BLS(4, 4); else if (K_local <= 16) DGS_BLS(16, 4); else DGS_BLS(32, 2);
+  } else {
+    if (K_local <= 4) DGS_BLS(4, 1); else if (K_local <= 16) DGS_BLS(16, 1); else DGS_BLS(32, 1);
+  }
+#undef DGS_BLS
+  e = hipGetLastError();
+  return e == hipSuccess ? DGS_OK : fail_hip(e, "blur_loss_slice_grad");
 }
 
 int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t K_total, int32_t P,

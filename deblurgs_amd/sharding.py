@@ -446,6 +446,26 @@ def subframe_sharded_loss_grad(local_subframes, gt, K, lambda_t, group=None):
             sends.append((S[-1].contiguous(), upper))
             recvs.append((next_first, upper))
         _p2p(sends, recvs, group)
+    if S.is_cuda and 0 < k_loc <= 32 and S.dtype == torch.float32:
+        # device tensors: the whole block in ONE launch (dgs_blur_loss_slice_grad: dL/dsubframes, the L1 value and this
+        # rank's share of the smoothness value, deterministic totals) instead of ~20 elementwise / reduction launches
+        import ctypes
+        from . import _lib
+        Sc, gtc, blurc = S.contiguous(), gt.contiguous().float(), blur.contiguous()
+        dS = torch.empty_like(Sc)
+        work = torch.empty(8, dtype=torch.float32, device=S.device)
+        ptr = lambda t: None if t is None else ctypes.c_void_p(t.contiguous().data_ptr())
+        prev_c = None if prev_last is None else prev_last.contiguous()
+        next_c = None if next_first is None else next_first.contiguous()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(S.device).cuda_stream)
+        _lib.check(_lib.lib().dgs_blur_loss_slice_grad(ptr(Sc), ptr(prev_c), ptr(next_c), ptr(blurc), ptr(gtc), k_loc, int(K),
+                                                       int(gt.shape[0]) if gt.dim() == 3 else 1,
+                                                       int(E // (gt.shape[0] if gt.dim() == 3 else 1)), float(lambda_t),
+                                                       ptr(dS), ptr(work), stream), "dgs_blur_loss_slice_grad")
+        l1v, sm_local = work[0], work[1:2]
+        if every:
+            dist.all_reduce(sm_local, op=dist.ReduceOp.SUM, group=group)
+        return dS, l1v, sm_local.reshape(())
     d = blur - gt
     g_l1 = _sgn(d) / (E * K)
     dS = g_l1[None].expand_as(S).clone() if k_loc > 0 else S

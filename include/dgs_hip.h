@@ -295,6 +295,17 @@ int dgs_blur_loss_grad_dev(const float* subframes, const float* gt, int32_t K, i
                            const float* lambda_t_dev, const float* upstream, float* blur, float* dL_dsubframes,
                            float* losses, dgs_stream_t stream);
 
+/* Multi-GPU runs, "subframes" sharding (new work, the reference is single-GPU): the loss block of ONE RANK, which
+ * holds K_local consecutive subframes [K_local,C,HW] of a view's K_total.  blur [C,HW] = the view's blur image (mean over
+ * all K_total subframes, after the ranks' partial sums have been all-reduced), prev_last / next_first [C,HW] = the boundary
+ * subframes of the neighbouring ranks (NULL at the ends of the view).  Writes dL/dsubframes of the local subframes (the
+ * formula of dgs_blur_loss_grad with K = K_total) and, in the 8-float work area `losses`: [0] mean |blur - gt| (the same
+ * on every rank), [1] this rank's share of the temporal-smoothness value (the differences whose LEFT frame it holds,
+ * over E (K_total - 1)): the caller sums the shares over the ranks.  Same deterministic fixed-point totals.  K_local <= 32. */
+int dgs_blur_loss_slice_grad(const float* subframes, const float* prev_last, const float* next_first, const float* blur,
+                             const float* gt, int32_t K_local, int32_t K_total, int32_t C, int32_t HW, float lambda_t,
+                             float* dL_dsubframes, float* losses, dgs_stream_t stream);
+
 /* Densification-statistic consumers of the rasteriser's per-subframe outputs (train.py:188-193 with
  * scene/gaussian_model.py:456-458), for all K subframes in one pass and in subframe order:
  *   visible = radii[k] > 0;  max_radii2D = max(max_radii2D, radii[k]);

@@ -876,6 +876,51 @@ def test_cfg1_exact_shape_on_the_device(gpu):
     sharp_backward_check(sc, 1, depth=True)
 
 
+@pytest.mark.parametrize("K,H,W,cuts", [(15, 37, 53, (0, 1, 3, 5, 7, 9, 11, 13, 15)), (5, 16, 20, (0, 2, 2, 5)), (2, 9, 7, (0, 1, 2))])
+def test_slice_loss_kernel_equals_the_whole_view_loss(gpu, K, H, W, cuts):
+    """dgs_blur_loss_slice_grad (one rank's loss block of a subframe-sharded view) against torch autograd of the reference
+    loss (train.py:147-163 image terms) on the WHOLE view: for every slice [k0, k1) of the subframes -- with the
+    neighbouring slices' boundary frames handed in as a rank would receive them -- dL/dsubframes must be the whole-view
+    gradient's rows, losses[0] the L1 value, and the slices' smoothness shares must add up to the smoothness value.
+    Ragged sizes (E not a multiple of 4: scalar path) and an empty slice in between."""
+    import ctypes
+    import torch
+    from deblurgs_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(K * 1000 + H)
+    X = torch.rand(K, 3, H, W, device=gpu)
+    X[1, :, : H // 2] = X[0, :, : H // 2]                       # exact ties: sign(0) = 0 on both sides
+    gt = torch.rand(3, H, W, device=gpu)
+    lam = 0.037
+    Xr = X.clone().requires_grad_(True)
+    blur = Xr.mean(0)
+    l1 = (blur - gt).abs().mean()
+    sm = (Xr[1:] - Xr[:-1]).abs().mean() if K > 1 else torch.zeros((), device=gpu)
+    (l1 + lam * sm).backward()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    blur_c = X.mean(0).contiguous()
+    share = 0.0
+    for k0, k1 in zip(cuts[:-1], cuts[1:]):
+        if k1 == k0:
+            continue
+        S = X[k0:k1].contiguous()
+        prev = X[k0 - 1].contiguous() if k0 > 0 else None
+        nxt = X[k1].contiguous() if k1 < K else None
+        dS = torch.full_like(S, float("nan"))
+        work = torch.empty(8, device=gpu)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        _lib.check(L.dgs_blur_loss_slice_grad(p(S), p(prev), p(nxt), p(blur_c), p(gt), k1 - k0, K, 3, H * W, lam, p(dS),
+                                              p(work), st), "dgs_blur_loss_slice_grad")
+        torch.cuda.synchronize()
+        ref = Xr.grad[k0:k1]
+        assert float((dS - ref).abs().max()) <= 1e-9 + 1e-6 * float(ref.abs().max()), (k0, k1)
+        assert abs(float(work[0]) - float(l1)) <= 1e-6
+        share += float(work[1])
+    assert abs(share - float(sm)) <= 2e-6
+    assert L.dgs_blur_loss_slice_grad(None, None, None, None, None, 1, 1, 3, 4, 0.0, None, None, st) != 0
+    assert L.dgs_blur_loss_slice_grad(p(X), None, None, p(blur_c), p(gt), 33, 40, 3, H * W, 0.0, p(X), p(work), st) != 0
+
+
 def test_densification_stats_match_reference_loop(gpu):
     """dgs_densify_stats against the reference's per-subframe Python loop (train.py:188-193,
     scene/gaussian_model.py:456-458) written with torch ops."""
