@@ -501,6 +501,10 @@ def run_rank(args):
     extras = None
     if world > 1 and not args.no_extras and not args.autograd_path:
         extras = {}
+        if rank == 0:   # for the record, should an extra region never return: the headline region's figures, on stderr
+            print(json.dumps({"headline_before_extras": {
+                "n_gpus": world, "sharding": args.shard, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "value": round((K if subframes_mode else world * K) * args.steps / dt, 2)}}), file=sys.stderr, flush=True)
         n_bucket = sum(p.numel() for p in params)
 
         def ab_allreduce(kind, iters=8):
