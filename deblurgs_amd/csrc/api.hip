@@ -511,7 +511,7 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
                                 hipStream_t s) {
   const size_t E = (size_t)C * HW;
   if (losses != nullptr) {
-    hipError_t e = hipMemsetAsync(losses, 0, 8 * sizeof(float), s);   // results + accumulators + arrival counter
+    hipError_t e = dgs_launch_clear_words(reinterpret_cast<uint32_t*>(losses), 8, s);   // results + accumulators + arrival counter
     if (e != hipSuccess) return e;
   }
   const bool v4 = (E % 4 == 0) && ((reinterpret_cast<uintptr_t>(sub) | reinterpret_cast<uintptr_t>(gt) |
@@ -611,7 +611,8 @@ static hipError_t launch_tile_cull(const DgsView& v, const DgsCarve& c, hipStrea
   return dgs_launch_cull_offsets(v, c, c.num_rendered + 2, s);
 }
 
-int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stream_t stream) {
+// copy_count = false: the caller (the capacity-mode forward) publishes the count words itself, from its finalize kernel
+static int forward_geometry_impl(const DgsProblem* p, const DgsForwardOut* out, dgs_stream_t stream, bool copy_count) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = check_problem(p);
   if (rc != DGS_OK) return rc;
@@ -629,24 +630,30 @@ int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stre
   DgsCarve c;
   carve(p, L, &c);
   const DgsView v = make_view(p);
-  hipError_t e = hipMemsetAsync(c.num_rendered, 0, 32, s);
+  hipError_t e = dgs_launch_clear_words(c.num_rendered, 8, s);   // (a kernel, not a memset node: see finalize_count_kernel)
   if (e != hipSuccess) return fail_hip(e, "clear status");
   DGS_STAGE(DGS_STAGE_PREPROCESS, "preprocess", dgs_launch_preprocess(*p, v, c, out->radii, s));
   if (!v.tile_cull) {
     DGS_STAGE(DGS_STAGE_SCAN, "scan",
               dgs_launch_scan(c.tiles_touched, c.point_offsets, (uint64_t)p->K * p->P, c.scan_tmp, c.num_rendered, s));
     // two words: R and the high half of the 64-bit total (non-zero = the u32 duplicate offsets overflowed)
-    e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (copy_count)
+      e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   } else {
     // tile_cull: R is the number of surviving duplicates: per-slot test in natural order, depth ordering (which also
     // lays the per-pair records and counts out in its order), scan of the counts.  Status words [0], [1] stay 0.
     DGS_STAGE(DGS_STAGE_DEPTH_ORDER, "depth order", launch_depth_order(p, c, s));
     DGS_STAGE(DGS_STAGE_TILE_CULL, "tile cull", launch_tile_cull(v, c, s));
     // two words: R and the high half of the 64-bit total (non-zero = the u32 duplicate offsets overflowed)
-    e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (copy_count)
+      e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   }
   if (e != hipSuccess) return fail_hip(e, "copy num_rendered");
   return DGS_OK;
+}
+
+int dgs_forward_geometry(const DgsProblem* p, const DgsForwardOut* out, dgs_stream_t stream) {
+  return forward_geometry_impl(p, out, stream, true);
 }
 
 // R = the exact duplicate count (two-phase forward), or the capacity of the duplicate arrays when `speculative`
@@ -730,20 +737,33 @@ int dgs_forward_composite(const DgsProblem* p, const DgsForwardOut* out, uint32_
 static int forward_capacity_impl(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream,
                                  int phases) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  int rc = dgs_forward_geometry(p, out, stream);   // includes the async copy of the counts to num_rendered_host[0..1]
+  // The count words reach the host from the finalize kernel itself when num_rendered_host is device-accessible pinned
+  // memory (hipHostMalloc / torch pin_memory: the usual case) -- no copy node in the launch chain; otherwise by copies.
+  uint32_t* host_dev = nullptr;
+  if (out != nullptr && out->num_rendered_host != nullptr && p != nullptr && p->P > 0) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, out->num_rendered_host, 0) == hipSuccess && dp != nullptr)
+      host_dev = reinterpret_cast<uint32_t*>(dp);
+    else
+      (void)hipGetLastError();   // not mapped: the copies below
+  }
+  int rc = forward_geometry_impl(p, out, stream, host_dev == nullptr);
   if (rc != DGS_OK) return rc;
   if (p->P > 0) {
     DgsLayout L;
     make_layout(p->P, p->W, p->H, p->K, 0, p->wide_records != 0, &L);
     DgsCarve c;
     carve(p, L, &c);
-    hipError_t e = dgs_launch_finalize_count(c, p->tile_cull != 0, capacity, out->drop_counter, out->status_dev, s);
-    if (e == hipSuccess && out->drop_counter != nullptr)   // [4] = overflowed forwards so far (caller's running counter)
-      e = hipMemcpyAsync(out->num_rendered_host + 4, out->drop_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess)   // [2] = overflow flag, [3] = the count the lists were built with (0 on overflow)
-      e = hipMemcpyAsync(out->num_rendered_host + 2, c.num_rendered + 5, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(out->num_rendered_host + 3, c.num_rendered + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    hipError_t e = dgs_launch_finalize_count(c, p->tile_cull != 0, capacity, out->drop_counter, out->status_dev, host_dev,
+                                             out->status_host_indirect, s);
+    if (host_dev == nullptr) {
+      if (e == hipSuccess && out->drop_counter != nullptr)   // [4] = overflowed forwards so far (caller's running counter)
+        e = hipMemcpyAsync(out->num_rendered_host + 4, out->drop_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess)   // [2] = overflow flag, [3] = the count the lists were built with (0 on overflow)
+        e = hipMemcpyAsync(out->num_rendered_host + 2, c.num_rendered + 5, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(out->num_rendered_host + 3, c.num_rendered + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    }
     if (e != hipSuccess) return fail_hip(e, "finalize count");
   } else {
     out->num_rendered_host[2] = 0;
@@ -913,7 +933,7 @@ int dgs_blur_loss_slice_grad(const float* subframes, const float* prev_last, con
     return fail(DGS_E_ARG, "blur_loss_slice_grad: bad argument (1 <= K_local <= 32, K_local <= K_total)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t E = (size_t)C * HW;
-  hipError_t e = hipMemsetAsync(losses, 0, 8 * sizeof(float), s);
+  hipError_t e = dgs_launch_clear_words(reinterpret_cast<uint32_t*>(losses), 8, s);
   if (e != hipSuccess) return fail_hip(e, "blur_loss_slice_grad");
   const uintptr_t align = reinterpret_cast<uintptr_t>(subframes) | reinterpret_cast<uintptr_t>(blur) |
                           reinterpret_cast<uintptr_t>(gt) | reinterpret_cast<uintptr_t>(dL_dsubframes) |
@@ -933,6 +953,28 @@ int dgs_blur_loss_slice_grad(const float* subframes, const float* prev_last, con
 #undef DGS_BLS
   e = hipGetLastError();
   return e == hipSuccess ? DGS_OK : fail_hip(e, "blur_loss_slice_grad");
+}
+
+int dgs_copy_words(void* dst_dev, const void* src, int32_t n_words, dgs_stream_t stream) {
+  if (n_words < 0 || n_words > 4096 || (n_words > 0 && (dst_dev == nullptr || src == nullptr)))
+    return fail(DGS_E_ARG, "copy_words: bad argument (at most 4096 words)");
+  if (n_words == 0) return DGS_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  void* dp = nullptr;
+  hipError_t e;
+  if (hipHostGetDevicePointer(&dp, const_cast<void*>(src), 0) == hipSuccess && dp != nullptr) {
+    e = dgs_launch_copy_words(reinterpret_cast<uint32_t*>(dst_dev), reinterpret_cast<const uint32_t*>(dp), n_words, s);
+  } else {   // src is not mapped pinned host memory: device memory (a kernel copies it just the same) or pageable
+    (void)hipGetLastError();
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeDevice)
+      e = dgs_launch_copy_words(reinterpret_cast<uint32_t*>(dst_dev), reinterpret_cast<const uint32_t*>(src), n_words, s);
+    else {
+      (void)hipGetLastError();
+      e = hipMemcpyAsync(dst_dev, src, (size_t)n_words * 4, hipMemcpyDefault, s);
+    }
+  }
+  return e == hipSuccess ? DGS_OK : fail_hip(e, "copy_words");
 }
 
 int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t K, int32_t K_total, int32_t P,

@@ -631,19 +631,48 @@ cull_emit_kernel(DgsView v, const DgsRow* __restrict__ rows, const uint32_t* __r
 // the sort / ranges kernels use = min(count, capacity), [5] overflow flag (the lists are truncated: every consumer that
 // indexes by duplicate offset returns early, the caller re-runs with a larger capacity).
 __global__ void finalize_count_kernel(uint32_t* __restrict__ nr, int cull, uint32_t cap, uint32_t* __restrict__ drops,
-                                      uint32_t* __restrict__ status) {
+                                      uint32_t* __restrict__ status, uint32_t* __restrict__ host_words,
+                                      const unsigned long long* __restrict__ host_indirect) {
   const uint32_t n = cull ? nr[2] : nr[0];
   const uint32_t hi = cull ? nr[3] : nr[1];
   const bool bad = (hi != 0u) || (n > cap);
   nr[4] = bad ? 0u : n;
   nr[5] = bad ? 1u : 0u;
-  if (bad && drops != nullptr) drops[0] += 1u;   // the caller's running count of overflowed forwards (graph replays)
+  uint32_t dropped = 0u;
+  if (drops != nullptr) {   // the caller's running count of overflowed forwards (graph replays)
+    dropped = drops[0] + (bad ? 1u : 0u);
+    if (bad) drops[0] = dropped;
+  }
   if (status != nullptr) {                       // DgsForwardOut.status_dev: the words of THIS forward, outside the blobs
     status[0] = n;
     status[1] = hi;
     status[2] = bad ? 1u : 0u;
     status[3] = bad ? 0u : n;
   }
+  // The same words straight into PINNED HOST memory (device-accessible), instead of four 4-byte copy nodes behind this
+  // kernel: a copy node in a replayed graph costs a hand-over between the compute queue and the copy engine -- tens of
+  // microseconds each on a step that takes a few hundred (tools/step_gaps.py).  host_words = num_rendered_host itself;
+  // host_indirect = a device word holding the address of the pinned block this REPLAY should write (the caller changes it
+  // from step to step through device memory: DgsForwardOut.status_host_indirect).
+  uint32_t* dst[2] = {host_words, host_indirect != nullptr ? reinterpret_cast<uint32_t*>(host_indirect[0]) : nullptr};
+  for (int i = 0; i < 2; i++) {
+    uint32_t* h = dst[i];
+    if (h == nullptr) continue;
+    __hip_atomic_store(&h[0], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&h[1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&h[2], bad ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&h[3], bad ? 0u : n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (drops != nullptr) __hip_atomic_store(&h[4], dropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+}
+
+// a few words cleared / copied by a kernel instead of a memset / copy node (see finalize_count_kernel)
+__global__ void clear_words_kernel(uint32_t* __restrict__ p, int n) {
+  for (int i = threadIdx.x; i < n; i += 64) p[i] = 0u;
+}
+__global__ void copy_words_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int n) {
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
 // ---------------------------------------------------------------------------------------------- ranges
@@ -1203,8 +1232,19 @@ PassPlan plan_passes(int begin_bit, int end_bit) {
 }  // namespace
 
 hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, uint32_t* drops, uint32_t* status,
-                                     hipStream_t s) {
-  hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, s, c.num_rendered, cull, cap, drops, status);
+                                     uint32_t* host_words, const uint64_t* host_indirect, hipStream_t s) {
+  hipLaunchKernelGGL(finalize_count_kernel, dim3(1), dim3(1), 0, s, c.num_rendered, cull, cap, drops, status, host_words,
+                     reinterpret_cast<const unsigned long long*>(host_indirect));
+  return hipGetLastError();
+}
+
+hipError_t dgs_launch_clear_words(uint32_t* p, int n, hipStream_t s) {
+  hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(64), 0, s, p, n);
+  return hipGetLastError();
+}
+
+hipError_t dgs_launch_copy_words(uint32_t* dst, const uint32_t* src, int n, hipStream_t s) {
+  hipLaunchKernelGGL(copy_words_kernel, dim3(1), dim3(256), 0, s, dst, src, n);
   return hipGetLastError();
 }
 

@@ -204,7 +204,9 @@ hipError_t dgs_launch_cloud_activations(int P, const float* scales, const float*
                                         float scale_lb, float* out_scales, float* out_rotations, float* out_opacities,
                                         hipStream_t s);
 hipError_t dgs_launch_finalize_count(const DgsCarve& c, int cull, uint32_t cap, uint32_t* drops, uint32_t* status,
-                                     hipStream_t s);
+                                     uint32_t* host_words, const uint64_t* host_indirect, hipStream_t s);
+hipError_t dgs_launch_clear_words(uint32_t* p, int n, hipStream_t s);
+hipError_t dgs_launch_copy_words(uint32_t* dst, const uint32_t* src, int n, hipStream_t s);
 hipError_t dgs_launch_ranges(const DgsView& v, const DgsCarve& c, uint32_t R, hipStream_t s,
                              const uint32_t* n_dev = nullptr, int tile_shift = 32);
 hipError_t dgs_launch_scan(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* tmp, uint32_t* total,

@@ -108,17 +108,28 @@ class FusedStep:
                 still.append(pnd)
         self._pending = still
 
-    def _track_replay(self, ent, ckey, request, cap, dev):
-        """Behind a replay: this step's count / overflow words travel from the graph's status words (device, written by
-        the forward's finalize kernel) into a pinned slot of THIS step, and the step joins the pending list."""
+    def _track_replay(self, slot, ckey, request, cap, dev):
+        """Behind a replay: the step joins the pending list with the pinned slot that its forward's finalize kernel writes
+        the count / overflow words into (DgsForwardOut.status_host_indirect: the slot's address travelled to the graph
+        through the scalar block, no copy behind the replay)."""
         pnd = _Pending()
-        pnd.host = self._host_words()
-        pnd.host[:4].copy_(ent["status"], non_blocking=True)
+        pnd.host = slot
         pnd.speculative, pnd.key, pnd.generation = True, ckey, self._generation
         pnd.request, pnd.capacity = request, cap
         pnd.event = torch.cuda.Event()
         pnd.event.record(torch.cuda.current_stream(dev))
         self._pending.append(pnd)
+
+    def _push_scalars(self, ent, hbuf, dev):
+        """This step's scalar block -- and the address of the pinned slot its count words go to (words [4:6]) -- from the
+        pinned ring buffer to the graph's device block by a KERNEL (dgs_copy_words): an asynchronous copy in front of every
+        graph launch costs a hand-over between the copy engine and the compute queue, tens of microseconds per step."""
+        slot = self._host_words()
+        hbuf.numpy().view("uint64")[2] = slot.data_ptr()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().dgs_copy_words(ctypes.c_void_p(ent["hyper"].data_ptr()), ctypes.c_void_p(hbuf.data_ptr()),
+                                             int(hbuf.numel()), stream), "dgs_copy_words")
+        return slot
 
     def _capacity(self, key):
         seen = self._seen.get(key)
@@ -210,10 +221,11 @@ class FusedStep:
         return self._drops_dev
 
     # ------------------------------------------------------------------------------------------ captured replay
-    HYPER_FLOATS = 64        # [0] lambda_t, [1:4] background, [8:8 + 2 * 16] Adam scalars, [48:] alignment jitter (f <= 16)
+    HYPER_FLOATS = 64        # [0] lambda_t, [1:4] background, [4:6] address of the step's pinned status slot (one uint64),
+                             # [8:8 + 2 * 16] Adam scalars, [48:] alignment jitter (f <= 16)
 
     def _hyper_words(self, f):
-        return max(self.HYPER_FLOATS, 48 + f)
+        return (max(self.HYPER_FLOATS, 48 + f) + 1) // 2 * 2        # (even: words [4:6] are written as one uint64)
 
     def replay(self, cam_idx, lambda_t, gt, subframe_indice, optimizer, tail, signature=(), background=None,
                uniform=None, stats=None):
@@ -270,10 +282,10 @@ class FusedStep:
             p.grad = g
         optimizer.skip_flag_ptr = ent["result"]["skip_flag_ptr"]
         optimizer.step_scalars(hv[8:8 + 2 * _lib.ADAM_MAX_GROUPS])
-        ent["hyper"].copy_(hbuf, non_blocking=True)
+        slot = self._push_scalars(ent, hbuf, dev)
         hev.record(torch.cuda.current_stream(dev))
         ent["graph"].replay()
-        self._track_replay(ent, ckey, (cam_idx, subframe_indice), cap, dev)
+        self._track_replay(slot, ckey, (cam_idx, subframe_indice), cap, dev)
         self.last_capacity = cap
         self.replayed += 1
         return ent["result"]
@@ -337,14 +349,14 @@ class FusedStep:
         hv[1:4] = (torch.rand(3) if background is None else background.detach().float().cpu()).numpy()
         if m.curve_random_sample and f > 2:
             hv[48:48 + f - 2] = (torch.rand(f - 2) if uniform is None else uniform.detach().float().cpu()).numpy()
-        ent["hyper"].copy_(hbuf, non_blocking=True)
+        slot = self._push_scalars(ent, hbuf, dev)
         hev.record(torch.cuda.current_stream(dev))
         if background_dev is not None:               # (shared draws of a "subframes" step: device to device, stream-ordered)
             ent["hyper"][1:4].copy_(background_dev.reshape(3))
         if uniform_dev is not None and m.curve_random_sample and f > 2:
             ent["hyper"][48:48 + f - 2].copy_(uniform_dev.reshape(f - 2))
         ent["graph"].replay()
-        self._track_replay(ent, ckey, (cam_idx, subframe_indice), cap, dev)
+        self._track_replay(slot, ckey, (cam_idx, subframe_indice), cap, dev)
         self.last_capacity = cap
         self.replayed += 1
         return ent["finish"](float(lambda_t))
@@ -527,7 +539,13 @@ class FusedStep:
         row = cam * (C + 1) * 3                       # this view's curve in the translation control points ...
         quat = int(cr_all.shape[-1] == 4)             # ... and in the rotation ones ([C+1,4]: quaternion curve)
         rrow = cam * (C + 1) * cr_all.shape[-1]
-        proj = m.ref_cam.projection_matrix.to(dev, torch.float32).contiguous()   # (stored as a transposed view)
+        # (stored as a transposed view: made contiguous ONCE -- a 16-float copy kernel per step is a launch and a gap on the
+        # device's timeline, 2 % of a cfg2 step)
+        pm = m.ref_cam.projection_matrix
+        pc = getattr(self, "_proj_cache", None)
+        if pc is None or pc[0] is not pm or pc[1] != pm._version or pc[2].device != dev:
+            pc = self._proj_cache = (pm, pm._version, pm.to(dev, torch.float32).contiguous().clone())
+        proj = pc[2]
         view = torch.empty((K, 4, 4), **f32)
         full = torch.empty((K, 4, 4), **f32)
         campos = torch.empty((K, 3), **f32)
@@ -585,6 +603,7 @@ class FusedStep:
             host, cap, pnd = _cap["host"], int(_cap["capacity"]), None
             out.drop_counter = ctypes.c_void_p(self._drop_counter(dev).data_ptr())
             out.status_dev = ctypes.c_void_p(_cap["status"].data_ptr())
+            out.status_host_indirect = ctypes.c_void_p(_cap["lambda_ptr"] + 16)     # words [4:6] of the scalar block
         out.num_rendered_host = ctypes.c_void_p(host.data_ptr())
         if cap is not None:
             binning = torch.empty(L.dgs_binning_state_bytes(cap, W, H, K), dtype=torch.uint8, device=dev)

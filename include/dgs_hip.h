@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 11
+#define DGS_ABI_VERSION 12
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -110,6 +110,12 @@ typedef struct DgsForwardOut {
                                 * into the SAME pinned num_rendered_host block; a caller that runs several replays ahead
                                 * enqueues its own copy of status_dev into a per-step pinned slot right behind each replay
                                 * and so reads the words of exactly that replay. */
+  const uint64_t* status_host_indirect; /* dgs_forward only, optional DEVICE uint64: the address of a device-accessible
+                                * PINNED HOST uint32[5] that this forward's finalize kernel writes the five words of
+                                * num_rendered_host into, read from device memory when the kernel runs.  A caller that
+                                * replays a captured graph stores a different block's address there before every replay
+                                * (through its own device-side scalar block): every replay then reports into a pinned
+                                * slot of its own without any copy behind it. */
 } DgsForwardOut;
 
 typedef struct DgsBackwardIO {
@@ -228,7 +234,9 @@ int dgs_forward_render(const DgsProblem* p, const DgsForwardOut* out, uint32_t n
  * dgs_binning_state_bytes(capacity, ...).  num_rendered_host (pinned, >= 4 words) receives asynchronously
  * [0] the true duplicate count, [1] its u32-overflow word, [2] overflow flag (count > capacity or [1] != 0: the lists
  * were NOT built, the outputs are meaningless and dgs_backward on this state returns garbage-but-in-bounds results;
- * re-run with a larger capacity), [3] the count the lists were built with, [4] the running drop_counter (if given).
+ * re-run with a larger capacity), [3] the count the lists were built with, [4] the running drop_counter (if given) --
+ * written by the forward's finalize kernel itself when the block is device-accessible pinned memory (no copy in the
+ * launch chain), by asynchronous copies otherwise.
  * The same flag is the device word at
  * geom_state + DgsLayout.num_rendered + 20 bytes, which dgs_adam_step / dgs_densify_stats accept as `skip_flag` so that
  * a whole training step can be enqueued without any host synchronisation and still never apply a truncated gradient.
@@ -305,6 +313,13 @@ int dgs_blur_loss_grad_dev(const float* subframes, const float* gt, int32_t K, i
 int dgs_blur_loss_slice_grad(const float* subframes, const float* prev_last, const float* next_first, const float* blur,
                              const float* gt, int32_t K_local, int32_t K_total, int32_t C, int32_t HW, float lambda_t,
                              float* dL_dsubframes, float* losses, dgs_stream_t stream);
+
+/* A few words (n_words <= 4096) copied to device memory BY A KERNEL on `stream`: src may be device memory or pinned host
+ * memory (hipHostMalloc / torch pin_memory: device-accessible).  What a captured training step's per-step scalars travel
+ * with: an asynchronous host-to-device copy in front of every graph launch costs a hand-over between the copy engine and
+ * the compute queue (tens of microseconds); a kernel in front of the graph costs one launch.  Pageable host memory falls
+ * back to hipMemcpyAsync. */
+int dgs_copy_words(void* dst_dev, const void* src, int32_t n_words, dgs_stream_t stream);
 
 /* Densification-statistic consumers of the rasteriser's per-subframe outputs (train.py:188-193 with
  * scene/gaussian_model.py:456-458), for all K subframes in one pass and in subframe order:

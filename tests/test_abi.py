@@ -41,7 +41,7 @@ def test_struct_sizes_match_the_header_layout():
     from deblurgs_amd import _lib
     # 6 ints + 5 floats + 5 ints + 1 float = 68 bytes (+4 padding), then 12 pointers, then 3 x (pointer + size_t)
     assert ctypes.sizeof(_lib.DgsProblem) == 72 + 12 * 8 + 3 * 16
-    assert ctypes.sizeof(_lib.DgsForwardOut) == 48     # + drop_counter, status_dev
+    assert ctypes.sizeof(_lib.DgsForwardOut) == 56     # + drop_counter, status_dev, status_host_indirect
     assert ctypes.sizeof(_lib.DgsBackwardIO) == 8 + 8 * 3 + 16 + 11 * 8 + 8 + 3 * 8 + 8   # + hinge scale, stats_* (padded)
     assert ctypes.sizeof(_lib.DgsLayout) == 29 * 8 + 16     # + sort_bits, sort_passes, pack_g_shift, pack_tile_shift
 
