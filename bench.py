@@ -182,8 +182,10 @@ def stage_bytes(P, Pv_tot, R_tot, N, K, s):
         "contrib_reduce": 0,
         "depth_order": 24 * P * K,   # ideal one-read-one-write sort of the K*P (key, index) pairs
         # tile_cull: the per-slot test in natural order (tiles_touched in, 16-byte record + count out per pair, 36 B of
-        # each visible pair's row), the counts gathered into depth order (order, flag, count in, count out) and their scan
-        "tile_cull": (4 + 20) * P * K + 36 * Pv_tot + 16 * P * K + 8 * P * K,
+        # each visible pair's row).  K * P <= 2^24: the counts ride through the depth sort and only their scan follows
+        # (timed as "scan"); beyond that they are gathered into depth order (order, flag, count in, count out) and scanned
+        # inside this stage
+        "tile_cull": (4 + 20) * P * K + 36 * Pv_tot + (0 if P * K <= (1 << 24) else 16 * P * K + 8 * P * K),
     }
 
 

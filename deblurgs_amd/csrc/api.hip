@@ -596,11 +596,12 @@ int dgs_backward_scratch_layout(uint64_t R, int32_t P, int32_t K, size_t* sums_o
 // order the (k, Gaussian) pairs by (k, depth bits, index): segmented stable sort of the depth keys preprocess wrote;
 // the result (flat indices) lands in c.gsort_vals
 // (tile_cull: its last pass also writes the visibility flags in that order)
-static hipError_t launch_depth_order(const DgsProblem* p, const DgsCarve& c, hipStream_t s) {
+static hipError_t launch_depth_order(const DgsProblem* p, const DgsCarve& c, hipStream_t s, bool carry_counts = false) {
   const bool cull = p->tile_cull != 0;
   // (status word [6]: "a visible depth key needs more than 27 bits", zeroed with the other status words before preprocess)
   return dgs_launch_depth_sort(c.gsort_keys, c.gsort_keys_alt, c.gsort_vals, c.gsort_vals_alt, p->K, (uint32_t)p->P,
-                               c.gsort_tmp, cull ? c.tt_sorted : nullptr, c.num_rendered + 6, s);
+                               c.gsort_tmp, cull ? c.tt_sorted : nullptr, c.num_rendered + 6, s,
+                               carry_counts ? c.cull_cnt : nullptr, carry_counts ? c.tt_tight : nullptr);
 }
 
 // tile_cull: per-slot test in natural order (independent of the depth order), then records and counts into depth order and
@@ -610,6 +611,9 @@ static hipError_t launch_tile_cull(const DgsView& v, const DgsCarve& c, hipStrea
   if (e != hipSuccess) return e;
   return dgs_launch_cull_offsets(v, c, c.num_rendered + 2, s);
 }
+// the surviving-tile counts ride through the depth sort in the top byte of its 32-bit values when the flat (subframe,
+// Gaussian) index fits 24 bits: COUNT first (natural order), then the depth order, then only the scan
+static bool counts_ride_with_the_sort(const DgsProblem* p) { return (uint64_t)p->K * (uint64_t)p->P <= (1ull << 24); }
 
 // copy_count = false: the caller (the capacity-mode forward) publishes the count words itself, from its finalize kernel
 static int forward_geometry_impl(const DgsProblem* p, const DgsForwardOut* out, dgs_stream_t stream, bool copy_count) {
@@ -642,8 +646,14 @@ static int forward_geometry_impl(const DgsProblem* p, const DgsForwardOut* out, 
   } else {
     // tile_cull: R is the number of surviving duplicates: per-slot test in natural order, depth ordering (which also
     // lays the per-pair records and counts out in its order), scan of the counts.  Status words [0], [1] stay 0.
-    DGS_STAGE(DGS_STAGE_DEPTH_ORDER, "depth order", launch_depth_order(p, c, s));
-    DGS_STAGE(DGS_STAGE_TILE_CULL, "tile cull", launch_tile_cull(v, c, s));
+    if (counts_ride_with_the_sort(p)) {
+      DGS_STAGE(DGS_STAGE_TILE_CULL, "tile cull", dgs_launch_cull_count(v, c, s));
+      DGS_STAGE(DGS_STAGE_DEPTH_ORDER, "depth order", launch_depth_order(p, c, s, true));
+      DGS_STAGE(DGS_STAGE_SCAN, "scan", dgs_launch_cull_offsets(v, c, c.num_rendered + 2, s, true));
+    } else {
+      DGS_STAGE(DGS_STAGE_DEPTH_ORDER, "depth order", launch_depth_order(p, c, s));
+      DGS_STAGE(DGS_STAGE_TILE_CULL, "tile cull", launch_tile_cull(v, c, s));
+    }
     // two words: R and the high half of the 64-bit total (non-zero = the u32 duplicate offsets overflowed)
     if (copy_count)
       e = hipMemcpyAsync(out->num_rendered_host, c.num_rendered + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);

@@ -217,7 +217,8 @@ hipError_t dgs_launch_sort(uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, u
 hipError_t dgs_launch_duplicate_sorted(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t* tt_sorted,
                                        uint32_t* offs_sorted, uint32_t* scan_tmp, uint32_t cap, hipStream_t s);
 hipError_t dgs_launch_cull_count(const DgsView& v, const DgsCarve& c, hipStream_t s);
-hipError_t dgs_launch_cull_offsets(const DgsView& v, const DgsCarve& c, uint32_t* total_tight, hipStream_t s);
+hipError_t dgs_launch_cull_offsets(const DgsView& v, const DgsCarve& c, uint32_t* total_tight, hipStream_t s,
+                                   bool counts_in_order = false);
 hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t cap,
                                       hipStream_t s);
 hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,
@@ -232,7 +233,8 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
                                 hipStream_t s);
 
 hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
-                                 uint32_t P, uint32_t* tmp, uint32_t* vis_dst, uint32_t* wide_flag, hipStream_t s);
+                                 uint32_t P, uint32_t* tmp, uint32_t* vis_dst, uint32_t* wide_flag, hipStream_t s,
+                                 const uint32_t* cnt_src = nullptr, uint32_t* cnt_dst = nullptr);
 size_t dgs_depth_sort_tmp_words(int K, uint32_t P);
 size_t dgs_scan_tmp_words(uint64_t n);
 size_t dgs_sort_tmp_words(uint64_t n);
