@@ -254,7 +254,7 @@ NCCL_PROTOS = {0: "LL", 1: "LL128", 2: "Simple"}
 def rccl_log_setup(rank):
     """"verify which algorithm RCCL picks".  BEFORE init_process_group (environment only, no exec): this rank's
     RCCL log (INFO; init, collective calls, the tuner's algorithm / protocol choices) goes to a file of its own, which
-    rank 0 parses after the run (parse_rccl_log).  Anything the caller already set wins."""
+    rank 0 parses after the run (parse_rccl_log).  A log level, subsystem list or file the caller already set wins."""
     if os.environ.get("DGS_DIST_BACKEND", "nccl") != "nccl" or os.environ.get("DGS_BENCH_NO_RCCL_LOG", "0") == "1":
         return None
     import tempfile
@@ -262,15 +262,18 @@ def rccl_log_setup(rank):
     d = os.path.join(tempfile.gettempdir(), f"dgs_rccl_{job}")
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, f"rank{rank}.log")
-    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):    # (the pool's image presets NCCL_DEBUG=VERSION)
+        os.environ["NCCL_DEBUG"] = "INFO"
     os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
     os.environ.setdefault("NCCL_DEBUG_FILE", path)
     return os.environ["NCCL_DEBUG_FILE"]
 
 
-def parse_rccl_log(path, max_lines=8):
+def parse_rccl_log(path, max_lines=10):
     """What the library said about itself: version, the rings / trees / channels it built, and -- per message size -- the
-    algorithm and protocol its tuner chose ("<n> Bytes -> Algo <a> proto <p> time <t>")."""
+    algorithm and protocol its tuner chose ("<n> Bytes -> Algo <a> proto <p> ...", numbers or names depending on the
+    release).  Checked against a log of this image's RCCL 2.26 (one rank: no tuning lines) and, for the tuning lines, a
+    log in NCCL's format (tests/test_host_logic.py)."""
     import re
     if not path or not os.path.exists(path):
         return None
@@ -279,13 +282,15 @@ def parse_rccl_log(path, max_lines=8):
     except OSError:
         return None
     out = {"file": path, "bytes_logged": len(text)}
-    m = re.search(r"\b(RCCL|NCCL) version ([^\n]+)", text)
+    m = re.search(r"\b(RCCL|NCCL) version\s*:?\s*([^\n]+)", text)
     if m:
         out["version"] = (m.group(1) + " " + m.group(2)).strip()[:120]
     chosen = {}
-    for nb, a, pr in re.findall(r"(\d+) Bytes -> Algo (\d+) proto (\d+)", text):
+    for nb, a, pr in re.findall(r"(\d+) Bytes -> Algo (\w+) proto (\w+)", text):
         key = int(nb)
-        name = f"{NCCL_ALGOS.get(int(a), a)}/{NCCL_PROTOS.get(int(pr), pr)}"
+        an = NCCL_ALGOS.get(int(a), a) if a.isdigit() else a.capitalize()
+        pn = NCCL_PROTOS.get(int(pr), pr) if pr.isdigit() else {"SIMPLE": "Simple"}.get(pr.upper(), pr.upper())
+        name = f"{an}/{pn}"
         chosen.setdefault(key, {})
         chosen[key][name] = chosen[key].get(name, 0) + 1
     if chosen:      # the largest messages are the gradient bucket (or its chunks)
@@ -295,12 +300,15 @@ def parse_rccl_log(path, max_lines=8):
         calls[name] = calls.get(name, 0) + 1
     if calls:
         out["calls_logged"] = calls
-    topo = [ln.strip()[-200:] for ln in text.splitlines()
-            if re.search(r"Init COMPLETE|Channel \d+/\d+ *:|\bRing \d+ *:|Trees? \[|nRanks \d+|via P2P|threadThresholds|"
-                         r"channels? per|Connected all (rings|trees)", ln)]
+    lines = text.splitlines()
+    pick = lambda rx, n: [ln.strip()[-200:] for ln in lines if re.search(rx, ln)][:n]
+    chan = re.findall(r"Channel \d+/(\d+) *:", text)
+    if chan:
+        out["channels"] = int(chan[0])
+    topo = (pick(r"nRanks \d+", 1) + pick(r"Init COMPLETE", 1) + pick(r"Connected all (rings|trees)", 2) +
+            pick(r"\bRing \d+ *:", 2) + pick(r"Trees? \[", 1) + pick(r"Channel \d+/\d+ *:", 2) + pick(r"via P2P|P2P/IPC|P2P/direct", 2))
     if topo:
         out["init_lines"] = topo[:max_lines]
-        out["init_lines_total"] = len(topo)
     return out
 
 
@@ -331,7 +339,7 @@ def run_rank(args):
                           DGS_DIST_FORCE_INIT="1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rccl_log = None
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or emu is not None:
         rccl_log = rccl_log_setup(int(os.environ.get("RANK", "0")))
     rank, world_env, local_rank = sharding.init_distributed("cuda")
     world = dist.get_world_size() if dist.is_initialized() else 1
@@ -687,6 +695,7 @@ def run_rank(args):
                                          "ms_per_step": round(ms_per_step, 3), "steps": args.steps,
                                          "graph": graph_info,
                                          "eager_ms_per_step": None if graph_info is None else graph_info.get("eager_ms_per_step"),
+                                         "rccl": parse_rccl_log(rccl_log),
                                          "bucket_bytes": 4 * sum(p.numel() for p in params),
                                          "blur_bytes": 12 * H * W,
                                          "note": "one rank's launches between its exchanges (one-rank process group on the "
@@ -730,10 +739,23 @@ def run_rank(args):
                 result["cpu_baseline_torch_naive"] = cpu_baseline_torch_naive(scene, K // 2)
             except Exception as ex:     # never lose the headline line to the secondary baseline
                 result["cpu_baseline_torch_naive"] = {"error": repr(ex)}
-        print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
+        final_line = json.dumps(result)
+    else:
+        final_line = None
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
+    # The one JSON line goes out LAST: the collective library prints a version banner of its own through C stdio (block-
+    # buffered when stdout is a pipe, flushed at exit), which would otherwise land behind the line in rank 0's output.
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stderr.flush()
+    if final_line is not None:
+        print(final_line, flush=True)
 
 
 def main():

@@ -198,14 +198,22 @@ class TrainingLoop:
             out = self._step_graph(iteration, cam_idx, subframe_indice, lambda_t_smooth, gt, bg_host, uni_host)
             if out is not None:
                 return out
-        bg = bg_host.to(dev)
-        uniform = None if uni_host is None else uni_host.to(dev)
+        # The draws as device tensors, only where a device tensor is needed (the shared draws of a "subframes" step, the
+        # eager step): a copy from PAGEABLE host memory blocks the host until the stream has drained -- twice per step it
+        # kept the host from running ahead of a sharded run, whose ~60 eager launches per step then sat on the device's
+        # timeline (0.6 ms of an 11.5 ms step, bench.py --emulate-shard) -- so they go through pinned memory, asynchronously.
+        def draws_on_device():
+            b = bg_host.pin_memory().to(dev, non_blocking=True)
+            u = None if uni_host is None else uni_host.pin_memory().to(dev, non_blocking=True)
+            return b, u
+        bg, uniform = None, None
         shard = None
         if self.distributed:
             self._drain_dist_flags(lag=2)
         if self.mode == "subframes":
             import torch.distributed as dist
             shard = self.emulate_shard or (dist.get_rank(), dist.get_world_size())
+            bg, uniform = draws_on_device()
             bg, uniform = self._shared_draws(bg, uniform)
         ar = None
         if self.distributed and self.ar_chunks > 1:      # the bucket is reduced inside run(), chunk by chunk
@@ -238,6 +246,8 @@ class TrainingLoop:
                 self._front_failed = True
                 fr = None
         if fr is None:
+            if bg is None:
+                bg, uniform = draws_on_device()
             fr = self._fused.run(cam_idx, lambda_t_smooth, gt, bg, subframe_indice, uniform=uniform,
                                  lambda_depth_tv=max(float(self.opt.lambda_depth_tv), 0.0), shard=shard, exact=exact,
                                  ar=ar, stats=stats)
@@ -261,7 +271,14 @@ class TrainingLoop:
                 # -- the bias-correction exponent, the value stored in checkpoints -- count applied updates only and stay
                 # identical on all replicas.
                 h = self._flag_words.pop() if self._flag_words else torch.zeros(1, dtype=torch.int32).pin_memory()
-                h.copy_(flag[:1], non_blocking=True)
+                if flag.is_cuda:     # by a kernel: an asynchronous copy is a hand-over to the copy engine
+                    import ctypes
+                    from . import _lib
+                    _lib.check(_lib.lib().dgs_copy_words(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(flag.data_ptr()), 1,
+                                                         ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                               "dgs_copy_words")
+                else:
+                    h.copy_(flag[:1], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(dev))
                 self._dist_flags.append((h, ev, flag))

@@ -365,7 +365,15 @@ def test_rccl_log_parser_reads_version_algorithm_and_topology(tmp_path):
     assert got["algo_proto_by_message_bytes"]["152000000"] == {"Ring/Simple": 2}
     assert got["algo_proto_by_message_bytes"]["4"] == {"Tree/LL": 1}
     assert got["calls_logged"] == {"AllReduce": 2}
-    assert any("Init COMPLETE" in ln for ln in got["init_lines"]) and got["init_lines_total"] >= 5
+    assert any("Init COMPLETE" in ln for ln in got["init_lines"]) and got["channels"] == 16
+    # the image's RCCL 2.26 writes the banner as "RCCL version : <x>" and (newer NCCL) the tuner's choice by name
+    log.write_text("runc:227:227 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6\nHIP version  : 7.0\n"
+                   "runc:227:227 [0] NCCL INFO AllReduce: 38000000 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..15}\n"
+                   "runc:227:227 [0] NCCL INFO AllReduce: opCount 0 sendbuff 0x7 recvbuff 0x7 count 75264 datatype 7 op 4 root 0 "
+                   "comm 0x65 [nranks=8] stream 0x65 task 0 globalrank 0\n")
+    got2 = bench.parse_rccl_log(str(log))
+    assert got2["version"] == "RCCL 2.26.6-HEAD:64f48b6" and got2["calls_logged"] == {"AllReduce": 1}
+    assert got2["algo_proto_by_message_bytes"] == {"38000000": {"Ring/Simple": 1}}
     assert bench.parse_rccl_log(str(tmp_path / "missing.log")) is None
     # a rank only redirects its log for the real backend
     keep = {k: os.environ.get(k) for k in ("DGS_DIST_BACKEND", "NCCL_DEBUG", "NCCL_DEBUG_FILE", "NCCL_DEBUG_SUBSYS")}

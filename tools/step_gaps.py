@@ -2,7 +2,7 @@
 every kernel) of a bench.py run, cuts it into steps at a marker kernel, and prints per step the span, the busy time (union
 of the kernels' intervals), the idle time, and the largest gaps with the kernels on either side.
 
-    rocprofv3 --kernel-trace -d out -o t --output-format csv -- python3 bench.py --steps 20 ... ;  python tools/step_gaps.py out
+    rocprofv3 --kernel-trace -d out -o t --output-format csv -- python3 bench.py --steps 20 ... ;  python tools/step_gaps.py out [marker kernel] [first|last]
 """
 import collections
 import csv
@@ -22,7 +22,9 @@ def main():
     marker = sys.argv[2] if len(sys.argv) > 2 else "alignment_fwd_kernel"
     starts = [i for i, r in enumerate(rows) if r[2].startswith(marker)]
     steps = [(starts[i], starts[i + 1]) for i in range(len(starts) - 1)]
-    steps = steps[len(steps) // 2:][:8]                      # a few steps from the second half (the timed region)
+    # bench.py: warm-up, the timed (replayed) region, then a short eager region with stage timers: `part` picks where
+    part = sys.argv[3] if len(sys.argv) > 3 else "first"
+    steps = steps[len(steps) // 4:][:10] if part == "first" else steps[-12:-2]
     agg = collections.Counter()
     tot = collections.Counter()
     for a, b in steps:
