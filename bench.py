@@ -507,10 +507,10 @@ def run_rank(args):
     # the same step on the reference's duplicate lists (tile_cull = 0: sort keys / point lists bit-identical to the
     # reference's), reported beside the headline value
     # ---- N > 1 only: what makes ONE multi-GPU run decisive -- the other sharding mode's value and a
-    # collective-vs-point-to-point A/B of the gradient bucket's all-reduce, in the same invocation on the same ranks
-    extras = None
-    if world > 1 and not args.no_extras and not args.autograd_path:
-        extras = {}
+    # collective-vs-point-to-point A/B of the gradient bucket's all-reduce, in the same invocation on the same ranks.
+    # They run AFTER rank 0 has assembled the headline's result and under a watchdog: should an extra region never return
+    # (a collective path that has never met this node's RCCL), the line still goes out with the headline in it.
+    def run_extras(extras):
         if rank == 0:   # for the record, should an extra region never return: the headline region's figures, on stderr
             print(json.dumps({"headline_before_extras": {
                 "n_gpus": world, "sharding": args.shard, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -682,8 +682,6 @@ def run_rank(args):
             result["value_reference_lists"] = ref_lists
         if per_rank is not None:
             result["config"]["per_rank"] = per_rank
-        if extras is not None:
-            result["extras"] = extras
         if world > 1:
             result["config"]["rccl"] = parse_rccl_log(rccl_log)
             result["config"]["backend"] = dist.get_backend()
@@ -739,9 +737,32 @@ def run_rank(args):
                 result["cpu_baseline_torch_naive"] = cpu_baseline_torch_naive(scene, K // 2)
             except Exception as ex:     # never lose the headline line to the secondary baseline
                 result["cpu_baseline_torch_naive"] = {"error": repr(ex)}
-        final_line = json.dumps(result)
     else:
-        final_line = None
+        result = None
+    hung = False
+    if world > 1 and not args.no_extras and not args.autograd_path:
+        import threading
+        extras = {}
+
+        def guarded():
+            torch.cuda.set_device(local_rank)
+            run_extras(extras)
+        th = threading.Thread(target=guarded, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("DGS_BENCH_EXTRAS_TIMEOUT_S", "300")))
+        hung = th.is_alive()
+        if hung:
+            extras = dict(extras, error="an extra region did not return within DGS_BENCH_EXTRAS_TIMEOUT_S; the headline "
+                                        "figures above were measured before it started")
+        if result is not None:
+            result["extras"] = extras
+            result["config"]["rccl"] = parse_rccl_log(rccl_log)      # (again: now with the extra regions' collectives)
+    final_line = json.dumps(result) if result is not None else None
+    if hung:    # the process group is wedged: no barrier, no destroy -- say what was measured and leave
+        sys.stderr.flush()
+        if final_line is not None:
+            print(final_line, flush=True)
+        os._exit(0)
     if dist.is_initialized():
         if world > 1:
             dist.barrier()

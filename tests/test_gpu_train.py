@@ -1210,3 +1210,18 @@ def test_emulated_shard_slice_of_the_bench(gpu):
         assert got[mode]["world"] == 4 and got[mode]["rank"] == 1 and got[mode]["ms_per_step"] > 0
     assert got["subframes"]["subframes_of_this_rank"] == 2 and got["views"]["subframes_of_this_rank"] == 9   # K = 9: [2, 4)
     assert got["subframes"]["ms_per_step"] < got["views"]["ms_per_step"]
+
+
+def test_bench_line_survives_an_extra_region_that_never_returns(gpu):
+    """The regions behind the headline one (other sharding mode, all-reduce A/B) run under a watchdog AFTER rank 0 has
+    assembled the headline's result: with the watchdog's patience set to (almost) nothing the line must still come out,
+    carry the headline figures and say that the extras were cut short; every rank leaves with exit code 0."""
+    import json
+    import os
+    import sys
+    root, tool, env = _two_rank_env(DGS_BENCH_EXTRAS_TIMEOUT_S="0.01")
+    out = _run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "cfg2", "--steps", "3",
+                "--warmup", "1", "--no-cpu-baseline"], env)
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["per_rank"] is not None
+    assert "did not return" in line["extras"].get("error", ""), line["extras"]
