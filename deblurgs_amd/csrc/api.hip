@@ -601,7 +601,8 @@ static hipError_t launch_depth_order(const DgsProblem* p, const DgsCarve& c, hip
   // (status word [6]: "a visible depth key needs more than 27 bits", zeroed with the other status words before preprocess)
   return dgs_launch_depth_sort(c.gsort_keys, c.gsort_keys_alt, c.gsort_vals, c.gsort_vals_alt, p->K, (uint32_t)p->P,
                                c.gsort_tmp, cull ? c.tt_sorted : nullptr, c.num_rendered + 6, s,
-                               carry_counts ? c.cull_cnt : nullptr, carry_counts ? c.tt_tight : nullptr);
+                               carry_counts ? c.cull_cnt : nullptr, carry_counts ? c.tt_tight : nullptr,
+                               /* drop_invisible = */ cull);
 }
 
 // tile_cull: per-slot test in natural order (independent of the depth order), then records and counts into depth order and

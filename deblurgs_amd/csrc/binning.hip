@@ -990,7 +990,10 @@ static_assert(DS_TILE <= 65535, "per-wave digit counts are kept in 16 bits");
 // pass: 0..2 the 9-bit digits, 3 the optional pass on bits [27, 32) (returns unless *wide_flag)
 __global__ void __launch_bounds__(DS_THREADS)
 dsort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t P, uint32_t nb, int pass, uint32_t* __restrict__ table,
-                  uint32_t* __restrict__ wide_flag) {
+                  uint32_t* __restrict__ wide_flag, const uint32_t* __restrict__ segcnt) {
+  // segcnt (tile_cull; round 5): the first pass DROPS the invisible pairs (22 % at the metric configuration: they only
+  // ever sorted to the end of their segment) -- it counts and scatters the visible ones alone and leaves their number per
+  // segment in segcnt[k]; the later passes work on the first segcnt[k] pairs of every segment
   if (pass == 3 && *wide_flag == 0u) return;
   __shared__ uint32_t h[DS_BINS];
   for (int i = threadIdx.x; i < DS_BINS; i += DS_THREADS) h[i] = 0;
@@ -998,13 +1001,15 @@ dsort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t P, uint32_t nb, in
   const int shift = DS_RB * pass;
   const uint32_t k = blockIdx.x / nb, b = blockIdx.x - k * nb;
   const uint32_t* seg = keys + (size_t)k * P;
+  const uint32_t Pk = (segcnt != nullptr && pass > 0) ? segcnt[k] : P;
   const int lane = dgs_lane();
   bool wide = false;
 #pragma unroll 4
   for (int r = 0; r < DS_ITEMS; r++) {
     const uint32_t i = b * DS_TILE + (uint32_t)r * DS_THREADS + threadIdx.x;
-    const bool valid = i < P;
+    bool valid = i < Pk;
     const uint32_t key = valid ? seg[i] : 0u;
+    if (segcnt != nullptr && pass == 0) valid = valid && key != DS_INVISIBLE;
     const uint32_t d = (key >> shift) & (uint32_t)(DS_BINS - 1);
     if (pass == 0) wide = wide || (valid && key != DS_INVISIBLE && key >= DS_NARROW_MAX);
     // the upper digits of depth keys take few values, and after the earlier passes a wave's 64 keys often share theirs:
@@ -1028,7 +1033,8 @@ dsort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t P, uint32_t nb, in
 // the segment, so the digit bases are formed right here and the top kernel is not launched
 __global__ void __launch_bounds__(DS_BINS)
 dsort_colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nb, uint32_t nch, uint32_t* __restrict__ ctot,
-                           int fuse_top, uint32_t P, int pass, const uint32_t* __restrict__ wide_flag) {
+                           int fuse_top, uint32_t P, int pass, const uint32_t* __restrict__ wide_flag,
+                           uint32_t* __restrict__ segcnt) {
   if (pass == 3 && *wide_flag == 0u) return;
   __shared__ uint32_t lds[DS_BINS / 64];
   const uint32_t k = blockIdx.x / nch, c = blockIdx.x - k * nch;
@@ -1049,6 +1055,7 @@ dsort_colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nb, uint32_t n
   if (fuse_top) {
     uint32_t tot;
     run = block_excl_scan_n<DS_BINS>(run, &tot, lds) + k * P;   // (what dsort_colscan_top_kernel leaves for the only chunk)
+    if (segcnt != nullptr && pass == 0 && threadIdx.x == 0) segcnt[k] = tot;   // the segment's visible pairs
   }
   ctot[(size_t)blockIdx.x * DS_BINS + threadIdx.x] = run;
 }
@@ -1056,7 +1063,7 @@ dsort_colscan_chunk_kernel(uint32_t* __restrict__ table, uint32_t nb, uint32_t n
 // segment k: chunk totals -> exclusive chunk bases per digit, plus the digit's base inside the segment and k * P
 __global__ void __launch_bounds__(DS_BINS)
 dsort_colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nch, uint32_t P, int pass,
-                         const uint32_t* __restrict__ wide_flag) {
+                         const uint32_t* __restrict__ wide_flag, uint32_t* __restrict__ segcnt) {
   if (pass == 3 && *wide_flag == 0u) return;
   __shared__ uint32_t lds[DS_BINS / 64];
   uint32_t* base = ctot + ((size_t)blockIdx.x * nch) * DS_BINS + threadIdx.x;
@@ -1068,6 +1075,7 @@ dsort_colscan_top_kernel(uint32_t* __restrict__ ctot, uint32_t nch, uint32_t P, 
   }
   uint32_t tot;
   const uint32_t pre = block_excl_scan_n<DS_BINS>(run, &tot, lds) + blockIdx.x * P;
+  if (segcnt != nullptr && pass == 0 && threadIdx.x == 0) segcnt[blockIdx.x] = tot;   // the segment's visible pairs
   for (uint32_t c = 0; c < nch; c++) base[(size_t)c * DS_BINS] += pre;
 }
 
@@ -1079,7 +1087,8 @@ dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t P, uint32_t nb,
                      uint32_t nch, const uint32_t* __restrict__ table, const uint32_t* __restrict__ ctot,
                      uint32_t* __restrict__ vis_dst, const uint32_t* __restrict__ wide_flag,
-                     const uint32_t* __restrict__ cnt_src, uint32_t* __restrict__ cnt_dst) {
+                     const uint32_t* __restrict__ cnt_src, uint32_t* __restrict__ cnt_dst,
+                     const uint32_t* __restrict__ segcnt) {
   // cnt_src / cnt_dst (tile_cull, K * P <= 2^24; round 5): a per-pair payload -- the surviving-tile count cull_count_kernel
   // left in NATURAL order -- rides in the top byte of the 32-bit value through all passes (the flat index needs 24 bits;
   // 255 = "look the count up", for the few pairs with more tiles) and is laid out in the final order by the last pass,
@@ -1098,6 +1107,21 @@ dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   __shared__ uint32_t s_scan[DS_THREADS / 64];
   const int lane = dgs_lane(), w = threadIdx.x >> 6;
   const uint32_t k = blockIdx.x / nb, b = blockIdx.x - k * nb;
+  // segcnt: the invisible pairs were dropped by the first pass (see dsort_hist_kernel): this pass sees the segment's first
+  // Pk pairs; the last pass clears the flags and counts of the positions behind them (their indices stay undefined:
+  // no consumer reads the index of a pair whose flag is 0)
+  const bool drop = segcnt != nullptr;
+  const uint32_t Pk = (drop && !FIRST) ? segcnt[k] : P;
+  if (drop && !FIRST) {
+    const uint32_t t0 = b * DS_TILE, t1 = min(t0 + (uint32_t)DS_TILE, P);
+    if (last && t1 > Pk) {   // (block-uniform)
+      for (uint32_t i = max(t0, Pk) + threadIdx.x; i < t1; i += DS_THREADS) {
+        if (vis_dst != nullptr) vis_dst[(size_t)k * P + i] = 0u;
+        if (cnt_dst != nullptr) cnt_dst[(size_t)k * P + i] = 0u;
+      }
+    }
+    if (t0 >= Pk) return;   // nothing of this block is left (block-uniform, before any barrier)
+  }
 #pragma unroll
   for (int i = 0; i < DS_BINS / 64; i++) whist[w][lane + 64 * i] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1111,17 +1135,27 @@ dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
 #pragma unroll
   for (int r = 0; r < DS_ITEMS; r++) {
     const uint32_t i = wbase + (uint32_t)r * 64 + lane;
-    const bool valid = i < P;
+    const bool valid = i < Pk;
     key[r] = valid ? keys_in[sbase + i] : DS_INVISIBLE;
     val[r] = FIRST ? (uint32_t)(sbase + i) : (valid ? vals_in[sbase + i] : 0u);
-    if (FIRST && cnt_src != nullptr) {
-      const uint32_t cn = (valid && key[r] != DS_INVISIBLE) ? cnt_src[sbase + i] : 0u;
-      val[r] |= (cn < 255u ? cn : 255u) << 24;
+  }
+  if (FIRST && cnt_src != nullptr) {
+    // the payload: loaded for every pair, whatever its key says (an invisible pair's count is 0 by construction:
+    // cull_count_kernel) -- a load that waits for the key to decide whether it is needed turns the sixteen rounds into
+    // sixteen dependent round trips (134 instead of 75 us for this pass)
+    uint32_t cn[DS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < DS_ITEMS; r++) {
+      const uint32_t i = wbase + (uint32_t)r * 64 + lane;
+      cn[r] = (i < Pk) ? cnt_src[sbase + i] : 0u;
     }
+#pragma unroll
+    for (int r = 0; r < DS_ITEMS; r++) val[r] |= (cn[r] < 255u ? cn[r] : 255u) << 24;
   }
 #pragma unroll
   for (int r = 0; r < DS_ITEMS; r++) {
-    const bool valid = (wbase + (uint32_t)r * 64 + lane) < P;
+    // (first pass with `drop`: an invisible pair takes no part -- it gets no rank and no slot)
+    const bool valid = (wbase + (uint32_t)r * 64 + lane) < Pk && !(drop && FIRST && key[r] == DS_INVISIBLE);
     const uint32_t d = (key[r] >> shift) & (uint32_t)(DS_BINS - 1);
     uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -1172,7 +1206,7 @@ dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < DS_ITEMS; r++) {
-    if ((wbase + (uint32_t)r * 64 + lane) < P) {
+    if ((wbase + (uint32_t)r * 64 + lane) < Pk && !(drop && FIRST && key[r] == DS_INVISIBLE)) {
       const uint32_t d = (key[r] >> shift) & (uint32_t)(DS_BINS - 1);
       const uint32_t slot = (uint32_t)whist[w][d] + rank[r];
       lds_k[slot] = key[r];
@@ -1180,7 +1214,9 @@ dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __res
     }
   }
   __syncthreads();
-  const uint32_t nvalid = min((uint32_t)DS_TILE, P - b * DS_TILE);
+  // pairs of this block that take part: all of it, what the segment's visible count leaves of it, or (first pass with
+  // `drop`) its visible pairs = the block total of the digit counts
+  const uint32_t nvalid = (drop && FIRST) ? tot : min((uint32_t)DS_TILE, Pk - b * DS_TILE);
 #pragma unroll
   for (int r = 0; r < DS_ITEMS; r++) {
     const uint32_t i = (uint32_t)r * DS_THREADS + threadIdx.x;
@@ -1388,13 +1424,16 @@ size_t dgs_depth_sort_tmp_words(int K, uint32_t P) {
 // fourth): the result always lands in `order`.  wide_flag: one device word, zero on entry.
 hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
                                  uint32_t P, uint32_t* tmp, uint32_t* vis_dst, uint32_t* wide_flag, hipStream_t s,
-                                 const uint32_t* cnt_src, uint32_t* cnt_dst) {
+                                 const uint32_t* cnt_src, uint32_t* cnt_dst, bool drop_invisible) {
   if (K <= 0 || P == 0) return hipSuccess;
+  if (drop_invisible && (vis_dst == nullptr || K > 128)) return hipErrorInvalidValue;
   if (cnt_src != nullptr && ((uint64_t)K * P > (1ull << 24) || cnt_dst == nullptr)) return hipErrorInvalidValue;
   const uint32_t nb = (P + DS_TILE - 1) / DS_TILE;
   const uint32_t nch = (nb + DS_CHUNK - 1) / DS_CHUNK;
   uint32_t* table = tmp;
   uint32_t* ctot = tmp + (size_t)K * nb * DS_BINS;
+  // per-segment visible counts (drop_invisible): in the slack words behind the two tables
+  uint32_t* segcnt = drop_invisible ? tmp + (size_t)K * (nb + nch) * DS_BINS + 64 : nullptr;
   const dim3 grid((uint32_t)K * nb), cgrid((uint32_t)K * nch);
   // buffers A = (keys, order), B = (keys_alt, order_alt):
   //   pass 0  A.keys          -> B.keys, A.order        pass 1  B.keys, A.order -> A.keys, B.order
@@ -1404,14 +1443,15 @@ hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* o
     uint32_t* kout = (pass & 1) ? keys : keys_alt;
     const uint32_t* vin = (pass & 1) ? order : order_alt;
     uint32_t* vout = (pass & 1) ? order_alt : order;
-    hipLaunchKernelGGL(dsort_hist_kernel, grid, dim3(DS_THREADS), 0, s, kin, P, nb, pass, table, wide_flag);
+    hipLaunchKernelGGL(dsort_hist_kernel, grid, dim3(DS_THREADS), 0, s, kin, P, nb, pass, table, wide_flag, segcnt);
     hipLaunchKernelGGL(dsort_colscan_chunk_kernel, cgrid, dim3(DS_BINS), 0, s, table, nb, nch, ctot, nch == 1 ? 1 : 0, P,
-                       pass, wide_flag);
+                       pass, wide_flag, segcnt);
     if (nch > 1)
-      hipLaunchKernelGGL(dsort_colscan_top_kernel, dim3((uint32_t)K), dim3(DS_BINS), 0, s, ctot, nch, P, pass, wide_flag);
+      hipLaunchKernelGGL(dsort_colscan_top_kernel, dim3((uint32_t)K), dim3(DS_BINS), 0, s, ctot, nch, P, pass, wide_flag,
+                         segcnt);
 #define DGS_DS_SCATTER(PASS_)                                                                                         \
   hipLaunchKernelGGL((dsort_scatter_kernel<PASS_>), grid, dim3(DS_THREADS), 0, s, kin, vin, kout, vout, P, nb, nch, table, \
-                     ctot, vis_dst, wide_flag, cnt_src, cnt_dst)
+                     ctot, vis_dst, wide_flag, cnt_src, cnt_dst, segcnt)
     if (pass == 0) DGS_DS_SCATTER(0);
     else if (pass == 1) DGS_DS_SCATTER(1);
     else if (pass == 2) DGS_DS_SCATTER(2);

@@ -234,7 +234,8 @@ hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C,
 
 hipError_t dgs_launch_depth_sort(uint32_t* keys, uint32_t* keys_alt, uint32_t* order, uint32_t* order_alt, int K,
                                  uint32_t P, uint32_t* tmp, uint32_t* vis_dst, uint32_t* wide_flag, hipStream_t s,
-                                 const uint32_t* cnt_src = nullptr, uint32_t* cnt_dst = nullptr);
+                                 const uint32_t* cnt_src = nullptr, uint32_t* cnt_dst = nullptr,
+                                 bool drop_invisible = false);
 size_t dgs_depth_sort_tmp_words(int K, uint32_t P);
 size_t dgs_scan_tmp_words(uint64_t n);
 size_t dgs_sort_tmp_words(uint64_t n);

@@ -172,7 +172,9 @@ typedef struct DgsLayout {
                           * (tile_cull = 1), [4] the count the lists were built with, [5] overflow flag (capacity mode) */
   size_t gsort_keys;     /* u32 [K,P] bits(depth) - bits(0.2f) (0xFFFFFFFF = invisible): keys of the segmented depth sort */
   size_t gsort_keys_alt; /* u32 [K,P] its ping-pong buffer */
-  size_t gsort_vals;     /* u32 [K*P] flat (k, Gaussian) indices in (k, depth, index) order (the sort's result) */
+  size_t gsort_vals;     /* u32 [K*P] flat (k, Gaussian) indices in (k, depth, index) order (the sort's result).  tile_cull = 1:
+                          * the invisible pairs are dropped by the first sort pass -- every subframe's segment holds its
+                          * visible pairs first (tt_sorted = 1) and UNDEFINED indices behind them (tt_sorted = 0) */
   size_t gsort_vals_alt; /* u32 [K*P] */
   size_t tt_sorted;      /* u32 [K*P] tiles_touched in (k, depth, index) order (tile_cull: 1 / 0 = visible / not) */
   size_t offs_sorted;    /* u32 [K*P] its exclusive prefix sum (tile_cull = 0 only) */

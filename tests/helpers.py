@@ -159,6 +159,9 @@ def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_p
         tiles_touched=view(geom, L.tiles_touched, K * P * 4, np.uint32, (K, P)),
         point_offsets=view(geom, L.point_offsets, K * P * 4, np.uint32, (K, P)),
         order=view(geom, L.gsort_vals, K * P * 4, np.uint32, (K * P,)),
+        # tile_cull: 1 / 0 per position of the depth order = a visible pair sits there (the invisible pairs are dropped by
+        # the first depth-order pass: the tail of every segment has flag 0 and an UNDEFINED index)
+        order_visible=view(geom, L.tt_sorted, K * P * 4, np.uint32, (K * P,)) != 0,
         tt_tight=view(geom, L.tt_tight, K * P * 4, np.uint32, (K * P,)),
         offs_tight=view(geom, L.offs_tight, K * P * 4, np.uint32, (K * P,)),
         final_T=view(image, L.final_T, K * N * 4, np.float32, (K, N)),

@@ -383,14 +383,21 @@ def test_tile_cull_lists_are_the_contributing_subset(gpu, seed, sigma):
     u = (cul["keys"] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     assert np.array_equal(np.sort(u), np.arange(cul["R"]))
     # first contribution row of every pair, by natural index: offs_tight is laid out in (k, depth, index) order
+    vis = cul["order_visible"]            # (positions behind a segment's visible pairs: flag 0, index undefined)
+    assert vis.sum() == int((cul["radii"] > 0).sum()) and not cul["tt_tight"][~vis].any()
+    for k in range(K):                  # the visible pairs come first in every segment
+        seg = vis[k * P:(k + 1) * P]
+        assert not seg[int(seg.sum()):].any()
+    order_v = cul["order"][vis].astype(np.int64)
+    assert np.array_equal(np.sort(order_v), np.nonzero((cul["radii"] > 0).reshape(-1))[0])
     flat_off = np.zeros(K * P, np.int64)
-    flat_off[cul["order"].astype(np.int64)] = cul["offs_tight"].astype(np.int64)
+    flat_off[order_v] = cul["offs_tight"][vis].astype(np.int64)
     gi = (cul["keys"] >> np.uint64(32)).astype(np.int64) // cul["T"] * P + cul["point_list"]
     doff = flat_off[gi]
     cnt = np.bincount(gi, minlength=K * P)
     assert np.all((u >= doff) & (u < doff + cnt[gi])), "contribution-row slot inside the pair's segment"
     tight_nat = np.zeros(K * P, np.int64)
-    tight_nat[cul["order"].astype(np.int64)] = cul["tt_tight"].astype(np.int64)
+    tight_nat[order_v] = cul["tt_tight"][vis].astype(np.int64)
     assert np.array_equal(tight_nat, cnt), "surviving-tile counts per pair"
     rng = cul["ranges"].reshape(-1, 2).astype(np.int64)
     assert np.array_equal(rng[:, 1] - rng[:, 0], np.bincount((cul["keys"] >> np.uint64(32)).astype(np.int64),
@@ -493,8 +500,9 @@ def test_capacity_mode_builds_the_same_lists(gpu, P, W, H, K, sigma):
     for cap in (R + 1000, max(R, 1)):
         b = hip_forward_state(sc, K, cull=True, capacity=cap)
         assert b["R"] == R and b["counted"] == R and not b["overflow"]
-        for key in ("tt_tight", "offs_tight", "order", "radii", "ranges", "color", "depth", "n_contrib", "final_T"):
+        for key in ("tt_tight", "offs_tight", "order_visible", "radii", "ranges", "color", "depth", "n_contrib", "final_T"):
             assert np.array_equal(a[key], b[key]), (key, cap)
+        assert np.array_equal(a["order"][a["order_visible"]], b["order"][b["order_visible"]]), cap
         assert np.array_equal(a["keys"], b["keys"][:R]) and np.array_equal(a["point_list"], b["point_list"][:R])
     if R > 1:
         c = hip_forward_state(sc, K, cull=True, capacity=R - 1)
