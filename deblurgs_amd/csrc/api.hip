@@ -783,6 +783,100 @@ static int forward_capacity_impl(const DgsProblem* p, const DgsForwardOut* out, 
   return forward_render_impl(p, out, capacity, true, s, phases);
 }
 
+// ---- the compositing backward in parts, each part's row totals next to the next part's compositing
+// composite_bwd is bound by VALU issue and the LDS, contrib_reduce by scattered HBM writes: side by side they share the
+// device well.  The subframes are cut into (up to) three parts; their compositing kernels run back to back on the
+// caller's stream, and the row totals of every part but the last run on a side stream owned by the library, each as soon as
+// its part's compositing is done; the caller's stream waits for the side stream before the last part's totals, so all of
+// the call's work is ordered before whatever the caller enqueues next (and a stream capture picks the side stream up
+// through the event wait, like any forked capture).  The kernels and every sum are the ones of the single launch:
+// bit-identical results (tools/grad_hash.py).  Measured at the metric configuration: -0.15 ms of 10.8.
+// DGS_BWD_OVERLAP=0 turns it off, =2 forces it whatever the size (tests); DGS_BWD_PARTS="7,6" overrides the cut (subframes
+// per part, the rest = last part).
+constexpr int BWD_MAX_PARTS = 8;
+constexpr uint64_t BWD_OVERLAP_MIN_PAIRS = 4000000;   // below this the extra launches and events cost more than they hide
+
+static int bwd_overlap_mode() {
+  static const int mode = [] {
+    const char* e = getenv("DGS_BWD_OVERLAP");
+    return (e != nullptr) ? atoi(e) : 1;
+  }();
+  return mode;
+}
+
+struct SideStream {
+  bool ready = false;
+  hipStream_t s2 = nullptr;
+  hipEvent_t done[BWD_MAX_PARTS] = {}, join = nullptr;
+};
+static std::mutex g_side_mu;          // the enqueue sequence of one call is not interleaved with another thread's
+static hipError_t side_stream(SideStream** out) {
+  static SideStream st[16];
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+  SideStream& t = st[dev];
+  if (!t.ready) {
+    e = hipStreamCreateWithFlags(&t.s2, hipStreamNonBlocking);
+    for (int i = 0; i < BWD_MAX_PARTS && e == hipSuccess; i++) e = hipEventCreateWithFlags(&t.done[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t.join, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    t.ready = true;
+  }
+  *out = &t;
+  return hipSuccess;
+}
+
+// cut[0..n]: part i = subframes [cut[i], cut[i+1]).  Default for K >= 6: two near-equal parts and a short last one (its
+// totals are the only ones nothing runs next to): K = 15 -> 7, 6, 2
+static int bwd_parts(int K, int* cut, bool force) {
+  int n = 0;
+  cut[0] = 0;
+  const char* spec = getenv("DGS_BWD_PARTS");
+  if (spec != nullptr) {
+    const char* q = spec;
+    while (*q && n < BWD_MAX_PARTS - 1) {
+      const int len = atoi(q);
+      if (len <= 0 || cut[n] + len >= K) break;
+      cut[n + 1] = cut[n] + len;
+      n++;
+      while (*q && *q != ',') q++;
+      if (*q == ',') q++;
+    }
+  } else if (K >= 6) {
+    const int last = K / 8 + 1, rest = K - last;
+    cut[1] = (rest + 1) / 2;
+    cut[2] = rest;
+    n = 2;
+  } else if (force && K >= 2) {
+    cut[1] = (K + 1) / 2;
+    n = 1;
+  }
+  cut[++n] = K;
+  return n;
+}
+
+static hipError_t backward_composite_overlapped(const DgsProblem* p, const DgsBackwardIO* io, const DgsView& v, const DgsCarve& c,
+                                                float* contrib, float* sums, double* partials, hipStream_t s, const int* cut,
+                                                int n) {
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStream* st = nullptr;
+  hipError_t e = side_stream(&st);
+  for (int i = 0; i < n && e == hipSuccess; i++) {
+    e = dgs_launch_composite_bwd(v, c, p->bg, io->dL_dout_color, io->dL_dout_depth, contrib, s, cut[i], cut[i + 1]);
+    if (i + 1 < n) {
+      if (e == hipSuccess) e = hipEventRecord(st->done[i], s);
+      if (e == hipSuccess) e = hipStreamWaitEvent(st->s2, st->done[i], 0);
+      if (e == hipSuccess) e = dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, st->s2, 1, 0, 0, cut[i], cut[i + 1]);
+    }
+  }
+  if (e == hipSuccess) e = hipEventRecord(st->join, st->s2);
+  if (e == hipSuccess) e = hipStreamWaitEvent(s, st->join, 0);
+  if (e == hipSuccess) e = dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s, 1, 0, 0, cut[n - 1], cut[n]);
+  return e;
+}
+
 // which != 0: 1 = compositing backward + per-pair totals, 2 = per-Gaussian kernel for [g_begin, g_end), 4 = pose sums
 static int backward_impl(const DgsProblem* p, const DgsBackwardIO* io, int which, int32_t g_begin, int32_t g_end,
                          hipStream_t s) {
@@ -828,12 +922,21 @@ static int backward_impl(const DgsProblem* p, const DgsBackwardIO* io, int which
   float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(io->scratch) + up((size_t)R * DGS_CONTRIB_F * 4));
   double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(sums) +
                                                up((size_t)p->K * (size_t)p->P * DGS_SUMS_F * 4));
-  if (which & 1)
+  // (with the stage timers on -- dgs_profile_begin -- the two kernels run one after the other: their event pairs then time
+  // what they say; so does debug mode, which synchronises after every stage)
+  int cut[BWD_MAX_PARTS + 1], parts = 1;
+  if ((which & 1) && v.tile_cull && !p->debug && !g_prof.on && bwd_overlap_mode() != 0 &&
+      (R >= BWD_OVERLAP_MIN_PAIRS || bwd_overlap_mode() == 2))
+    parts = bwd_parts(p->K, cut, bwd_overlap_mode() == 2);
+  if (parts > 1) {
+    hipError_t e = backward_composite_overlapped(p, io, v, c, contrib, sums, partials, s, cut, parts);
+    if (e != hipSuccess) return fail_hip(e, "composite backward (parts)");
+  } else if (which & 1) {
     DGS_STAGE(DGS_STAGE_COMPOSITE_BWD, "composite backward",
               dgs_launch_composite_bwd(v, c, p->bg, io->dL_dout_color, io->dL_dout_depth, contrib, s));
-  if (which & 1)
     DGS_STAGE(DGS_STAGE_CONTRIB_REDUCE, "contribution-row totals",
               dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s, 1, 0, 0));
+  }
   if (which & 6)
     DGS_STAGE(DGS_STAGE_GEOMETRY_BWD, "geometry backward",
               dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s, which & 6, g_begin, g_end));

@@ -619,13 +619,25 @@ hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const f
   return hipGetLastError();
 }
 
-hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const float* bg, const float* dL_dpix,
-                                    const float* dL_ddepth, float* contrib, hipStream_t s) {
+hipError_t dgs_launch_composite_bwd(const DgsView& v_all, const DgsCarve& c, const float* bg, const float* dL_dpix,
+                                    const float* dL_ddepth, float* contrib, hipStream_t s, int k0, int k1) {
+  // subframes [k0, k1) of the view (k1 < 0: all of them): the kernel sees a view of k1 - k0 subframes whose per-subframe
+  // arrays start at subframe k0; list positions (ranges, keys, duplicate offsets, contribution rows) are absolute
+  if (k1 < 0) { k0 = 0; k1 = v_all.K; }
+  DgsView v = v_all;
+  v.K = k1 - k0;
+  const size_t N = (size_t)v.W * v.H;
   const uint32_t per = per_xcd_blocks(v);
   if (per == 0) return hipSuccess;
+  const uint2* ranges = c.ranges + (size_t)k0 * v.T;
+  const DgsRow* rows = c.rows + (size_t)k0 * v.P;
+  const float* final_T = c.final_T + (size_t)k0 * N;
+  const uint32_t* n_contrib = c.n_contrib + (size_t)k0 * N;
+  dL_dpix += (size_t)k0 * 3 * N;
+  if (dL_ddepth != nullptr) dL_ddepth += (size_t)k0 * N;
 #define DGS_CBWD(TI, HD)                                                                                            \
-  hipLaunchKernelGGL((composite_bwd_kernel<TI, HD>), dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list, \
-                     c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, dL_dpix, dL_ddepth, c.point_offsets, contrib)
+  hipLaunchKernelGGL((composite_bwd_kernel<TI, HD>), dim3(per * 8), dim3(64 * CW), 0, s, v, per, ranges, c.point_list, \
+                     c.keys_sorted, rows, bg, final_T, n_contrib, dL_dpix, dL_ddepth, c.point_offsets, contrib)
   if (v.tile_cull) {
     if (dL_ddepth != nullptr) DGS_CBWD(true, true); else DGS_CBWD(true, false);
   } else {

@@ -224,10 +224,10 @@ hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const
 hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,
                                     float* out_depth, hipStream_t s);
 hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const float* bg, const float* dL_dpix,
-                                    const float* dL_ddepth, float* contrib, hipStream_t s);
+                                    const float* dL_ddepth, float* contrib, hipStream_t s, int k0 = 0, int k1 = -1);
 hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const DgsCarve& c, const DgsBackwardIO& io,
                                    const float* contrib, float* sums, double* partials, hipStream_t s, int phases,
-                                   int g_begin, int g_end);
+                                   int g_begin, int g_end, int k0 = 0, int k1 = -1);
 hipError_t dgs_launch_blur_loss(const float* sub, const float* gt, int K, int C, int HW, float lambda_t,
                                 const float* lambda_dev, const float* scale, float* blur, float* dsub, float* losses,
                                 hipStream_t s);

@@ -739,7 +739,7 @@ int dgs_geometry_bwd_blocks(int P) { return (P + GB_THREADS - 1) / GB_THREADS; }
 // 4 = the final sum of the pose-gradient partials of ALL blocks (after every chunk has run)
 hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const DgsCarve& c, const DgsBackwardIO& io,
                                    const float* contrib, float* sums, double* partials, hipStream_t s, int phases,
-                                   int g_begin, int g_end) {
+                                   int g_begin, int g_end, int k0, int k1) {
   const int all_blocks = dgs_geometry_bwd_blocks(v.P);
   const size_t lds = (size_t)(GB_THREADS / 64) * v.K * NMAT * sizeof(float);
   const int ncoef = (p.shs != nullptr) ? (v.D + 1) * (v.D + 1) : 1;
@@ -748,10 +748,16 @@ hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const 
   // (that is the order the duplicates were laid out in)
   // (the depth order, tt_sorted / offs_sorted exist whenever a duplicate or -- with tile culling -- a visible pair does;
   // otherwise no pair is visible and the geometry kernel reads no total)
-  if ((phases & 1) && (io.num_rendered > 0 || v.tile_cull))
-    hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((4 * kp + 255) / 256)), dim3(256), 0, s, kp, c.num_rendered,
-                     c.gsort_vals, c.tt_sorted, v.tile_cull ? c.tt_tight : c.tt_sorted,
-                     v.tile_cull ? c.offs_tight : c.offs_sorted, contrib, sums);
+  // (phase 1 for subframes [k0, k1) only, k1 < 0 = all: the pairs of a subframe are one segment of the depth order, their
+  // totals go to absolute natural indices)
+  if ((phases & 1) && (io.num_rendered > 0 || v.tile_cull)) {
+    if (k1 < 0) { k0 = 0; k1 = v.K; }
+    const uint64_t j0 = (uint64_t)k0 * v.P, nj = (uint64_t)(k1 - k0) * v.P;
+    if (nj > 0)
+      hipLaunchKernelGGL(contrib_reduce_kernel, dim3((uint32_t)((4 * nj + 255) / 256)), dim3(256), 0, s, nj, c.num_rendered,
+                         c.gsort_vals + j0, c.tt_sorted + j0, (v.tile_cull ? c.tt_tight : c.tt_sorted) + j0,
+                         (v.tile_cull ? c.offs_tight : c.offs_sorted) + j0, contrib, sums);
+  }
   const int blocks = (g_end - g_begin + GB_THREADS - 1) / GB_THREADS;
 #define DGS_GB_LAUNCH(MAXC)                                                                                          \
   hipLaunchKernelGGL(geometry_bwd_kernel<MAXC>, dim3(blocks), dim3(GB_THREADS), lds, s, v, p.means3D, p.shs,         \

@@ -249,7 +249,11 @@ int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity
  * compositing of the lists the first call built: the VALU-bound half).  Same arguments as dgs_forward. */
 int dgs_forward_lists(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream);
 int dgs_forward_composite(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream);
-/* Replaces Rasterizer::backward (rasterizer_impl.cu:350-463). */
+/* Replaces Rasterizer::backward (rasterizer_impl.cu:350-463).
+ * For a large view (tile_cull, K >= 6, >= 4 M duplicates) the compositing backward runs in up to three parts of the
+ * subframes and the per-pair totals of every part but the last run on a side stream the library owns, forked from and
+ * joined back into `stream` inside the call (events): ordering on `stream` is unchanged, a stream capture includes the
+ * side stream, results are bit-identical.  Environment: DGS_BWD_OVERLAP=0 disables it. */
 int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream);
 /* dgs_backward in three parts, for callers that overlap the gradient all-reduce of a sharded run with the backward's
  * tail: dgs_backward_composite (compositing backward + per-(subframe, Gaussian) totals), then dgs_backward_geometry for

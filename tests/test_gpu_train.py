@@ -1225,3 +1225,32 @@ def test_bench_line_survives_an_extra_region_that_never_returns(gpu):
     line = json.loads([ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["per_rank"] is not None
     assert "did not return" in line["extras"].get("error", ""), line["extras"]
+
+
+def test_backward_in_parts_is_bit_identical_to_the_single_launch(gpu):
+    """csrc/api.hip cuts the compositing backward of a large view into parts and runs every part's row totals on a side
+    stream next to the next part's compositing.  Same kernels, same sums: every output of a forward + backward must have
+    the same bits with the feature off (DGS_BWD_OVERLAP=0), forced on for this small view (=2, default cut) and with an
+    explicit cut into four parts -- and a captured step must still equal the eager one when the backward forks inside the
+    capture.  Separate processes: the library reads the variables once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def hashes(**env):
+        e = dict(os.environ, **env)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "grad_hash.py"), "cfg2"], env=e, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if len(ln.split()) >= 2 and len(ln.split()[1]) == 24]
+        assert len(lines) >= 12, r.stdout
+        return lines
+
+    off = hashes(DGS_BWD_OVERLAP="0")
+    assert hashes(DGS_BWD_OVERLAP="2") == off
+    assert hashes(DGS_BWD_OVERLAP="2", DGS_BWD_PARTS="1,1,1") == off
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_train.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "graph_replay_equals_eager or captured_front_equals_the_eager"],
+                       env=dict(os.environ, DGS_BWD_OVERLAP="2"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:]

@@ -8,6 +8,10 @@ cd $root
 export TMPDIR=/tmp
 out=$root/gpurun_out/profiles_$rnd
 mkdir -p $out
+# every profiler pass runs the compositing backward as ONE launch per step (DGS_BWD_OVERLAP=0): the launch the bench line's
+# `roofline` is about; the replayed-step trace below is taken with the library's default (the backward in parts, each part's
+# row totals next to the next part's compositing: kernel durations then overlap and do not add up to the step)
+export DGS_BWD_OVERLAP=0
 B="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-reference-lists --no-graph"
 tools/valu_rate > $out/valu_classes_$rnd.txt 2>&1
 cp $out/valu_classes_$rnd.txt profiles/valu_classes_$rnd.txt
@@ -16,7 +20,7 @@ python3 profiles/make_valu_peak.py $out/valu_peak $out/valu_classes_$rnd.txt > p
 python3 tools/isa_census.py --json profiles/isa_census_$rnd.json > $out/isa_census.log 2>&1
 rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-reference-lists --no-graph > $out/trace.log 2>&1
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/${rnd}_kernel_stats.csv
-rocprofv3 --kernel-trace --stats -d $out/trace_graph -o trace --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-reference-lists > $out/trace_graph.log 2>&1
+DGS_BWD_OVERLAP=1 rocprofv3 --kernel-trace --stats -d $out/trace_graph -o trace --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-reference-lists > $out/trace_graph.log 2>&1
 cp $(find $out/trace_graph -name "*kernel_stats.csv" | head -1) $out/${rnd}_kernel_stats_graph_replay.csv
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -d $out/valu -o pmc --output-format csv -- $B > $out/valu.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -o pmc --output-format csv -- $B > $out/fetch.log 2>&1
@@ -25,4 +29,5 @@ R=$(grep -o '"R_total": [0-9]*' $out/valu.log | head -1 | grep -o '[0-9]*$')
 python3 profiles/make_valu.py $out/valu metric $rnd $R > $out/make_valu.log 2>&1
 python3 profiles/make_traffic.py $out/fetch $out/write metric $rnd > $out/make_traffic.log 2>&1
 cp profiles/valu_$rnd.json profiles/traffic_$rnd.json profiles/valu_peak_$rnd.json profiles/isa_census_$rnd.json $out/ 2>/dev/null
+unset DGS_BWD_OVERLAP
 tail -3 $out/make_valu.log; echo "R_total=$R"; ls $out

@@ -17,7 +17,7 @@ for cfg in metric cfg2 cfg1 cfg3 cfg5; do
 done
 # SURVEY 8's secondary variant: D = 3, M = 16 (bench line + kernel stats)
 python3 bench.py --config metric --sh-degree 3 --steps 100 --warmup 5 --no-cpu-baseline > $out/bench_${rnd}_metric_sh3.json 2> $out/bench_${rnd}_metric_sh3.err
-( cd /tmp && rocprofv3 --kernel-trace --stats -d $out/trace_sh3 -o trace --output-format csv -- python3 $root/bench.py --sh-degree 3 --steps 20 --warmup 3 --no-cpu-baseline --no-reference-lists --no-graph > $out/trace_sh3.log 2>&1 )
+( cd /tmp && DGS_BWD_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $out/trace_sh3 -o trace --output-format csv -- python3 $root/bench.py --sh-degree 3 --steps 20 --warmup 3 --no-cpu-baseline --no-reference-lists --no-graph > $out/trace_sh3.log 2>&1 )
 cp $(find $out/trace_sh3 -name "*kernel_stats.csv" | head -1) $out/${rnd}_kernel_stats_sh3.csv 2>/dev/null; rm -rf $out/trace_sh3
 # one GPU's view of the N-GPU step: emulated shard slices -> predicted scaling table
 python3 tools/predict_scaling.py --out $out/predicted_scaling_${rnd}.json > $out/predicted_scaling_${rnd}.txt 2>&1

@@ -31,6 +31,7 @@ def main():
     if "timeline" not in os.environ.get("DGS_LIB_PATH", ""):   # (any build with -DDGS_TIMELINE=1)
         raise SystemExit("set DGS_LIB_PATH=variants/libdgs_timeline.so (tools/build_variant.sh timeline composite.hip "
                          "deblurgs_amd/csrc/composite.hip -DDGS_TIMELINE=1)")
+    os.environ["DGS_BWD_OVERLAP"] = "0"      # one launch over all subframes: the buffer is indexed by the launch's own tiles
     import numpy as np
     import torch
     from deblurgs_amd import _lib, synthetic
