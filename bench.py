@@ -659,6 +659,10 @@ def run_rank(args):
                        "dropped_steps": (loop._fused.dropped if loop._fused is not None else 0),
                        "retried_steps": loop.retried,
                        "tile_cull": bool(dgr.TILE_CULL),
+                       # csrc/api.hip: in the timed region a large view's compositing backward runs in parts, each part's
+                       # row totals on a side stream beside the next part's compositing (bit-identical); the
+                       # per-stage averages below are taken with the stage timers on, i.e. with ONE launch per step
+                       "backward_in_parts": os.environ.get("DGS_BWD_OVERLAP", "1") != "0",
                        "sharding": (args.shard if world > 1 else "none"), "ranks_in_process_group": world,
                        "ar_chunks": (args.ar_chunks if world > 1 and loop._fused is not None else None),
                        "allreduce": (sharding.ALLREDUCE_MODE if world > 1 else None),
