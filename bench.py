@@ -673,7 +673,11 @@ def run_rank(args):
                          "unit": "GB/s", "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 5), "traffic": None,
                          "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["avg_ms"],
                          "avg_launch_ms_source": "HIP events on the launch stream inside this run (dgs_profile_*)" +
-                                                 (", recorded in the eager region that follows the replayed one" if graph_info else ""),
+                                                 (", recorded in the eager region that follows the replayed one" if graph_info else "") +
+                                                 "; with the stage timers on the compositing backward runs as ONE launch "
+                                                 "per step (in the timed region: in parts, see config.backward_in_parts), "
+                                                 "and profiles/r05_kernel_stats.csv is taken the same way "
+                                                 "(DGS_BWD_OVERLAP=0)",
                          "note": "the dominant kernel (compositing) is bound by VALU issue, not by HBM (SURVEY 8d): `frac` is "
                                  "the honest HBM fraction of its byte model, `valu` (when the round's PMC profile of this "
                                  "config is committed) the fraction of the VALU issue peak it reaches"},
