@@ -20,7 +20,10 @@
  *     (rasterizer_impl.cu:286-287): dgs_forward_geometry -> caller sizes the binning blob ->
  *     dgs_forward_render.
  * Every entry point returns 0 on success or a negative DGS_E_* code; dgs_last_error() gives the text.
- * All kernels are enqueued on the given stream; nothing here synchronises unless `debug` is set.
+ * All kernels are enqueued on the given stream; nothing here synchronises unless `debug` is set.  One exception to "on
+ * the given stream", invisible to the caller's ordering: the backward of a large view forks part of its work onto a side
+ * stream the library creates once per device (one stream, nine events; no device memory) and joins it back before it
+ * returns -- see dgs_backward.
  */
 #ifndef DGS_HIP_H_INCLUDED
 #define DGS_HIP_H_INCLUDED
