@@ -67,6 +67,9 @@ def parse_args(argv=None):
                          "reduce-scatter + all-gather over point-to-point sends (deblurgs_amd.sharding.p2p_allreduce_)")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--graph-always", action="store_true",
+                    help="replay the captured hipGraph also for large views (default: TrainingLoop's own policy, graph='auto': "
+                         "views whose compositing backward the library runs in parts when enqueued eagerly stay eager)")
     ap.add_argument("--emulate-shard", default=None, metavar="r/G",
                     help="ONE GPU: time rank r's share of a G-GPU step of --shard mode with every collective degenerate "
                          "(one-rank process group): 'subframes' = its slice of the view's K subframes, 'views' = a whole "
@@ -400,7 +403,8 @@ def run_rank(args):
     def make_loop(mode_, motion_):
         lp = TrainingLoop(cloud, motion_, opt, cameras_extent=1.0, spatial_lr_scale=1.0, distributed=mode_,
                           fused_step=False if args.autograd_path else "auto", log_losses=False,
-                          graph=False if args.no_graph else "always", ar_chunks=args.ar_chunks,
+                          graph=False if args.no_graph else ("always" if args.graph_always else "auto"),
+                          ar_chunks=args.ar_chunks,
                           emulate_shard=emu if mode_ else None)
         # The ground truth is noise, so real learning rates would pull the cloud away from the configured workload within
         # the timed region (opacities collapse and the step gets ~5 % cheaper).  The Adam kernel does the same work for
@@ -469,9 +473,10 @@ def run_rank(args):
         Pv_tot = int((probe["radii_all"] > 0).sum().item())
         del probe
     # (N ranks: the step up to its first collective is replayed -- FusedStep.replay_front)
-    replaying = loop.graph and loop._fused is not None and not args.autograd_path and not args.no_graph
-    dt = timed(args.steps, profile=not replaying)
-    stats["profiled_steps"] = args.steps
+    replayed_before = loop._fused.replayed if loop._fused is not None else 0
+    # the timed region never carries the stage timers (their event pairs, and -- csrc/api.hip -- the compositing backward
+    # as one launch instead of parts); the per-stage durations come from a second region right after it
+    dt = timed(args.steps, profile=False)
     per_rank = None
     if world > 1:       # every rank's own time for the region (the headline divides by the slowest)
         mine = torch.tensor([stats["dt_local"]], dtype=torch.float64, device=dev)
@@ -489,6 +494,8 @@ def run_rank(args):
         evs = loop._fused.ar_events[-args.steps:]
         allreduce_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
     graph_info = None
+    # did the timed region replay the captured step?  (TrainingLoop(graph="auto") leaves large views to the eager fused step)
+    replaying = loop._fused is not None and loop._fused.replayed > replayed_before
     if replaying:
         # The timed region replayed the captured step (one hipGraph launch per iteration): HIP events cannot be recorded
         # between the kernels of a graph, so the per-stage durations come from a second, EAGER region of the same step
@@ -502,6 +509,11 @@ def run_rank(args):
         stats["profiled_steps"] = n_prof
         graph_info["eager_ms_per_step"] = round(dt_eager / n_prof * 1e3, 3)
         loop.graph = True
+    else:
+        n_prof = max(10, min(args.steps, 30))
+        dt_prof = timed(n_prof, profile=True)
+        stats["profiled_steps"] = n_prof
+        stats["profiled_ms_per_step"] = round(dt_prof / n_prof * 1e3, 3)
     prof = _lib.profile_read()
 
     # the same step on the reference's duplicate lists (tile_cull = 0: sort keys / point lists bit-identical to the
@@ -656,13 +668,22 @@ def run_rank(args):
                                       (", the iteration replayed as one captured hipGraph)" if graph_info else ")")
                                       if loop._fused is not None else "CameraMotionModule.query + torch autograd")),
                        "graph": graph_info,
+                       "graph_policy": ("off (--no-graph)" if args.no_graph else "always (--graph-always)" if args.graph_always
+                                        else "auto (TrainingLoop's default): a view whose compositing backward the library "
+                                             "runs in parts when it is enqueued eagerly -- tile culling, K >= 6, >= 4 M "
+                                             "duplicates -- is enqueued eagerly, smaller views are replayed as one hipGraph"),
+                       "eager_preferred_steps": (loop._fused.eager_preferred if loop._fused is not None else None),
                        "dropped_steps": (loop._fused.dropped if loop._fused is not None else 0),
                        "retried_steps": loop.retried,
                        "tile_cull": bool(dgr.TILE_CULL),
                        # csrc/api.hip: in the timed region a large view's compositing backward runs in parts, each part's
                        # row totals on a side stream beside the next part's compositing (bit-identical); the
                        # per-stage averages below are taken with the stage timers on, i.e. with ONE launch per step
-                       "backward_in_parts": os.environ.get("DGS_BWD_OVERLAP", "1") != "0",
+                       # and only for eagerly enqueued steps: the library does not fork inside a stream capture (a forked
+                       # executable graph does not give its memory back on this runtime, tools/graph_fork_leak.hip)
+                       "backward_in_parts": (os.environ.get("DGS_BWD_OVERLAP", "1") == "3" or
+                                             (os.environ.get("DGS_BWD_OVERLAP", "1") != "0" and not graph_info)),
+                       "profiled_region_ms_per_step": stats.get("profiled_ms_per_step"),
                        "sharding": (args.shard if world > 1 else "none"), "ranks_in_process_group": world,
                        "ar_chunks": (args.ar_chunks if world > 1 and loop._fused is not None else None),
                        "allreduce": (sharding.ALLREDUCE_MODE if world > 1 else None),
@@ -675,9 +696,9 @@ def run_rank(args):
                          "avg_launch_ms_source": "HIP events on the launch stream inside this run (dgs_profile_*)" +
                                                  (", recorded in the eager region that follows the replayed one" if graph_info else "") +
                                                  "; with the stage timers on the compositing backward runs as ONE launch "
-                                                 "per step (in the timed region: in parts, see config.backward_in_parts), "
-                                                 "and profiles/r05_kernel_stats.csv is taken the same way "
-                                                 "(DGS_BWD_OVERLAP=0)",
+                                                 "per step (as it does inside a captured graph; an eagerly enqueued step "
+                                                 "runs it in parts, see config.backward_in_parts), and "
+                                                 "profiles/r05_kernel_stats.csv is taken the same way (DGS_BWD_OVERLAP=0)",
                          "note": "the dominant kernel (compositing) is bound by VALU issue, not by HBM (SURVEY 8d): `frac` is "
                                  "the honest HBM fraction of its byte model, `valu` (when the round's PMC profile of this "
                                  "config is committed) the fraction of the VALU issue peak it reaches"},

@@ -79,7 +79,7 @@ class DgsCloudArrays(ctypes.Structure):
 
 
 ADAM_MAX_GROUPS = 16
-ABI_VERSION = 12           # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
+ABI_VERSION = 13           # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
 
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {
@@ -128,6 +128,7 @@ EXPORTS = {
                                                 ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_void_p]),
     "dgs_copy_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
+    "dgs_backward_parts": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_uint64, ctypes.c_int32]),
     "dgs_adam_scalars": (ctypes.c_int, [ctypes.POINTER(DgsAdamGroup), ctypes.c_int32, ctypes.c_double, ctypes.c_double,
                                         ctypes.POINTER(ctypes.c_float)]),
     "dgs_adam_step_dev": (ctypes.c_int, [ctypes.POINTER(DgsAdamGroup), ctypes.c_int32, ctypes.c_double, ctypes.c_double,

@@ -791,8 +791,8 @@ static int forward_capacity_impl(const DgsProblem* p, const DgsForwardOut* out, 
 // the call's work is ordered before whatever the caller enqueues next (and a stream capture picks the side stream up
 // through the event wait, like any forked capture).  The kernels and every sum are the ones of the single launch:
 // bit-identical results (tools/grad_hash.py).  Measured at the metric configuration: -0.15 ms of 10.8.
-// DGS_BWD_OVERLAP=0 turns it off, =2 forces it whatever the size (tests); DGS_BWD_PARTS="7,6" overrides the cut (subframes
-// per part, the rest = last part).
+// DGS_BWD_OVERLAP=0 turns it off, =2 forces it whatever the size (tests), =3 also inside a stream capture (measurements
+// only: see backward_impl); DGS_BWD_PARTS="7,6" overrides the cut (subframes per part, the rest = last part).
 constexpr int BWD_MAX_PARTS = 8;
 constexpr uint64_t BWD_OVERLAP_MIN_PAIRS = 4000000;   // below this the extra launches and events cost more than they hide
 
@@ -924,10 +924,17 @@ static int backward_impl(const DgsProblem* p, const DgsBackwardIO* io, int which
                                                up((size_t)p->K * (size_t)p->P * DGS_SUMS_F * 4));
   // (with the stage timers on -- dgs_profile_begin -- the two kernels run one after the other: their event pairs then time
   // what they say; so does debug mode, which synchronises after every stage)
+  // ... and never inside a stream capture (unless DGS_BWD_OVERLAP=3 asks for it): on this runtime (ROCm 7.2) an executable
+  // graph with a kernel on a forked branch does not give back all device memory when it is destroyed -- 4 MB per
+  // capture / instantiate / destroy cycle in plain HIP (tools/graph_fork_leak.hip), and with torch's graph pools the
+  // step's released buffers stay in use as well: ~0.9 GB per re-capture at 1.2 M Gaussians (tools/soak.py)
   int cut[BWD_MAX_PARTS + 1], parts = 1;
-  if ((which & 1) && v.tile_cull && !p->debug && !g_prof.on && bwd_overlap_mode() != 0 &&
-      (R >= BWD_OVERLAP_MIN_PAIRS || bwd_overlap_mode() == 2))
-    parts = bwd_parts(p->K, cut, bwd_overlap_mode() == 2);
+  const int omode = bwd_overlap_mode();
+  if ((which & 1) && v.tile_cull && !p->debug && !g_prof.on && omode != 0 && (R >= BWD_OVERLAP_MIN_PAIRS || omode >= 2)) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (omode != 3 && hipStreamIsCapturing(s, &cs) != hipSuccess) cs = hipStreamCaptureStatusActive;   // (unknown: stay serial)
+    if (cs == hipStreamCaptureStatusNone) parts = bwd_parts(p->K, cut, omode >= 2);
+  }
   if (parts > 1) {
     hipError_t e = backward_composite_overlapped(p, io, v, c, contrib, sums, partials, s, cut, parts);
     if (e != hipSuccess) return fail_hip(e, "composite backward (parts)");
@@ -952,6 +959,12 @@ int dgs_backward_composite(const DgsProblem* p, const DgsBackwardIO* io, dgs_str
 int dgs_backward_geometry(const DgsProblem* p, const DgsBackwardIO* io, int32_t g_begin, int32_t g_end,
                           dgs_stream_t stream) {
   return backward_impl(p, io, 2, g_begin, g_end, reinterpret_cast<hipStream_t>(stream));
+}
+int32_t dgs_backward_parts(int32_t K, uint64_t num_rendered, int32_t tile_cull) {
+  const int omode = bwd_overlap_mode();
+  if (K < 1 || !tile_cull || omode == 0 || (num_rendered < BWD_OVERLAP_MIN_PAIRS && omode < 2)) return 1;
+  int cut[BWD_MAX_PARTS + 1];
+  return bwd_parts(K, cut, omode >= 2);
 }
 int dgs_backward_pose(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream) {
   return backward_impl(p, io, 4, 0, 0, reinterpret_cast<hipStream_t>(stream));

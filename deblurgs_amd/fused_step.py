@@ -30,6 +30,7 @@ queued (`retry`): TrainingLoop re-runs the view through the exact path as soon a
 still gets its update (the reference applies every step).
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -68,6 +69,13 @@ class FusedStep:
         self._free_hosts = []
         self._keep = None           # buffers of the last step (the skip flag lives in its geometry blob)
         self.last_capacity = None
+        # replay() / replay_front() decline (None: the caller enqueues the step eagerly) when the library would run this
+        # view's compositing backward in parts if it were enqueued eagerly (dgs_backward_parts > 1: large views).  Inside a
+        # capture the backward is one launch -- a forked executable graph does not return its memory on this runtime --
+        # and beside its row totals the eagerly enqueued step is the faster one at these sizes (metric configuration:
+        # 10.54-10.62 against 10.76-10.87 ms replayed).  True (TrainingLoop(graph="always")) captures anyway.
+        self.capture_large = False
+        self.eager_preferred = 0    # steps declined for that reason
         self._sel_cache = {}
         self._side = None           # side stream of the chunked gradient all-reduce
         self.time_allreduce = False
@@ -130,6 +138,14 @@ class FusedStep:
         _lib.check(_lib.lib().dgs_copy_words(ctypes.c_void_p(ent["hyper"].data_ptr()), ctypes.c_void_p(hbuf.data_ptr()),
                                              int(hbuf.numel()), stream), "dgs_copy_words")
         return slot
+
+    def _eager_is_faster(self, K, cap, cull):
+        if self.capture_large or os.environ.get("DGS_BWD_OVERLAP") == "3":   # (=3: the library forks inside a capture too)
+            return False
+        if _lib.lib().dgs_backward_parts(int(K), int(cap), int(bool(cull))) <= 1:
+            return False
+        self.eager_preferred += 1
+        return True
 
     def _capacity(self, key):
         seen = self._seen.get(key)
@@ -256,6 +272,8 @@ class FusedStep:
         cap = -(-cap // q) * q
         hot = list(cloud.hot_parameters())
         cull = dgr.TILE_CULL if self.tile_cull is None else bool(self.tile_cull)
+        if self._eager_is_faster(K_total, cap, cull):
+            return None
         gkey = (int(cam_idx), subframe_indice, int(cloud.active_sh_degree), bool(m.is_optimizing()),
                 bool(m.curve_random_sample), cap, self._generation, gt.data_ptr(), bool(cull), bool(dgr.WIDE_RECORDS),
                 tuple(p.data_ptr() for p in hot), tuple(signature),
@@ -327,6 +345,8 @@ class FusedStep:
         cap = -(-cap // q) * q
         hot = list(cloud.hot_parameters())
         cull = dgr.TILE_CULL if self.tile_cull is None else bool(self.tile_cull)
+        if shard is None and self._eager_is_faster(K_total, cap, cull):   # ("subframes": the captured front ends before the backward)
+            return None
         chunks = 1 if ar is None else int(ar.get("chunks", 1))
         gkey = ("front", int(cam_idx), subframe_indice, int(cloud.active_sh_degree), bool(m.is_optimizing()),
                 bool(m.curve_random_sample), cap, self._generation, gt.data_ptr(), bool(cull), bool(dgr.WIDE_RECORDS),

@@ -52,7 +52,10 @@ class TrainingLoop:
         launch -- as ONE captured hipGraph per (view, subframe selection, SH degree, ...) whenever that is possible
         (single process, no depth-smoothness term, no ground-truth noise, not an iteration that densifies or resets
         opacities), falling back to the eager fused step otherwise; False never captures; "always" captures whenever
-        possible.  FusedStep.replay has the details.
+        possible.  FusedStep.replay has the details.  "auto" also leaves LARGE views to the eager fused step (those whose
+        compositing backward the library runs in parts beside its row totals when it is enqueued eagerly, which it cannot
+        do inside a capture: dgs_backward_parts > 1, i.e. tile culling, K >= 6, >= 4 M duplicates): at those sizes the
+        host is far ahead of the device and the eager step is the faster one; "always" replays them too.
         A capture costs tens of milliseconds (more for large clouds) and every densification invalidates all of them, so
         while the cloud is still being densified "auto" only captures when a view can expect to be replayed often enough
         before the next densification: densification_interval / number of views >= graph_min_reuse (the reference's
@@ -109,6 +112,7 @@ class TrainingLoop:
                 if gaussians._xyz.device.type == "cuda":
                     self._fused = FusedStep(gaussians, cam_motion_module, lambda_hinge=max(opt.lambda_hinge, 0.0),
                                             speculative=speculative)
+                    self._fused.capture_large = self._graph_always
             except NotImplementedError:
                 if fused_step is True:
                     raise

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 12
+#define DGS_ABI_VERSION 13
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -253,10 +253,11 @@ int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity
 int dgs_forward_lists(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream);
 int dgs_forward_composite(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream);
 /* Replaces Rasterizer::backward (rasterizer_impl.cu:350-463).
- * For a large view (tile_cull, K >= 6, >= 4 M duplicates) the compositing backward runs in up to three parts of the
- * subframes and the per-pair totals of every part but the last run on a side stream the library owns, forked from and
- * joined back into `stream` inside the call (events): ordering on `stream` is unchanged, a stream capture includes the
- * side stream, results are bit-identical.  Environment: DGS_BWD_OVERLAP=0 disables it. */
+ * For a large view (tile_cull, K >= 6, >= 4 M duplicates) an EAGERLY enqueued call runs the compositing backward in up
+ * to three parts of the subframes and the per-pair totals of every part but the last on a side stream the library owns,
+ * forked from and joined back into `stream` inside the call (events): ordering on `stream` is unchanged, results are
+ * bit-identical.  Not while `stream` is being captured (a forked executable graph does not return all its memory on
+ * ROCm 7.2: tools/graph_fork_leak.hip), not under dgs_profile_begin, not in debug mode.  DGS_BWD_OVERLAP=0 disables it. */
 int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream);
 /* dgs_backward in three parts, for callers that overlap the gradient all-reduce of a sharded run with the backward's
  * tail: dgs_backward_composite (compositing backward + per-(subframe, Gaussian) totals), then dgs_backward_geometry for
@@ -268,6 +269,10 @@ int dgs_backward_composite(const DgsProblem* p, const DgsBackwardIO* io, dgs_str
 int dgs_backward_geometry(const DgsProblem* p, const DgsBackwardIO* io, int32_t g_begin, int32_t g_end,
                           dgs_stream_t stream);
 int dgs_backward_pose(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream);
+/* How many parts an eagerly enqueued dgs_backward / dgs_backward_composite of such a view runs its compositing in (1 = one
+ * launch: small view, K < 6, no tile culling, or DGS_BWD_OVERLAP=0).  For callers that choose between replaying a captured
+ * step (always one launch) and enqueueing it eagerly: deblurgs_amd/fused_step.py does. */
+int32_t dgs_backward_parts(int32_t K, uint64_t num_rendered, int32_t tile_cull);
 /* Replaces Rasterizer::markVisible (rasterizer_impl.cu:141-153); present is bool[P] as bytes. */
 int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, dgs_stream_t stream);

@@ -151,3 +151,20 @@ def test_argument_checks_of_the_training_side_entry_points_need_no_gpu():
     p.shs_rest = 16
     assert L.dgs_forward_geometry(ctypes.byref(p), ctypes.byref(out), None) != 0
     assert b"shs_rest" in L.dgs_last_error()
+
+
+def test_backward_parts_query_needs_no_gpu():
+    """dgs_backward_parts: how an eagerly enqueued backward cuts a view's subframes (csrc/api.hip, bwd_parts) -- three
+    parts for a large view with tile culling and K >= 6, one launch otherwise.  (DGS_BWD_OVERLAP must not be set in the
+    environment of the CPU suite: the library reads it once.)"""
+    import os
+    from deblurgs_amd import _lib
+    if os.environ.get("DGS_BWD_OVERLAP") not in (None, "1"):
+        pytest.skip("DGS_BWD_OVERLAP is set")
+    L = _lib.lib()
+    big = 37_000_000
+    assert L.dgs_backward_parts(15, big, 1) == 3 and L.dgs_backward_parts(31, 380_000_000, 1) == 3
+    assert L.dgs_backward_parts(6, big, 1) == 3 and L.dgs_backward_parts(5, big, 1) == 1
+    assert L.dgs_backward_parts(15, 3_999_999, 1) == 1 and L.dgs_backward_parts(15, 4_000_000, 1) == 3
+    assert L.dgs_backward_parts(15, big, 0) == 1          # the reference's lists: no per-subframe segments to cut at
+    assert L.dgs_backward_parts(0, big, 1) == 1

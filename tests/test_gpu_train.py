@@ -1232,7 +1232,9 @@ def test_backward_in_parts_is_bit_identical_to_the_single_launch(gpu):
     stream next to the next part's compositing.  Same kernels, same sums: every output of a forward + backward must have
     the same bits with the feature off (DGS_BWD_OVERLAP=0), forced on for this small view (=2, default cut) and with an
     explicit cut into four parts -- and a captured step must still equal the eager one when the backward forks inside the
-    capture.  Separate processes: the library reads the variables once."""
+    capture (=3: by default the library does not fork inside a capture, because this runtime's forked graphs do not give
+    all device memory back when they are destroyed -- tools/graph_fork_leak.hip).  Separate processes: the library reads
+    the variables once."""
     import os
     import subprocess
     import sys
@@ -1252,5 +1254,42 @@ def test_backward_in_parts_is_bit_identical_to_the_single_launch(gpu):
     assert hashes(DGS_BWD_OVERLAP="2", DGS_BWD_PARTS="1,1,1") == off
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_train.py"), "-q", "-m", "gpu", "-x",
                         "-k", "graph_replay_equals_eager or captured_front_equals_the_eager"],
-                       env=dict(os.environ, DGS_BWD_OVERLAP="2"), capture_output=True, text=True, timeout=900, cwd=root)
+                       env=dict(os.environ, DGS_BWD_OVERLAP="3"), capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_auto_graph_policy_leaves_views_whose_backward_runs_in_parts_to_the_eager_step(gpu):
+    """TrainingLoop(graph="auto") does not replay a view whose compositing backward the library would run in parts when it
+    is enqueued eagerly (inside a capture it cannot: dgs_hip.h, dgs_backward) -- FusedStep.replay declines and the eager
+    fused step runs; graph="always" captures it all the same.  DGS_BWD_OVERLAP=2 makes this small view such a view (the
+    library reads the variable once: separate process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from test_gpu_train import _fused_fixture
+from deblurgs_amd import _lib
+from deblurgs_amd.training import TrainingLoop, default_optimization_params
+assert _lib.lib().dgs_backward_parts(5, 1000, 1) == 2
+opt = default_optimization_params(iterations=100, densify_from_iter=10**9, densify_until_iter=0, curve_start_iter=1)
+for mode, want_capture in (("auto", False), ("always", True)):
+    sc, cloud, m = _fused_fixture(seed=9, K=5, P=3000)
+    loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, graph=mode)
+    for it in range(1, 13):
+        loop.step(it, it % 3)
+    loop.flush()
+    torch.cuda.synchronize()
+    fs = loop._fused
+    print(mode, fs.captured, fs.replayed, fs.eager_preferred)
+    if want_capture:
+        assert fs.captured >= 1 and fs.replayed >= 3 and fs.eager_preferred == 0
+    else:
+        assert fs.captured == 0 and fs.replayed == 0 and fs.eager_preferred >= 3
+print("policy ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, DGS_BWD_OVERLAP="2"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "policy ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
