@@ -22,7 +22,10 @@ cp $(find $out/trace_sh3 -name "*kernel_stats.csv" | head -1) $out/${rnd}_kernel
 # one GPU's view of the N-GPU step: emulated shard slices -> predicted scaling table
 python3 tools/predict_scaling.py --out $out/predicted_scaling_${rnd}.json > $out/predicted_scaling_${rnd}.txt 2>&1
 DGS_LIB_PATH=$root/variants/libdgs_timeline.so python3 tools/tile_timeline.py --json $out/tile_timeline_${rnd}.json > $out/tile_timeline_${rnd}.log 2>&1
-python3 bench.py --config metric --steps 50 --warmup 5 --no-cpu-baseline --no-reference-lists --no-graph > $out/bench_${rnd}_metric_eager.json 2>/dev/null
+# the metric step replayed as one hipGraph (TrainingLoop's "auto" leaves it to the eager step), the eager step with the
+# backward as one launch, cfg2's step enqueued eagerly (it is replayed by default)
+python3 bench.py --config metric --steps 50 --warmup 5 --no-cpu-baseline --no-reference-lists --graph-always > $out/bench_${rnd}_metric_graph_always.json 2>/dev/null
+DGS_BWD_OVERLAP=0 python3 bench.py --config metric --steps 50 --warmup 5 --no-cpu-baseline --no-reference-lists --no-graph > $out/bench_${rnd}_metric_eager.json 2>/dev/null
 python3 bench.py --config cfg2 --steps 50 --warmup 5 --no-cpu-baseline --no-reference-lists --no-graph > $out/bench_${rnd}_cfg2_eager.json 2>/dev/null
 python3 bench.py --config metric --steps 30 --warmup 5 --no-cpu-baseline --no-reference-lists --autograd-path > $out/bench_${rnd}_metric_autograd.json 2>/dev/null
 python3 tools/soak.py 2000 always > $out/soak_${rnd}.log 2>&1
