@@ -828,8 +828,13 @@ static hipError_t side_stream(SideStream** out) {
   return hipSuccess;
 }
 
-// cut[0..n]: part i = subframes [cut[i], cut[i+1]).  Default for K >= 6: two near-equal parts and a short last one (its
-// totals are the only ones nothing runs next to): K = 15 -> 7, 6, 2
+// cut[0..n]: part i = subframes [cut[i], cut[i+1]).  Default for K >= 6: a first part of two thirds of the subframes -- its
+// totals, which take about twice as long beside compositing as alone, then have the compositing of all the others to run
+// beside --, a second one of most of the rest and a last one of one subframe (its totals are the only ones nothing runs next
+// to): K = 15 -> 10, 4, 1; K = 31 -> 21, 9, 1.  (Measured for the eagerly enqueued step, the only place the parts run, on three
+// boxes: 10,4,1 10.40-10.44 against 7,6,2 10.47-10.55 ms; 10,4,1 10.86, 12,2,1 10.80-10.82, 12,3 10.84-10.90, 7,6,2 10.91-10.95,
+// 13,2 10.94, 14,1 11.03; on the third 12,2,1 and 7,6,2 were equal within its noise, and K = 31 lost 0.5 % with 26,4,1 against
+// 14,13,4 -- profiles/r05_ab_logs.txt, calls 31-34)
 static int bwd_parts(int K, int* cut, bool force) {
   int n = 0;
   cut[0] = 0;
@@ -845,9 +850,8 @@ static int bwd_parts(int K, int* cut, bool force) {
       if (*q == ',') q++;
     }
   } else if (K >= 6) {
-    const int last = K / 8 + 1, rest = K - last;
-    cut[1] = (rest + 1) / 2;
-    cut[2] = rest;
+    cut[1] = (2 * K + 1) / 3;
+    cut[2] = K - 1;
     n = 2;
   } else if (force && K >= 2) {
     cut[1] = (K + 1) / 2;
