@@ -788,9 +788,10 @@ static int forward_capacity_impl(const DgsProblem* p, const DgsForwardOut* out, 
 // device well.  The subframes are cut into (up to) three parts; their compositing kernels run back to back on the
 // caller's stream, and the row totals of every part but the last run on a side stream owned by the library, each as soon as
 // its part's compositing is done; the caller's stream waits for the side stream before the last part's totals, so all of
-// the call's work is ordered before whatever the caller enqueues next (and a stream capture picks the side stream up
-// through the event wait, like any forked capture).  The kernels and every sum are the ones of the single launch:
-// bit-identical results (tools/grad_hash.py).  Measured at the metric configuration: -0.15 ms of 10.8.
+// the call's work is ordered before whatever the caller enqueues next.  The kernels and every sum are the ones of the single
+// launch: bit-identical results (tools/grad_hash.py).  Only for an eagerly enqueued call (backward_impl: never inside a stream
+// capture); measured at the metric configuration: the eager step 10.4-10.6 ms against 10.7-10.9 replayed or eager with one
+// launch.
 // DGS_BWD_OVERLAP=0 turns it off, =2 forces it whatever the size (tests), =3 also inside a stream capture (measurements
 // only: see backward_impl); DGS_BWD_PARTS="7,6" overrides the cut (subframes per part, the rest = last part).
 constexpr int BWD_MAX_PARTS = 8;
