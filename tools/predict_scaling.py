@@ -15,7 +15,7 @@ Model (every assumption is in the output):
   * "subframes": before the backward, the partial blur image [3,H,W] is all-reduced and one boundary subframe travels to
     each neighbour (blur_bytes / link, both directions at once); after it the whole bucket's all-reduce is exposed (the
     per-Gaussian kernel of 1-2 subframes is too short to hide anything).
-  speed-up = renders per second of G GPUs / renders per second of the single-GPU (captured-graph) step measured in the
+  speed-up = renders per second of G GPUs / renders per second of the single-GPU step (bench.py's default: TrainingLoop's own graph policy) measured in the
   same invocation on the same box.
 """
 import argparse
