@@ -676,13 +676,15 @@ def run_rank(args):
                        "dropped_steps": (loop._fused.dropped if loop._fused is not None else 0),
                        "retried_steps": loop.retried,
                        "tile_cull": bool(dgr.TILE_CULL),
-                       # csrc/api.hip: in the timed region a large view's compositing backward runs in parts, each part's
-                       # row totals on a side stream beside the next part's compositing (bit-identical); the
-                       # per-stage averages below are taken with the stage timers on, i.e. with ONE launch per step
+                       # csrc/api.hip: how many parts the timed region's compositing backward ran in (1 = one launch; > 1: a
+                       # large view enqueued eagerly, each part's row totals on a side stream beside the next part's
+                       # compositing, bit-identical -- DESIGN.md 7); the per-stage averages below are taken with the stage
+                       # timers on, i.e. with ONE launch per step
                        # and only for eagerly enqueued steps: the library does not fork inside a stream capture (a forked
                        # executable graph does not give its memory back on this runtime, tools/graph_fork_leak.hip)
-                       "backward_in_parts": (os.environ.get("DGS_BWD_OVERLAP", "1") == "3" or
-                                             (os.environ.get("DGS_BWD_OVERLAP", "1") != "0" and not graph_info)),
+                       "backward_in_parts": (int(_lib.lib().dgs_backward_parts(int(round(K * frac_k)), int(R_tot * frac_k),
+                                                                               int(bool(dgr.TILE_CULL)))) if
+                                             (not graph_info or os.environ.get("DGS_BWD_OVERLAP") == "3") else 1),
                        "profiled_region_ms_per_step": stats.get("profiled_ms_per_step"),
                        "sharding": (args.shard if world > 1 else "none"), "ranks_in_process_group": world,
                        "ar_chunks": (args.ar_chunks if world > 1 and loop._fused is not None else None),
