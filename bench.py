@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+EXIT_EXTRAS_HUNG = 3    # a rank's exit code when the headline line was printed but an extra region behind it never returned
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
@@ -132,7 +133,8 @@ def launch_ranks(args):
         rcs = [p.poll() for p in procs]
         if all(rc is not None for rc in rcs):
             break
-        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        # (EXIT_EXTRAS_HUNG: that rank's headline figures are valid and its peers will give up on the same region by themselves)
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0, EXIT_EXTRAS_HUNG)]
         if bad or time.time() > deadline:
             failed = f"rank(s) {bad} exited non-zero" if bad else "timeout"
             for p in procs:                     # our own children, by handle (never by pattern)
@@ -153,7 +155,7 @@ def launch_ranks(args):
     for ln in out0.read().splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
-    if failed is not None or any(rc != 0 for rc in rcs) or line is None:
+    if failed is not None or any(rc not in (0, EXIT_EXTRAS_HUNG) for rc in rcs) or line is None:
         why = failed or ("no result line" if line is None else "non-zero exit")
         print(f"bench.py: {why}; rank exit codes {rcs}", file=sys.stderr)
         return 1
@@ -161,6 +163,10 @@ def launch_ranks(args):
         print(f"bench.py: the ranks saw {json.loads(line)['n_gpus']} peers, not {n}", file=sys.stderr)
         return 1
     print(line, flush=True)
+    if any(rc == EXIT_EXTRAS_HUNG for rc in rcs):    # headline valid, an extra region hung: the line is out, the code says so
+        print(f"bench.py: an extra region hung on rank(s) {[i for i, rc in enumerate(rcs) if rc]}; headline line printed",
+              file=sys.stderr)
+        return EXIT_EXTRAS_HUNG
     return 0
 
 
@@ -682,7 +688,7 @@ def run_rank(args):
                        # timers on, i.e. with ONE launch per step
                        # and only for eagerly enqueued steps: the library does not fork inside a stream capture (a forked
                        # executable graph does not give its memory back on this runtime, tools/graph_fork_leak.hip)
-                       "backward_in_parts": (int(_lib.lib().dgs_backward_parts(int(round(K * frac_k)), int(R_tot * frac_k),
+                       "backward_in_parts": (int(_lib.lib().dgs_backward_parts(_lib.context(), int(round(K * frac_k)), int(R_tot * frac_k),
                                                                                int(bool(dgr.TILE_CULL)))) if
                                              (not graph_info or os.environ.get("DGS_BWD_OVERLAP") == "3") else 1),
                        "profiled_region_ms_per_step": stats.get("profiled_ms_per_step"),
@@ -793,7 +799,7 @@ def run_rank(args):
         sys.stderr.flush()
         if final_line is not None:
             print(final_line, flush=True)
-        os._exit(0)
+        os._exit(EXIT_EXTRAS_HUNG)   # non-zero: a hung collective is not a success; the headline line is out
     if dist.is_initialized():
         if world > 1:
             dist.barrier()

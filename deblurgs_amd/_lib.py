@@ -35,7 +35,16 @@ class DgsProblem(ctypes.Structure):
         ("geom_state", ctypes.c_void_p), ("geom_bytes", ctypes.c_size_t),
         ("image_state", ctypes.c_void_p), ("image_bytes", ctypes.c_size_t),
         ("binning_state", ctypes.c_void_p), ("binning_bytes", ctypes.c_size_t),
+        ("context", ctypes.c_void_p),
     ]
+
+
+MAX_BWD_PARTS = 8          # DGS_MAX_BWD_PARTS
+
+
+class DgsContextOptions(ctypes.Structure):
+    _fields_ = [("bwd_overlap", ctypes.c_int32), ("bwd_n_parts", ctypes.c_int32),
+                ("bwd_parts", ctypes.c_int32 * (MAX_BWD_PARTS - 1))]
 
 
 class DgsForwardOut(ctypes.Structure):
@@ -79,12 +88,15 @@ class DgsCloudArrays(ctypes.Structure):
 
 
 ADAM_MAX_GROUPS = 16
-ABI_VERSION = 13           # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
+ABI_VERSION = 14           # DGS_ABI_VERSION of include/dgs_hip.h (tests/test_abi.py keeps the two in step)
 
 # every symbol include/dgs_hip.h declares (tests check that the library exports exactly these)
 EXPORTS = {
     "dgs_abi_version": (ctypes.c_int, []),
     "dgs_last_error": (ctypes.c_char_p, []),
+    "dgs_build_id": (ctypes.c_char_p, []),
+    "dgs_context_create": (ctypes.c_int, [ctypes.POINTER(DgsContextOptions), ctypes.POINTER(ctypes.c_void_p)]),
+    "dgs_context_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "dgs_geom_state_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "dgs_image_state_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "dgs_binning_state_bytes": (ctypes.c_size_t, [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
@@ -128,7 +140,7 @@ EXPORTS = {
                                                 ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_void_p]),
     "dgs_copy_words": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
-    "dgs_backward_parts": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_uint64, ctypes.c_int32]),
+    "dgs_backward_parts": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64, ctypes.c_int32]),
     "dgs_adam_scalars": (ctypes.c_int, [ctypes.POINTER(DgsAdamGroup), ctypes.c_int32, ctypes.c_double, ctypes.c_double,
                                         ctypes.POINTER(ctypes.c_float)]),
     "dgs_adam_step_dev": (ctypes.c_int, [ctypes.POINTER(DgsAdamGroup), ctypes.c_int32, ctypes.c_double, ctypes.c_double,
@@ -164,9 +176,9 @@ EXPORTS = {
     "dgs_pose_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dgs_pose_forward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 3 + [ctypes.c_void_p] * 4),
     "dgs_pose_backward": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int32] * 3 + [ctypes.c_void_p] * 7),
-    "dgs_profile_enable": (ctypes.c_int, [ctypes.c_int32]),
-    "dgs_profile_reset": (ctypes.c_int, []),
-    "dgs_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32),
+    "dgs_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "dgs_profile_reset": (ctypes.c_int, [ctypes.c_void_p]),
+    "dgs_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32),
                                         ctypes.c_int32]),
 }
 
@@ -192,8 +204,78 @@ def lib():
             fn.argtypes = args
         if L.dgs_abi_version() != ABI_VERSION:
             raise RuntimeError("libdgs_hip.so ABI version mismatch")
+        if not os.environ.get("DGS_LIB_PATH"):   # (an explicitly chosen A/B or sanitizer build is the caller's business)
+            verify_build_id(L)
         _lib = L
     return _lib
+
+
+def verify_build_id(L, csrc=None, header=None):
+    """The stale-binary guard: the library carries the SHA-256 of the sources and flags it was built from
+    (dgs_build_id()); the same hash is recomputed from the sources next to this file, and a binary that does not match is
+    refused -- *.so files are git-ignored but travel to the GPU box, so a commit made after the last local build would
+    otherwise be tested and benchmarked with the previous binary and nothing would notice."""
+    from . import build as _build
+    have = L.dgs_build_id().decode()
+    want = _build.build_id(**({} if csrc is None else {"csrc": csrc}), **({} if header is None else {"header": header}))
+    if have != want:
+        raise RuntimeError(
+            f"{LIB_PATH} is stale: it was built from sources with id {have[:16]}..., the sources here have id {want[:16]}... "
+            "-- rebuild with `python -m deblurgs_amd.build` (or __graft_entry__.build()).")
+    return have
+
+
+def build_id():
+    return lib().dgs_build_id().decode()
+
+
+# ---- the caller-owned context (include/dgs_hip.h, ABI 14).  The library reads no environment variable; THIS module does,
+# once per context, to fill the options struct:
+#   DGS_BWD_OVERLAP = 0 | 1 | 2 | 3    DgsContextOptions.bwd_overlap (default 1)
+#   DGS_BWD_PARTS   = "10,4"           DgsContextOptions.bwd_parts (subframes per part; the rest is the last part)
+_contexts = {}
+
+
+def context_options_from_env(environ=None):
+    env = os.environ if environ is None else environ
+    o = DgsContextOptions()
+    o.bwd_overlap = int(env.get("DGS_BWD_OVERLAP", "1"))
+    spec = [int(x) for x in env.get("DGS_BWD_PARTS", "").split(",") if x.strip()]
+    o.bwd_n_parts = min(len(spec), MAX_BWD_PARTS - 1)
+    for i in range(o.bwd_n_parts):
+        o.bwd_parts[i] = spec[i]
+    return o
+
+
+def create_context(options=None):
+    h = ctypes.c_void_p()
+    check(lib().dgs_context_create(ctypes.byref(options) if options is not None else None, ctypes.byref(h)),
+          "dgs_context_create")
+    return h
+
+
+def destroy_context(h):
+    check(lib().dgs_context_destroy(h), "dgs_context_destroy")
+
+
+def context(device=None):
+    """The package's context for a device (created on first use with the options the environment asks for; one per
+    device: its side stream belongs to the device that is current when the first large backward runs).  Callers that want
+    their own policy pass their own handle in DgsProblem.context."""
+    if device is None:
+        import torch
+        device = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    key = int(device)
+    if key not in _contexts:
+        _contexts[key] = create_context(context_options_from_env())
+    return _contexts[key]
+
+
+def reset_contexts():
+    """Destroys the package's contexts (tests that change DGS_BWD_* between runs; device must be idle)."""
+    for h in _contexts.values():
+        destroy_context(h)
+    _contexts.clear()
 
 
 def check(rc, what):
@@ -219,17 +301,17 @@ def backward_scratch_layout(R, P, K):
     return so.value, po.value
 
 
-def profile_enable(on=True):
-    check(lib().dgs_profile_enable(1 if on else 0), "profile_enable")
+def profile_enable(on=True, ctx=None):
+    check(lib().dgs_profile_enable(ctx if ctx is not None else context(), 1 if on else 0), "profile_enable")
 
 
-def profile_reset():
-    check(lib().dgs_profile_reset(), "profile_reset")
+def profile_reset(ctx=None):
+    check(lib().dgs_profile_reset(ctx if ctx is not None else context()), "profile_reset")
 
 
-def profile_read():
+def profile_read(ctx=None):
     n = len(STAGES)
     ms = (ctypes.c_float * n)()
     calls = (ctypes.c_int32 * n)()
-    check(lib().dgs_profile_read(ms, calls, n), "profile_read")
+    check(lib().dgs_profile_read(ctx if ctx is not None else context(), ms, calls, n), "profile_read")
     return {STAGES[i]: (float(ms[i]), int(calls[i])) for i in range(n)}

@@ -1,6 +1,9 @@
 """Builds deblurgs_amd/libdgs_hip.so from deblurgs_amd/csrc/*.hip with hipcc for gfx950 (in-tree, so the
 library travels with the repository snapshot).  `python -m deblurgs_amd.build` or `build()`.
 """
+import glob
+import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -44,6 +47,52 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+HEADER = os.path.join(HERE, "..", "include", "dgs_hip.h")
+
+
+def _sha(*chunks):
+    h = hashlib.sha256()
+    for c in chunks:
+        h.update(c if isinstance(c, bytes) else c.encode())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def _read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def flag_table():
+    return json.dumps({"common": COMMON, "sources": SOURCES, "arch": ARCH}, sort_keys=True)
+
+
+def build_id(csrc=CSRC, header=HEADER):
+    """SHA-256 over what the library is built from: every csrc/*.hip and csrc/*.h (by name), include/dgs_hip.h and the
+    flag table above.  The build compiles it into the library (dgs_build_id()); _lib.lib() recomputes it from the sources
+    it finds next to itself and refuses a binary that does not match (a stale libdgs_hip.so travels to the GPU box like a
+    fresh one: *.so is git-ignored, not gpurun-ignored)."""
+    parts = []
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        parts += [os.path.basename(f), _read(f)]
+    parts += ["dgs_hip.h", _read(header), flag_table()]
+    return _sha(*parts)
+
+
+def _object_stamp(src, extra, headers, bid):
+    """What an object file depends on: its source, the shared headers, its flags -- and, for api.hip, the build id it
+    carries.  Staleness is decided by content, not by modification time (a checkout or a copy resets mtimes)."""
+    return _sha(_read(src), *[_read(h) for h in headers], json.dumps(COMMON + extra), bid if src.endswith("api.hip") else "")
+
+
+def _stamp_matches(path, want):
+    try:
+        with open(path) as f:
+            return f.read().strip() == want
+    except OSError:
+        return False
+
+
 SAN_LIB = os.path.join(HERE, "libdgs_hip_san.so")
 SAN_OBJ = os.path.join(CSRC, "obj_san")
 # Host-side AddressSanitizer + UndefinedBehaviorSanitizer build of the WHOLE library (SURVEY 5): the same sources, the
@@ -77,7 +126,8 @@ def build_sanitized(force=False, verbose=False):
         o = os.path.join(SAN_OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + common + extra + ["-c", s, "-o", o])
+            define = [f'-DDGS_BUILD_ID="{build_id()}"'] if src == "api.hip" else []
+            jobs.append([hipcc] + common + extra + define + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -97,16 +147,21 @@ def build_sanitized(force=False, verbose=False):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "dgs_common.h"), os.path.join(HERE, "..", "include", "dgs_hip.h")]
+    headers = [os.path.join(CSRC, "dgs_common.h"), HEADER]
     hipcc = _hipcc()
+    bid = build_id()
     jobs = []
     objs = []
+    stamps = []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + COMMON + extra + ["-c", s, "-o", o])
+        want = _object_stamp(s, extra, headers, bid)
+        if force or not os.path.exists(o) or not _stamp_matches(o + ".stamp", want):
+            define = [f'-DDGS_BUILD_ID="{bid}"'] if src == "api.hip" else []
+            jobs.append([hipcc] + COMMON + extra + define + ["-c", s, "-o", o])
+            stamps.append((o + ".stamp", want))
 
     def run(cmd):
         if verbose:
@@ -118,8 +173,13 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
+    for path, want in stamps:
+        with open(path, "w") as f:
+            f.write(want + "\n")
+    if force or jobs or not os.path.exists(LIB) or not _stamp_matches(LIB + ".stamp", bid):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
+        with open(LIB + ".stamp", "w") as f:
+            f.write(bid + "\n")
     return LIB
 
 

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <new>
 
 #include "dgs_common.h"
 
@@ -163,47 +164,64 @@ void carve(const DgsProblem* p, const DgsLayout& L, DgsCarve* c) {
   c->sort_tmp = b ? reinterpret_cast<uint32_t*>(b + L.sort_tmp) : nullptr;
 }
 
-// ---------------------------------------------------------------------------------------------- profiling
+// ------------------------------------------------------------------------------------------------ context
+// Everything that outlives a call lives here, owned by the caller (include/dgs_hip.h, ABI 14): the side stream + events of
+// the backward in parts (created on first use, on the device that is current then), its policy, the stage timers.
 constexpr int PROF_MAX = 16384;
 struct Prof {
-  std::mutex mu;
   bool on = false;
   int n = 0;
-  hipEvent_t beg[PROF_MAX], end[PROF_MAX];
-  int stage[PROF_MAX];
+  hipEvent_t* beg = nullptr;   // PROF_MAX each, allocated when the timers are first switched on
+  hipEvent_t* end = nullptr;
+  int* stage = nullptr;
   int created = 0;
-} g_prof;
+};
+}  // namespace
 
-int prof_begin(int stage, hipStream_t s) {
-  if (!g_prof.on) return -1;
-  std::lock_guard<std::mutex> lk(g_prof.mu);
-  if (g_prof.n >= PROF_MAX) return -1;
-  const int i = g_prof.n++;
-  if (i >= g_prof.created) {
-    hipEventCreate(&g_prof.beg[i]);
-    hipEventCreate(&g_prof.end[i]);
-    g_prof.created = i + 1;
+struct DgsContext {
+  std::mutex mu;               // one enqueue sequence at a time per context
+  DgsContextOptions opt;
+  bool side_ready = false;
+  int side_device = -1;
+  hipStream_t s2 = nullptr;
+  hipEvent_t done[DGS_MAX_BWD_PARTS] = {}, join = nullptr;
+  Prof prof;
+};
+
+namespace {
+
+int prof_begin(DgsContext* ctx, int stage, hipStream_t s) {
+  if (ctx == nullptr || !ctx->prof.on) return -1;
+  Prof& pr = ctx->prof;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (pr.n >= PROF_MAX) return -1;
+  const int i = pr.n++;
+  if (i >= pr.created) {
+    hipEventCreate(&pr.beg[i]);
+    hipEventCreate(&pr.end[i]);
+    pr.created = i + 1;
   }
-  g_prof.stage[i] = stage;
-  hipEventRecord(g_prof.beg[i], s);
+  pr.stage[i] = stage;
+  hipEventRecord(pr.beg[i], s);
   return i;
 }
-void prof_end(int i, hipStream_t s) {
-  if (i >= 0) hipEventRecord(g_prof.end[i], s);
+void prof_end(DgsContext* ctx, int i, hipStream_t s) {
+  if (i >= 0) hipEventRecord(ctx->prof.end[i], s);
 }
 
 struct StageTimer {
+  DgsContext* ctx;
   int id;
   hipStream_t s;
-  StageTimer(int stage, hipStream_t st) : id(prof_begin(stage, st)), s(st) {}
-  ~StageTimer() { prof_end(id, s); }
+  StageTimer(DgsContext* c, int stage, hipStream_t st) : ctx(c), id(prof_begin(c, stage, st)), s(st) {}
+  ~StageTimer() { prof_end(ctx, id, s); }
 };
 
 #define DGS_STAGE(stage_id, where, expr)                                   \
   do {                                                                      \
     hipError_t e__;                                                         \
     {                                                                       \
-      StageTimer tm__(stage_id, s);                                         \
+      StageTimer tm__(p->context, stage_id, s);                                         \
       e__ = (expr);                                                         \
     }                                                                       \
     if (e__ != hipSuccess) return fail_hip(e__, where);                     \
@@ -751,7 +769,23 @@ static int forward_capacity_impl(const DgsProblem* p, const DgsForwardOut* out, 
   // The count words reach the host from the finalize kernel itself when num_rendered_host is device-accessible pinned
   // memory (hipHostMalloc / torch pin_memory: the usual case) -- no copy node in the launch chain; otherwise by copies.
   uint32_t* host_dev = nullptr;
-  if (out != nullptr && out->num_rendered_host != nullptr && p != nullptr && p->P > 0) {
+  {   // arguments first: an invalid call is refused before anything touches the HIP runtime
+    const int rc0 = check_problem(p);
+    if (rc0 != DGS_OK) return rc0;
+    if (out == nullptr || out->num_rendered_host == nullptr)
+      return fail(DGS_E_ARG, "DgsForwardOut: num_rendered_host is null");
+    if (p->P > 0) {
+      if (out->radii == nullptr) return fail(DGS_E_ARG, "DgsForwardOut: radii is null");
+      DgsLayout L0;
+      make_layout(p->P, p->W, p->H, p->K, capacity, p->wide_records != 0, &L0);
+      if (p->geom_state == nullptr || p->geom_bytes < L0.geom_total) return fail(DGS_E_CAPACITY, "geom_state too small");
+      if ((phases & 2) && (p->image_state == nullptr || p->image_bytes < L0.image_total))
+        return fail(DGS_E_CAPACITY, "image_state too small");
+      if (capacity > 0 && (p->binning_state == nullptr || p->binning_bytes < L0.binning_total))
+        return fail(DGS_E_CAPACITY, "binning_state too small");
+    }
+  }
+  if (p->P > 0) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, out->num_rendered_host, 0) == hipSuccess && dp != nullptr)
       host_dev = reinterpret_cast<uint32_t*>(dp);
@@ -792,40 +826,22 @@ static int forward_capacity_impl(const DgsProblem* p, const DgsForwardOut* out, 
 // launch: bit-identical results (tools/grad_hash.py).  Only for an eagerly enqueued call (backward_impl: never inside a stream
 // capture); measured at the metric configuration: the eager step 10.4-10.6 ms against 10.7-10.9 replayed or eager with one
 // launch.
-// DGS_BWD_OVERLAP=0 turns it off, =2 forces it whatever the size (tests), =3 also inside a stream capture (measurements
-// only: see backward_impl); DGS_BWD_PARTS="7,6" overrides the cut (subframes per part, the rest = last part).
-constexpr int BWD_MAX_PARTS = 8;
+// Policy and streams come from the caller's DgsContext (no context: always one launch).
+constexpr int BWD_MAX_PARTS = DGS_MAX_BWD_PARTS;
 constexpr uint64_t BWD_OVERLAP_MIN_PAIRS = 4000000;   // below this the extra launches and events cost more than they hide
 
-static int bwd_overlap_mode() {
-  static const int mode = [] {
-    const char* e = getenv("DGS_BWD_OVERLAP");
-    return (e != nullptr) ? atoi(e) : 1;
-  }();
-  return mode;
-}
-
-struct SideStream {
-  bool ready = false;
-  hipStream_t s2 = nullptr;
-  hipEvent_t done[BWD_MAX_PARTS] = {}, join = nullptr;
-};
-static std::mutex g_side_mu;          // the enqueue sequence of one call is not interleaved with another thread's
-static hipError_t side_stream(SideStream** out) {
-  static SideStream st[16];
+// the context's side stream and events, created on first use on the device that is current (mutex held by the caller)
+static hipError_t side_stream(DgsContext* ctx) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-  SideStream& t = st[dev];
-  if (!t.ready) {
-    e = hipStreamCreateWithFlags(&t.s2, hipStreamNonBlocking);
-    for (int i = 0; i < BWD_MAX_PARTS && e == hipSuccess; i++) e = hipEventCreateWithFlags(&t.done[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&t.join, hipEventDisableTiming);
-    if (e != hipSuccess) return e;
-    t.ready = true;
-  }
-  *out = &t;
+  if (ctx->side_ready) return dev == ctx->side_device ? hipSuccess : hipErrorInvalidDevice;   // one context, one device
+  e = hipStreamCreateWithFlags(&ctx->s2, hipStreamNonBlocking);
+  for (int i = 0; i < BWD_MAX_PARTS && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->done[i], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming);
+  if (e != hipSuccess) return e;
+  ctx->side_device = dev;
+  ctx->side_ready = true;
   return hipSuccess;
 }
 
@@ -836,19 +852,15 @@ static hipError_t side_stream(SideStream** out) {
 // boxes: 10,4,1 10.40-10.44 against 7,6,2 10.47-10.55 ms; 10,4,1 10.86, 12,2,1 10.80-10.82, 12,3 10.84-10.90, 7,6,2 10.91-10.95,
 // 13,2 10.94, 14,1 11.03; on the third 12,2,1 and 7,6,2 were equal within its noise, and K = 31 lost 0.5 % with 26,4,1 against
 // 14,13,4 -- profiles/r05_ab_logs.txt, calls 31-34)
-static int bwd_parts(int K, int* cut, bool force) {
+static int bwd_parts(const DgsContextOptions& opt, int K, int* cut, bool force) {
   int n = 0;
   cut[0] = 0;
-  const char* spec = getenv("DGS_BWD_PARTS");
-  if (spec != nullptr) {
-    const char* q = spec;
-    while (*q && n < BWD_MAX_PARTS - 1) {
-      const int len = atoi(q);
+  if (opt.bwd_n_parts > 0) {
+    for (int i = 0; i < opt.bwd_n_parts && i < BWD_MAX_PARTS - 1 && n < BWD_MAX_PARTS - 1; i++) {
+      const int len = opt.bwd_parts[i];
       if (len <= 0 || cut[n] + len >= K) break;
       cut[n + 1] = cut[n] + len;
       n++;
-      while (*q && *q != ',') q++;
-      if (*q == ',') q++;
     }
   } else if (K >= 6) {
     cut[1] = (2 * K + 1) / 3;
@@ -865,19 +877,29 @@ static int bwd_parts(int K, int* cut, bool force) {
 static hipError_t backward_composite_overlapped(const DgsProblem* p, const DgsBackwardIO* io, const DgsView& v, const DgsCarve& c,
                                                 float* contrib, float* sums, double* partials, hipStream_t s, const int* cut,
                                                 int n) {
-  std::lock_guard<std::mutex> lk(g_side_mu);
-  SideStream* st = nullptr;
-  hipError_t e = side_stream(&st);
+  DgsContext* ctx = p->context;
+  hipStream_t s2 = ctx->s2;
+  hipError_t e = hipSuccess;
+  bool forked = false;
   for (int i = 0; i < n && e == hipSuccess; i++) {
     e = dgs_launch_composite_bwd(v, c, p->bg, io->dL_dout_color, io->dL_dout_depth, contrib, s, cut[i], cut[i + 1]);
     if (i + 1 < n) {
-      if (e == hipSuccess) e = hipEventRecord(st->done[i], s);
-      if (e == hipSuccess) e = hipStreamWaitEvent(st->s2, st->done[i], 0);
-      if (e == hipSuccess) e = dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, st->s2, 1, 0, 0, cut[i], cut[i + 1]);
+      if (e == hipSuccess) e = hipEventRecord(ctx->done[i], s);
+      if (e == hipSuccess) e = hipStreamWaitEvent(s2, ctx->done[i], 0);
+      if (e == hipSuccess) {
+        forked = true;
+        e = dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s2, 1, 0, 0, cut[i], cut[i + 1]);
+      }
     }
   }
-  if (e == hipSuccess) e = hipEventRecord(st->join, st->s2);
-  if (e == hipSuccess) e = hipStreamWaitEvent(s, st->join, 0);
+  // the join is enqueued also when something failed half-way: whatever already sits on the side stream is ordered before
+  // the caller's next work on `s`
+  if (forked) {
+    hipError_t j = hipEventRecord(ctx->join, s2);
+    if (j == hipSuccess) j = hipStreamWaitEvent(s, ctx->join, 0);
+    if (j != hipSuccess && e == hipSuccess) e = j;
+    if (j != hipSuccess) (void)hipStreamSynchronize(s2);
+  }
   if (e == hipSuccess) e = dgs_launch_geometry_bwd(*p, v, c, *io, contrib, sums, partials, s, 1, 0, 0, cut[n - 1], cut[n]);
   return e;
 }
@@ -934,14 +956,25 @@ static int backward_impl(const DgsProblem* p, const DgsBackwardIO* io, int which
   // capture / instantiate / destroy cycle in plain HIP (tools/graph_fork_leak.hip), and with torch's graph pools the
   // step's released buffers stay in use as well: ~0.9 GB per re-capture at 1.2 M Gaussians (tools/soak.py)
   int cut[BWD_MAX_PARTS + 1], parts = 1;
-  const int omode = bwd_overlap_mode();
-  if ((which & 1) && v.tile_cull && !p->debug && !g_prof.on && omode != 0 && (R >= BWD_OVERLAP_MIN_PAIRS || omode >= 2)) {
+  DgsContext* ctx = p->context;
+  const int omode = ctx != nullptr ? ctx->opt.bwd_overlap : 0;
+  std::unique_lock<std::mutex> side_lock;
+  if ((which & 1) && v.tile_cull && !p->debug && omode != 0 && !ctx->prof.on && (R >= BWD_OVERLAP_MIN_PAIRS || omode >= 2)) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (omode != 3 && hipStreamIsCapturing(s, &cs) != hipSuccess) cs = hipStreamCaptureStatusActive;   // (unknown: stay serial)
-    if (cs == hipStreamCaptureStatusNone) parts = bwd_parts(p->K, cut, omode >= 2);
+    if (cs == hipStreamCaptureStatusNone) parts = bwd_parts(ctx->opt, p->K, cut, omode >= 2);
+    if (parts > 1) {
+      side_lock = std::unique_lock<std::mutex>(ctx->mu);
+      if (side_stream(ctx) != hipSuccess) {   // no side stream to be had: the single launch
+        (void)hipGetLastError();
+        side_lock.unlock();
+        parts = 1;
+      }
+    }
   }
   if (parts > 1) {
     hipError_t e = backward_composite_overlapped(p, io, v, c, contrib, sums, partials, s, cut, parts);
+    side_lock.unlock();
     if (e != hipSuccess) return fail_hip(e, "composite backward (parts)");
   } else if (which & 1) {
     DGS_STAGE(DGS_STAGE_COMPOSITE_BWD, "composite backward",
@@ -965,11 +998,11 @@ int dgs_backward_geometry(const DgsProblem* p, const DgsBackwardIO* io, int32_t 
                           dgs_stream_t stream) {
   return backward_impl(p, io, 2, g_begin, g_end, reinterpret_cast<hipStream_t>(stream));
 }
-int32_t dgs_backward_parts(int32_t K, uint64_t num_rendered, int32_t tile_cull) {
-  const int omode = bwd_overlap_mode();
+int32_t dgs_backward_parts(const DgsContext* ctx, int32_t K, uint64_t num_rendered, int32_t tile_cull) {
+  const int omode = ctx != nullptr ? ctx->opt.bwd_overlap : 0;
   if (K < 1 || !tile_cull || omode == 0 || (num_rendered < BWD_OVERLAP_MIN_PAIRS && omode < 2)) return 1;
   int cut[BWD_MAX_PARTS + 1];
-  return bwd_parts(K, cut, omode >= 2);
+  return bwd_parts(ctx->opt, K, cut, omode >= 2);
 }
 int dgs_backward_pose(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream) {
   return backward_impl(p, io, 4, 0, 0, reinterpret_cast<hipStream_t>(stream));
@@ -1087,25 +1120,29 @@ int dgs_blur_loss_slice_grad(const float* subframes, const float* prev_last, con
   return e == hipSuccess ? DGS_OK : fail_hip(e, "blur_loss_slice_grad");
 }
 
-int dgs_copy_words(void* dst_dev, const void* src, int32_t n_words, dgs_stream_t stream) {
-  if (n_words < 0 || n_words > 4096 || (n_words > 0 && (dst_dev == nullptr || src == nullptr)))
+// device-side address of a pointer that is either device memory or mapped pinned host memory; nullptr otherwise (pageable)
+static void* device_view(const void* ptr) {
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, const_cast<void*>(ptr), 0) == hipSuccess && dp != nullptr) return dp;
+  (void)hipGetLastError();
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type == hipMemoryTypeDevice) return const_cast<void*>(ptr);
+  (void)hipGetLastError();
+  return nullptr;
+}
+
+int dgs_copy_words(void* dst, const void* src, int32_t n_words, dgs_stream_t stream) {
+  if (n_words < 0 || n_words > 4096 || (n_words > 0 && (dst == nullptr || src == nullptr)))
     return fail(DGS_E_ARG, "copy_words: bad argument (at most 4096 words)");
   if (n_words == 0) return DGS_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  void* dp = nullptr;
+  void* d = device_view(dst);
+  void* sp = device_view(src);
   hipError_t e;
-  if (hipHostGetDevicePointer(&dp, const_cast<void*>(src), 0) == hipSuccess && dp != nullptr) {
-    e = dgs_launch_copy_words(reinterpret_cast<uint32_t*>(dst_dev), reinterpret_cast<const uint32_t*>(dp), n_words, s);
-  } else {   // src is not mapped pinned host memory: device memory (a kernel copies it just the same) or pageable
-    (void)hipGetLastError();
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeDevice)
-      e = dgs_launch_copy_words(reinterpret_cast<uint32_t*>(dst_dev), reinterpret_cast<const uint32_t*>(src), n_words, s);
-    else {
-      (void)hipGetLastError();
-      e = hipMemcpyAsync(dst_dev, src, (size_t)n_words * 4, hipMemcpyDefault, s);
-    }
-  }
+  if (d != nullptr && sp != nullptr)   // both reachable from a kernel (system-scope stores + fence: dst may be pinned host)
+    e = dgs_launch_copy_words(reinterpret_cast<uint32_t*>(d), reinterpret_cast<const uint32_t*>(sp), n_words, s);
+  else                                 // a pageable end: the runtime's copy
+    e = hipMemcpyAsync(dst, src, (size_t)n_words * 4, hipMemcpyDefault, s);
   return e == hipSuccess ? DGS_OK : fail_hip(e, "copy_words");
 }
 
@@ -1123,29 +1160,77 @@ int dgs_densify_stats(const float* viewspace_grad, const int32_t* radii, int32_t
   return e == hipSuccess ? DGS_OK : fail_hip(e, "densify_stats");
 }
 
-int dgs_profile_enable(int32_t on) {
-  std::lock_guard<std::mutex> lk(g_prof.mu);
-  g_prof.on = on != 0;
+int dgs_context_create(const DgsContextOptions* options, DgsContext** out) {
+  if (out == nullptr) return fail(DGS_E_ARG, "context_create: null output");
+  *out = nullptr;
+  DgsContextOptions o;
+  memset(&o, 0, sizeof(o));
+  o.bwd_overlap = 1;
+  if (options != nullptr) o = *options;
+  if (o.bwd_overlap < 0 || o.bwd_overlap > 3 || o.bwd_n_parts < 0 || o.bwd_n_parts > DGS_MAX_BWD_PARTS - 1)
+    return fail(DGS_E_ARG, "context_create: bwd_overlap must be 0..3, bwd_n_parts 0..DGS_MAX_BWD_PARTS-1");
+  for (int i = 0; i < o.bwd_n_parts; i++)
+    if (o.bwd_parts[i] < 1) return fail(DGS_E_ARG, "context_create: a part must hold at least one subframe");
+  DgsContext* c = new (std::nothrow) DgsContext();
+  if (c == nullptr) return fail(DGS_E_ARG, "context_create: out of host memory");
+  c->opt = o;
+  *out = c;
   return DGS_OK;
 }
-int dgs_profile_reset(void) {
-  std::lock_guard<std::mutex> lk(g_prof.mu);
-  g_prof.n = 0;
+int dgs_context_destroy(DgsContext* ctx) {
+  if (ctx == nullptr) return DGS_OK;
+  hipError_t e = hipSuccess;
+  if (ctx->side_ready) {
+    e = hipStreamSynchronize(ctx->s2);
+    for (int i = 0; i < BWD_MAX_PARTS; i++) (void)hipEventDestroy(ctx->done[i]);
+    (void)hipEventDestroy(ctx->join);
+    (void)hipStreamDestroy(ctx->s2);
+  }
+  for (int i = 0; i < ctx->prof.created; i++) {
+    (void)hipEventDestroy(ctx->prof.beg[i]);
+    (void)hipEventDestroy(ctx->prof.end[i]);
+  }
+  delete[] ctx->prof.beg;
+  delete[] ctx->prof.end;
+  delete[] ctx->prof.stage;
+  delete ctx;
+  return e == hipSuccess ? DGS_OK : fail_hip(e, "context_destroy");
+}
+
+int dgs_profile_enable(DgsContext* ctx, int32_t on) {
+  if (ctx == nullptr) return fail(DGS_E_ARG, "profile_enable: null context");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (on && ctx->prof.beg == nullptr) {
+    ctx->prof.beg = new (std::nothrow) hipEvent_t[PROF_MAX];
+    ctx->prof.end = new (std::nothrow) hipEvent_t[PROF_MAX];
+    ctx->prof.stage = new (std::nothrow) int[PROF_MAX];
+    if (ctx->prof.beg == nullptr || ctx->prof.end == nullptr || ctx->prof.stage == nullptr)
+      return fail(DGS_E_ARG, "profile_enable: out of host memory");
+  }
+  ctx->prof.on = on != 0;
   return DGS_OK;
 }
-int dgs_profile_read(float* ms, int32_t* calls, int32_t n) {
-  std::lock_guard<std::mutex> lk(g_prof.mu);
+int dgs_profile_reset(DgsContext* ctx) {
+  if (ctx == nullptr) return fail(DGS_E_ARG, "profile_reset: null context");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->prof.n = 0;
+  return DGS_OK;
+}
+int dgs_profile_read(DgsContext* ctx, float* ms, int32_t* calls, int32_t n) {
+  if (ctx == nullptr) return fail(DGS_E_ARG, "profile_read: null context");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  Prof& pr = ctx->prof;
   for (int i = 0; i < n; i++) {
     if (ms) ms[i] = 0.0f;
     if (calls) calls[i] = 0;
   }
-  for (int i = 0; i < g_prof.n; i++) {
-    hipError_t e = hipEventSynchronize(g_prof.end[i]);
+  for (int i = 0; i < pr.n; i++) {
+    hipError_t e = hipEventSynchronize(pr.end[i]);
     if (e != hipSuccess) return fail_hip(e, "profile_read");
     float t = 0.0f;
-    e = hipEventElapsedTime(&t, g_prof.beg[i], g_prof.end[i]);
+    e = hipEventElapsedTime(&t, pr.beg[i], pr.end[i]);
     if (e != hipSuccess) return fail_hip(e, "profile_read");
-    const int st = g_prof.stage[i];
+    const int st = pr.stage[i];
     if (st >= 0 && st < n) {
       if (ms) ms[st] += t;
       if (calls) calls[st] += 1;
@@ -1153,5 +1238,10 @@ int dgs_profile_read(float* ms, int32_t* calls, int32_t n) {
   }
   return DGS_OK;
 }
+
+#ifndef DGS_BUILD_ID
+#define DGS_BUILD_ID "unstamped"
+#endif
+const char* dgs_build_id(void) { return DGS_BUILD_ID; }
 
 }  // extern "C"

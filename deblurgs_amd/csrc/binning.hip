@@ -671,8 +671,10 @@ __global__ void finalize_count_kernel(uint32_t* __restrict__ nr, int cull, uint3
 __global__ void clear_words_kernel(uint32_t* __restrict__ p, int n) {
   for (int i = threadIdx.x; i < n; i += 64) p[i] = 0u;
 }
+// (dst may be pinned host memory: system-scope stores and a system fence, like finalize_count_kernel's)
 __global__ void copy_words_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int n) {
-  for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  for (int i = threadIdx.x; i < n; i += 256) __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
 }
 
 // ---------------------------------------------------------------------------------------------- ranges

@@ -98,6 +98,7 @@ class _State:
 def _make_problem(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm, campos,
                   rs, geom, image, binning, tile_cull, raw=None):
     p = _lib.DgsProblem()
+    p.context = _lib.context(means3D.device.index)   # the package's per-device context (side stream, stage timers)
     p.tile_cull = int(bool(tile_cull))
     p.wide_records = int(bool(WIDE_RECORDS))
     p.raw_params = 0 if raw is None else (3 if raw.get("isotropic") else 1)

@@ -142,7 +142,7 @@ class FusedStep:
     def _eager_is_faster(self, K, cap, cull):
         if self.capture_large or os.environ.get("DGS_BWD_OVERLAP") == "3":   # (=3: the library forks inside a capture too)
             return False
-        if _lib.lib().dgs_backward_parts(int(K), int(cap), int(bool(cull))) <= 1:
+        if _lib.lib().dgs_backward_parts(_lib.context(), int(K), int(cap), int(bool(cull))) <= 1:
             return False
         self.eager_preferred += 1
         return True
@@ -598,6 +598,7 @@ class FusedStep:
         bg = background.to(dev, torch.float32).contiguous()
         cull = dgr.TILE_CULL if self.tile_cull is None else bool(self.tile_cull)
         prob = _lib.DgsProblem()
+        prob.context = _lib.context(dev.index)
         prob.P, prob.D, prob.M, prob.W, prob.H, prob.K = P, int(cloud.active_sh_degree), 1 + Mr, W, H, K
         prob.tanfovx, prob.tanfovy = math.tan(m.ref_cam.FoVx * 0.5), math.tan(m.ref_cam.FoVy * 0.5)
         prob.scale_modifier, prob.z_near, prob.z_far = 1.0, float(cloud.z_near), float(cloud.z_far)

@@ -209,9 +209,17 @@ _recv_blocks = {}     # (device, stream, numel) -> receive block of p2p_allreduc
 def _recv_block(device, numel):
     key = (str(device), torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _recv_blocks.get(key)
-    if buf is None or buf.numel() < numel:
+    # grown when too small, and given back when the request has dropped well below it (a prune shrinks the bucket; a
+    # cached block of the old size would otherwise stay for the life of the process -- ADVICE r5)
+    if buf is None or buf.numel() < numel or buf.numel() > 2 * max(numel, 1) + 4096:
         buf = _recv_blocks[key] = torch.empty(max(numel, 1), dtype=torch.float32, device=device)
     return buf
+
+
+def release_buffers():
+    """Drops the cached receive blocks of the point-to-point all-reduce (TrainingLoop calls this after a densification:
+    the bucket has a new size, and the chunked path's per-chunk sizes change with it)."""
+    _recv_blocks.clear()
 
 
 def p2p_allreduce_multi_(tensors, average=False, group=None, align=256, force=False):

@@ -467,6 +467,8 @@ class TrainingLoop:
                                         (lambda m_sel, _it=iteration: self.split_noise_fn(_it, m_sel)))
                     if self._fused is not None:      # the cloud changed size: learn the duplicate counts afresh
                         self._fused.invalidate()
+                    if self.distributed:             # ... and the point-to-point all-reduce's receive blocks are re-sized
+                        sharding.release_buffers()
                 if not makeup and (iteration % opt.opacity_reset_interval == 0 or
                                    (self.white_background and iteration == opt.densify_from_iter)):
                     g.reset_opacity()

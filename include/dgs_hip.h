@@ -7,8 +7,7 @@
  *   - plain C: raw device pointers, sizes and a HIP stream handle; no torch types.  The caller owns every
  *     byte (inputs, outputs, gradients, the three state blobs and the backward scratch); the library never
  *     allocates device memory.  Blob sizes come from the dgs_*_bytes() queries, and the carving of a blob
- *     into sub-arrays is a pure function of (P, W, H, K, R, wide_records) -- no environment variable, no process
- *     state --, replayed identically by forward and backward
+ *     into sub-arrays is a pure function of (P, W, H, K, R, wide_records), replayed identically by forward and backward
  *     (the reference does the same with GeometryState/ImageState/BinningState::fromChunk,
  *     rasterizer_impl.cu:155-194,389-391).
  *   - the duplicates are generated in (k, depth, index) order (a 15 M-pair sort of the Gaussians) so that the
@@ -20,10 +19,12 @@
  *     (rasterizer_impl.cu:286-287): dgs_forward_geometry -> caller sizes the binning blob ->
  *     dgs_forward_render.
  * Every entry point returns 0 on success or a negative DGS_E_* code; dgs_last_error() gives the text.
- * All kernels are enqueued on the given stream; nothing here synchronises unless `debug` is set.  One exception to "on
- * the given stream", invisible to the caller's ordering: the backward of a large view forks part of its work onto a side
- * stream the library creates once per device (one stream, nine events; no device memory) and joins it back before it
- * returns -- see dgs_backward.
+ * All kernels are enqueued on the given stream; nothing here synchronises unless `debug` is set.
+ *   - NO PROCESS STATE (ABI 14): the library reads no environment variable and keeps no global but the thread-local
+ *     text of dgs_last_error().  What outlives a call -- the side stream and events the backward of a large view forks
+ *     part of its work onto, the policy for that fork, the stage timers -- lives in a DgsContext the CALLER creates,
+ *     hands over in DgsProblem.context and destroys; with context = NULL every call is one launch chain on the given
+ *     stream and nothing else.  (The reference keeps its state in caller tensors only, rasterize_points.cu:27-33.)
  */
 #ifndef DGS_HIP_H_INCLUDED
 #define DGS_HIP_H_INCLUDED
@@ -35,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 13
+#define DGS_ABI_VERSION 14
 #define DGS_MAX_K 128 /* subframes per fused call */
 
 #define DGS_OK 0
@@ -44,6 +45,27 @@ extern "C" {
 #define DGS_E_HIP (-3)      /* a HIP runtime error (text in dgs_last_error) */
 
 typedef void* dgs_stream_t; /* hipStream_t */
+
+/* ---- caller-owned context (ABI 14) ---------------------------------------------------------------------------
+ * Everything the library keeps between calls.  dgs_context_create, on the CURRENT device: one non-blocking side stream,
+ * DGS_MAX_BWD_PARTS + 1 events (no device memory), the options below, and the stage timers of dgs_profile_*.  A context
+ * serialises the calls that use it (a mutex around each enqueue sequence); use one per host thread that enqueues
+ * concurrently.  It must outlive every call it was handed to and be destroyed on a quiet device. */
+#define DGS_MAX_BWD_PARTS 8
+typedef struct DgsContextOptions {
+  int32_t bwd_overlap; /* the compositing backward in parts, each part's row totals on the side stream next to the next
+                        * part's compositing (dgs_backward): 0 = never; 1 = for large views (tile_cull, K >= 6, >= 4 M
+                        * duplicates), never inside a stream capture (the default); 2 = for any view with K >= 2 (tests);
+                        * 3 = as 2, also inside a stream capture (measurements only: a forked executable graph does not
+                        * return its memory on ROCm 7.2, tools/graph_fork_leak.hip) */
+  int32_t bwd_n_parts; /* 0 = the library's cut (K = 15: 10, 4, 1); n >= 1: bwd_parts[0..n-1] subframes per part, what is
+                        * left of K after them is the last part (entries that do not fit K are dropped) */
+  int32_t bwd_parts[DGS_MAX_BWD_PARTS - 1];
+} DgsContextOptions;
+typedef struct DgsContext DgsContext; /* opaque */
+/* options = NULL: {1, 0, {}}. */
+int dgs_context_create(const DgsContextOptions* options, DgsContext** out);
+int dgs_context_destroy(DgsContext* ctx); /* NULL is a no-op */
 
 /* Arguments shared by forward and backward: replaces the 22 / 25 positional arguments of
  * RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA (rasterize_points.cu:35-59,125-152). */
@@ -95,6 +117,8 @@ typedef struct DgsProblem {
   void* geom_state;    size_t geom_bytes;    /* >= dgs_geom_state_bytes(P,K) */
   void* image_state;   size_t image_bytes;   /* >= dgs_image_state_bytes(W,H,K) */
   void* binning_state; size_t binning_bytes; /* >= dgs_binning_state_bytes(R,W,H,K); unused by dgs_forward_geometry */
+  DgsContext* context; /* caller-owned (dgs_context_create) or NULL: no side stream, no stage timers -- every call is one
+                        * launch chain on `stream`.  Not part of the blob carving; may differ between forward and backward. */
 } DgsProblem;
 
 typedef struct DgsForwardOut {
@@ -212,6 +236,10 @@ typedef struct DgsLayout {
 
 int dgs_abi_version(void);
 const char* dgs_last_error(void);
+/* SHA-256 (64 hex digits) over the sources this binary was built from -- deblurgs_amd/csrc/*.hip, *.h, include/dgs_hip.h --
+ * and the compiler flag table of deblurgs_amd/build.py, computed by the build and compiled in.  A loader that has the
+ * sources at hand (deblurgs_amd/_lib.py) recomputes it and refuses a stale binary; bench.py prints it. */
+const char* dgs_build_id(void);
 
 size_t dgs_geom_state_bytes(int32_t P, int32_t K);
 size_t dgs_image_state_bytes(int32_t W, int32_t H, int32_t K);
@@ -253,11 +281,12 @@ int dgs_forward(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity
 int dgs_forward_lists(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream);
 int dgs_forward_composite(const DgsProblem* p, const DgsForwardOut* out, uint32_t capacity, dgs_stream_t stream);
 /* Replaces Rasterizer::backward (rasterizer_impl.cu:350-463).
- * For a large view (tile_cull, K >= 6, >= 4 M duplicates) an EAGERLY enqueued call runs the compositing backward in up
- * to three parts of the subframes and the per-pair totals of every part but the last on a side stream the library owns,
- * forked from and joined back into `stream` inside the call (events): ordering on `stream` is unchanged, results are
- * bit-identical.  Not while `stream` is being captured (a forked executable graph does not return all its memory on
- * ROCm 7.2: tools/graph_fork_leak.hip), not under dgs_profile_begin, not in debug mode.  DGS_BWD_OVERLAP=0 disables it. */
+ * With a context (DgsProblem.context) whose bwd_overlap allows it, an EAGERLY enqueued call for a large view (tile_cull,
+ * K >= 6, >= 4 M duplicates) runs the compositing backward in up to three parts of the subframes and the per-pair totals
+ * of every part but the last on the context's side stream, forked from and joined back into `stream` inside the call
+ * (events; joined also when an enqueue fails half-way): ordering on `stream` is unchanged, results are bit-identical.
+ * Not while `stream` is being captured (unless bwd_overlap = 3), not while the context's stage timers are on, not in
+ * debug mode, never without a context. */
 int dgs_backward(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream);
 /* dgs_backward in three parts, for callers that overlap the gradient all-reduce of a sharded run with the backward's
  * tail: dgs_backward_composite (compositing backward + per-(subframe, Gaussian) totals), then dgs_backward_geometry for
@@ -269,10 +298,10 @@ int dgs_backward_composite(const DgsProblem* p, const DgsBackwardIO* io, dgs_str
 int dgs_backward_geometry(const DgsProblem* p, const DgsBackwardIO* io, int32_t g_begin, int32_t g_end,
                           dgs_stream_t stream);
 int dgs_backward_pose(const DgsProblem* p, const DgsBackwardIO* io, dgs_stream_t stream);
-/* How many parts an eagerly enqueued dgs_backward / dgs_backward_composite of such a view runs its compositing in (1 = one
- * launch: small view, K < 6, no tile culling, or DGS_BWD_OVERLAP=0).  For callers that choose between replaying a captured
- * step (always one launch) and enqueueing it eagerly: deblurgs_amd/fused_step.py does. */
-int32_t dgs_backward_parts(int32_t K, uint64_t num_rendered, int32_t tile_cull);
+/* How many parts an eagerly enqueued dgs_backward / dgs_backward_composite of such a view runs its compositing in with
+ * this context (1 = one launch: no context, small view, K < 6, no tile culling, or bwd_overlap = 0).  For callers that
+ * choose between replaying a captured step (always one launch) and enqueueing it eagerly: deblurgs_amd/fused_step.py does. */
+int32_t dgs_backward_parts(const DgsContext* ctx, int32_t K, uint64_t num_rendered, int32_t tile_cull);
 /* Replaces Rasterizer::markVisible (rasterizer_impl.cu:141-153); present is bool[P] as bytes. */
 int dgs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, dgs_stream_t stream);
@@ -328,8 +357,9 @@ int dgs_blur_loss_slice_grad(const float* subframes, const float* prev_last, con
                              const float* gt, int32_t K_local, int32_t K_total, int32_t C, int32_t HW, float lambda_t,
                              float* dL_dsubframes, float* losses, dgs_stream_t stream);
 
-/* A few words (n_words <= 4096) copied to device memory BY A KERNEL on `stream`: src may be device memory or pinned host
- * memory (hipHostMalloc / torch pin_memory: device-accessible).  What a captured training step's per-step scalars travel
+/* A few words (n_words <= 4096) copied BY A KERNEL on `stream`: dst and src may each be device memory or pinned host
+ * memory (hipHostMalloc / torch pin_memory / hipHostRegister: resolved through hipHostGetDevicePointer; the kernel stores
+ * with system scope and fences, so a pinned destination is complete when the stream reaches the caller's next event).  What a captured training step's per-step scalars travel
  * with: an asynchronous host-to-device copy in front of every graph launch costs a hand-over between the copy engine and
  * the compute queue (tens of microseconds); a kernel in front of the graph costs one launch.  Pageable host memory falls
  * back to hipMemcpyAsync. */
@@ -454,7 +484,8 @@ int dgs_pose_backward(const float* ctrl_trans, const float* ctrl_rot, const floa
 int dgs_cloud_activations(int32_t P, const float* scaling, const float* rotation, const float* opacity, float scale_lb,
                           float* out_scaling, float* out_rotation, float* out_opacity, dgs_stream_t stream);
 
-/* Stage timing with HIP events recorded on the caller's stream (bench.py's roofline leg). */
+/* Stage timing with HIP events recorded on the caller's stream (bench.py's roofline leg); the timers belong to the context
+ * the timed calls are handed (DgsProblem.context). */
 #define DGS_STAGE_PREPROCESS 0
 #define DGS_STAGE_SCAN 1
 #define DGS_STAGE_DUPLICATE 2
@@ -468,10 +499,10 @@ int dgs_cloud_activations(int32_t P, const float* scaling, const float* rotation
 #define DGS_STAGE_CONTRIB_REDUCE 10 /* backward: per-(subframe, Gaussian) totals of the contribution rows (the second
                                      * stage of the atomics-free reduction; no counterpart in the reference) */
 #define DGS_STAGE_COUNT 11
-int dgs_profile_enable(int32_t on);
-int dgs_profile_reset(void);
+int dgs_profile_enable(DgsContext* ctx, int32_t on);
+int dgs_profile_reset(DgsContext* ctx);
 /* Synchronises on the recorded events; ms[i] = summed duration of stage i, calls[i] = launches timed. */
-int dgs_profile_read(float* ms, int32_t* calls, int32_t n);
+int dgs_profile_read(DgsContext* ctx, float* ms, int32_t* calls, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,8 @@ def test_no_torch_types_in_the_abi():
 def test_struct_sizes_match_the_header_layout():
     from deblurgs_amd import _lib
     # 6 ints + 5 floats + 5 ints + 1 float = 68 bytes (+4 padding), then 12 pointers, then 3 x (pointer + size_t)
-    assert ctypes.sizeof(_lib.DgsProblem) == 72 + 12 * 8 + 3 * 16
+    assert ctypes.sizeof(_lib.DgsProblem) == 72 + 12 * 8 + 3 * 16 + 8       # + context (ABI 14)
+    assert ctypes.sizeof(_lib.DgsContextOptions) == 4 * (2 + _lib.MAX_BWD_PARTS - 1)
     assert ctypes.sizeof(_lib.DgsForwardOut) == 56     # + drop_counter, status_dev, status_host_indirect
     assert ctypes.sizeof(_lib.DgsBackwardIO) == 8 + 8 * 3 + 16 + 11 * 8 + 8 + 3 * 8 + 8   # + hinge scale, stats_* (padded)
     assert ctypes.sizeof(_lib.DgsLayout) == 29 * 8 + 16     # + sort_bits, sort_passes, pack_g_shift, pack_tile_shift
@@ -155,16 +156,104 @@ def test_argument_checks_of_the_training_side_entry_points_need_no_gpu():
 
 def test_backward_parts_query_needs_no_gpu():
     """dgs_backward_parts: how an eagerly enqueued backward cuts a view's subframes (csrc/api.hip, bwd_parts) -- three
-    parts for a large view with tile culling and K >= 6, one launch otherwise.  (DGS_BWD_OVERLAP must not be set in the
-    environment of the CPU suite: the library reads it once.)"""
-    import os
+    parts for a large view with tile culling and K >= 6, one launch otherwise, and always one launch without a context.
+    The policy is the CONTEXT's (DgsContextOptions), not the environment's."""
     from deblurgs_amd import _lib
-    if os.environ.get("DGS_BWD_OVERLAP") not in (None, "1"):
-        pytest.skip("DGS_BWD_OVERLAP is set")
     L = _lib.lib()
     big = 37_000_000
-    assert L.dgs_backward_parts(15, big, 1) == 3 and L.dgs_backward_parts(31, 380_000_000, 1) == 3
-    assert L.dgs_backward_parts(6, big, 1) == 3 and L.dgs_backward_parts(5, big, 1) == 1
-    assert L.dgs_backward_parts(15, 3_999_999, 1) == 1 and L.dgs_backward_parts(15, 4_000_000, 1) == 3
-    assert L.dgs_backward_parts(15, big, 0) == 1          # the reference's lists: no per-subframe segments to cut at
-    assert L.dgs_backward_parts(0, big, 1) == 1
+    ctx = _lib.create_context()          # defaults: bwd_overlap = 1, the library's cut
+    try:
+        assert L.dgs_backward_parts(ctx, 15, big, 1) == 3 and L.dgs_backward_parts(ctx, 31, 380_000_000, 1) == 3
+        assert L.dgs_backward_parts(ctx, 6, big, 1) == 3 and L.dgs_backward_parts(ctx, 5, big, 1) == 1
+        assert L.dgs_backward_parts(ctx, 15, 3_999_999, 1) == 1 and L.dgs_backward_parts(ctx, 15, 4_000_000, 1) == 3
+        assert L.dgs_backward_parts(ctx, 15, big, 0) == 1      # the reference's lists: no per-subframe segments to cut at
+        assert L.dgs_backward_parts(ctx, 0, big, 1) == 1
+        assert L.dgs_backward_parts(None, 15, big, 1) == 1     # no context: no side stream, one launch
+    finally:
+        _lib.destroy_context(ctx)
+
+
+def test_context_options_decide_the_cut_and_are_validated():
+    from deblurgs_amd import _lib
+    L = _lib.lib()
+    o = _lib.DgsContextOptions()
+    o.bwd_overlap, o.bwd_n_parts = 2, 2
+    o.bwd_parts[0], o.bwd_parts[1] = 7, 6
+    ctx = _lib.create_context(o)
+    try:
+        assert L.dgs_backward_parts(ctx, 15, 1000, 1) == 3         # 7, 6, rest; forced for a small view
+        assert L.dgs_backward_parts(ctx, 10, 1000, 1) == 2         # 7, then 6 does not fit: 7, 3
+        assert L.dgs_backward_parts(ctx, 5, 1000, 1) == 1
+    finally:
+        _lib.destroy_context(ctx)
+    o.bwd_overlap = 0
+    ctx = _lib.create_context(o)
+    try:
+        assert L.dgs_backward_parts(ctx, 15, 37_000_000, 1) == 1
+    finally:
+        _lib.destroy_context(ctx)
+    h = ctypes.c_void_p()
+    o.bwd_overlap = 7
+    assert L.dgs_context_create(ctypes.byref(o), ctypes.byref(h)) == -1 and b"bwd_overlap" in L.dgs_last_error()
+    o.bwd_overlap, o.bwd_n_parts = 1, 1
+    o.bwd_parts[0] = 0
+    assert L.dgs_context_create(ctypes.byref(o), ctypes.byref(h)) == -1
+    assert L.dgs_context_create(None, None) == -1
+    assert L.dgs_context_destroy(None) == 0
+    # the environment reaches the library only through this module's options struct
+    e = _lib.context_options_from_env({"DGS_BWD_OVERLAP": "2", "DGS_BWD_PARTS": "10,4"})
+    assert (e.bwd_overlap, e.bwd_n_parts, e.bwd_parts[0], e.bwd_parts[1]) == (2, 2, 10, 4)
+    d = _lib.context_options_from_env({})
+    assert (d.bwd_overlap, d.bwd_n_parts) == (1, 0)
+
+
+def test_profile_calls_need_a_context():
+    from deblurgs_amd import _lib
+    L = _lib.lib()
+    assert L.dgs_profile_enable(None, 1) == -1 and L.dgs_profile_reset(None) == -1
+    ctx = _lib.create_context()
+    try:
+        assert L.dgs_profile_enable(ctx, 1) == 0 and L.dgs_profile_reset(ctx) == 0
+        ms, calls = (ctypes.c_float * 11)(), (ctypes.c_int32 * 11)()
+        assert L.dgs_profile_read(ctx, ms, calls, 11) == 0 and sum(calls) == 0
+        assert L.dgs_profile_enable(ctx, 0) == 0
+    finally:
+        _lib.destroy_context(ctx)
+
+
+def test_library_reads_no_environment_variable_and_keeps_no_global_state():
+    """SURVEY 8b "Threading / streams: re-entrant, stream-explicit, no globals": no getenv in the device library's sources,
+    no static side stream / profiler; the only thread_local is the error text."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "deblurgs_amd", "csrc", "*")):
+        if os.path.isdir(f):
+            continue
+        text = open(f, errors="replace").read()
+        code = re.sub(r"//.*", "", text)
+        assert "getenv" not in code, f
+        assert not re.search(r"^static\s+(std::mutex|SideStream|Prof)\b", code, flags=re.M), f
+    api = open(os.path.join(ROOT, "deblurgs_amd", "csrc", "api.hip")).read()
+    assert "g_prof" not in api and "g_side_mu" not in api
+
+
+def test_build_id_guard_refuses_a_stale_binary(tmp_path):
+    """The library carries the SHA-256 of its sources + flag table; the loader recomputes it from the sources it finds and
+    refuses a binary that does not match."""
+    import shutil
+    from deblurgs_amd import _lib, build
+    L = _lib.lib()
+    have = L.dgs_build_id().decode()
+    assert re.fullmatch(r"[0-9a-f]{64}", have) and have == build.build_id()
+    assert _lib.verify_build_id(L) == have
+    csrc = tmp_path / "csrc"
+    shutil.copytree(os.path.join(ROOT, "deblurgs_amd", "csrc"), csrc, ignore=shutil.ignore_patterns("obj*"))
+    assert build.build_id(csrc=str(csrc)) == have                      # a copy of the same sources: same id (no mtimes in it)
+    with open(csrc / "composite.hip", "a") as f:
+        f.write("// edited after the last build\n")
+    assert build.build_id(csrc=str(csrc)) != have
+    with pytest.raises(RuntimeError, match="stale"):
+        _lib.verify_build_id(L, csrc=str(csrc))
+    hdr = tmp_path / "dgs_hip.h"
+    hdr.write_text(open(os.path.join(ROOT, "include", "dgs_hip.h")).read() + "\n/* x */\n")
+    with pytest.raises(RuntimeError, match="stale"):
+        _lib.verify_build_id(L, header=str(hdr))

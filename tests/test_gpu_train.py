@@ -898,10 +898,10 @@ def test_training_matches_the_cpu_reference_loop_on_a_toy_deblurring_scene(gpu):
 
 
 # ------------------------------------------------------------------------------------ N-rank path on the one-GPU box
-def _run(cmd, env, timeout=900):
+def _run(cmd, env, timeout=900, rc=0):
     import subprocess
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, f"{cmd}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    assert r.returncode == rc, f"{cmd}\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
     return r.stdout
 
 
@@ -1215,13 +1215,14 @@ def test_emulated_shard_slice_of_the_bench(gpu):
 def test_bench_line_survives_an_extra_region_that_never_returns(gpu):
     """The regions behind the headline one (other sharding mode, all-reduce A/B) run under a watchdog AFTER rank 0 has
     assembled the headline's result: with the watchdog's patience set to (almost) nothing the line must still come out,
-    carry the headline figures and say that the extras were cut short; every rank leaves with exit code 0."""
+    carry the headline figures and say that the extras were cut short; the ranks -- and the launcher -- leave with
+    bench.EXIT_EXTRAS_HUNG (3): "headline valid, an extra region hung", never 0 (a hung collective is not a success)."""
     import json
     import os
     import sys
     root, tool, env = _two_rank_env(DGS_BENCH_EXTRAS_TIMEOUT_S="0.01")
     out = _run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "cfg2", "--steps", "3",
-                "--warmup", "1", "--no-cpu-baseline"], env)
+                "--warmup", "1", "--no-cpu-baseline"], env, rc=3)
     line = json.loads([ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["per_rank"] is not None
     assert "did not return" in line["extras"].get("error", ""), line["extras"]
