@@ -26,7 +26,7 @@ class DgsProblem(ctypes.Structure):
         ("z_near", ctypes.c_float), ("z_far", ctypes.c_float),
         ("use_sigmoid", ctypes.c_int32), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
         ("tile_cull", ctypes.c_int32), ("raw_params", ctypes.c_int32), ("scale_lb", ctypes.c_float),
-        ("wide_records", ctypes.c_int32),
+        ("wide_records", ctypes.c_int32), ("forward_only", ctypes.c_int32),
         ("means3D", ctypes.c_void_p), ("shs", ctypes.c_void_p), ("shs_rest", ctypes.c_void_p),
         ("colors_precomp", ctypes.c_void_p),
         ("opacities", ctypes.c_void_p), ("scales", ctypes.c_void_p), ("rotations", ctypes.c_void_p),
@@ -99,6 +99,7 @@ EXPORTS = {
     "dgs_context_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "dgs_geom_state_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "dgs_image_state_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dgs_image_state_bytes_forward_only": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "dgs_binning_state_bytes": (ctypes.c_size_t, [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "dgs_backward_scratch_bytes": (ctypes.c_size_t, [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32]),
     "dgs_layout": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64,

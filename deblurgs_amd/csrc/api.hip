@@ -30,7 +30,8 @@ int sort_bits_for(int W, int H, int K) {
   return 32 + (int)dgs_higher_msb(T * (uint32_t)K);  // rasterizer_impl.cu:306, with K*T tiles
 }
 
-void make_layout(int P, int W, int H, int K, uint64_t R, bool wide_records, DgsLayout* L) {
+// forward_only: the image blob holds the tile ranges alone (final_T / n_contrib are not stored: offsets 0, size 0)
+void make_layout(int P, int W, int H, int K, uint64_t R, bool wide_records, DgsLayout* L, bool forward_only = false) {
   const size_t KP = (size_t)K * (size_t)P;
   const size_t N = (size_t)W * (size_t)H;
   const size_t T = (size_t)((W + DGS_TILE - 1) / DGS_TILE) * (size_t)((H + DGS_TILE - 1) / DGS_TILE);
@@ -55,8 +56,8 @@ void make_layout(int P, int W, int H, int K, uint64_t R, bool wide_records, DgsL
   L->cull_cnt = o;       o += up(KP * 4);
   L->geom_total = o;
   o = 0;
-  L->final_T = o;        o += up((size_t)K * N * 4);
-  L->n_contrib = o;      o += up((size_t)K * N * 4);
+  L->final_T = o;        o += forward_only ? 0 : up((size_t)K * N * 4);
+  L->n_contrib = o;      o += forward_only ? 0 : up((size_t)K * N * 4);
   L->ranges = o;         o += up((size_t)K * T * 8);
   L->image_total = o;
   o = 0;
@@ -79,15 +80,19 @@ void make_layout(int P, int W, int H, int K, uint64_t R, bool wide_records, DgsL
   }
 }
 
-int check_problem(const DgsProblem* p) {
+// need_opacity = false: the backward of activated-value problems (raw_params = 0) -- the reference's backward entry point
+// is not handed the opacities either (rasterize_points.cu:125-152: it reads them from the geometry state)
+int check_problem(const DgsProblem* p, bool need_opacity = true) {
   if (p == nullptr) return fail(DGS_E_ARG, "null DgsProblem");
   if (p->P < 0 || p->W <= 0 || p->H <= 0) return fail(DGS_E_ARG, "bad P/W/H");
   // tile coordinates are packed into 12 bits each by the duplication kernels (and tile counts stay below 2^24)
   if (p->W > 4095 * DGS_TILE || p->H > 4095 * DGS_TILE) return fail(DGS_E_ARG, "W / H above 65520 pixels");
   if (p->K < 1 || p->K > DGS_MAX_K) return fail(DGS_E_ARG, "K must be in [1, DGS_MAX_K]");
   if (p->D < 0 || p->D > 3) return fail(DGS_E_ARG, "SH degree must be 0..3");
+  if (p->forward_only != 0 && p->forward_only != 1) return fail(DGS_E_ARG, "forward_only must be 0 or 1");
   if (p->P == 0) return DGS_OK;
-  if (p->means3D == nullptr || p->opacities == nullptr) return fail(DGS_E_ARG, "means3D / opacities are null");
+  if (p->means3D == nullptr || (need_opacity && p->opacities == nullptr))
+    return fail(DGS_E_ARG, "means3D / opacities are null");
   if ((p->shs == nullptr) == (p->colors_precomp == nullptr))
     return fail(DGS_E_ARG, "Please provide excatly one of either SHs or precomputed colors!");
   const bool sr = (p->scales != nullptr) && (p->rotations != nullptr);
@@ -137,8 +142,8 @@ void carve(const DgsProblem* p, const DgsLayout& L, DgsCarve* c) {
   char* im = reinterpret_cast<char*>(p->image_state);
   char* b = reinterpret_cast<char*>(p->binning_state);
   c->rows = reinterpret_cast<DgsRow*>(g + L.geom_rows);
-  c->cov3D = reinterpret_cast<float*>(g + L.cov3D);
-  c->pre_sigmoid = reinterpret_cast<float*>(g + L.pre_sigmoid);
+  c->cov3D = p->forward_only ? nullptr : reinterpret_cast<float*>(g + L.cov3D);   // (not stored by an inference call)
+  c->pre_sigmoid = p->forward_only ? nullptr : reinterpret_cast<float*>(g + L.pre_sigmoid);
   c->tiles_touched = reinterpret_cast<uint32_t*>(g + L.tiles_touched);
   c->point_offsets = reinterpret_cast<uint32_t*>(g + L.point_offsets);
   c->scan_tmp = reinterpret_cast<uint32_t*>(g + L.scan_tmp);
@@ -154,8 +159,8 @@ void carve(const DgsProblem* p, const DgsLayout& L, DgsCarve* c) {
   c->gsort_tmp = reinterpret_cast<uint32_t*>(g + L.gsort_tmp);
   c->cull_rec = reinterpret_cast<uint4*>(g + L.cull_rec);
   c->cull_cnt = reinterpret_cast<uint32_t*>(g + L.cull_cnt);
-  c->final_T = reinterpret_cast<float*>(im + L.final_T);
-  c->n_contrib = reinterpret_cast<uint32_t*>(im + L.n_contrib);
+  c->final_T = p->forward_only ? nullptr : reinterpret_cast<float*>(im + L.final_T);
+  c->n_contrib = p->forward_only ? nullptr : reinterpret_cast<uint32_t*>(im + L.n_contrib);
   c->ranges = reinterpret_cast<uint2*>(im + L.ranges);
   c->keys_sorted = b ? reinterpret_cast<uint64_t*>(b + L.keys_sorted) : nullptr;
   c->point_list = b ? reinterpret_cast<uint32_t*>(b + L.point_list) : nullptr;
@@ -589,6 +594,11 @@ size_t dgs_image_state_bytes(int32_t W, int32_t H, int32_t K) {
   make_layout(0, W, H, K, 0, false, &L);
   return L.image_total;
 }
+size_t dgs_image_state_bytes_forward_only(int32_t W, int32_t H, int32_t K) {
+  DgsLayout L;
+  make_layout(0, W, H, K, 0, false, &L, true);
+  return L.image_total;
+}
 size_t dgs_binning_state_bytes(uint64_t R, int32_t W, int32_t H, int32_t K) {
   DgsLayout L;
   make_layout(0, W, H, K, R, false, &L);
@@ -648,7 +658,7 @@ static int forward_geometry_impl(const DgsProblem* p, const DgsForwardOut* out, 
   }
   if (out->radii == nullptr) return fail(DGS_E_ARG, "DgsForwardOut: radii is null");
   DgsLayout L;
-  make_layout(p->P, p->W, p->H, p->K, 0, p->wide_records != 0, &L);
+  make_layout(p->P, p->W, p->H, p->K, 0, p->wide_records != 0, &L, p->forward_only != 0);
   if (p->geom_state == nullptr || p->geom_bytes < L.geom_total) return fail(DGS_E_CAPACITY, "geom_state too small");
   DgsCarve c;
   carve(p, L, &c);
@@ -699,7 +709,7 @@ static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, ui
     return e == hipSuccess ? DGS_OK : fail_hip(e, "memset outputs");
   }
   DgsLayout L;
-  make_layout(p->P, p->W, p->H, p->K, R, p->wide_records != 0, &L);
+  make_layout(p->P, p->W, p->H, p->K, R, p->wide_records != 0, &L, p->forward_only != 0);
   if (p->geom_state == nullptr || p->geom_bytes < L.geom_total) return fail(DGS_E_CAPACITY, "geom_state too small");
   if (p->image_state == nullptr || p->image_bytes < L.image_total) return fail(DGS_E_CAPACITY, "image_state too small");
   if (R > 0 && (p->binning_state == nullptr || p->binning_bytes < L.binning_total))
@@ -744,7 +754,7 @@ static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, ui
   if (phases & 1) DGS_STAGE(DGS_STAGE_RANGES, "identifyTileRanges", dgs_launch_ranges(v, c, R, s, n_dev, key_lo));
   if (phases & 2)
     DGS_STAGE(DGS_STAGE_COMPOSITE_FWD, "composite forward",
-              dgs_launch_composite_fwd(v, c, p->bg, out->out_color, out->out_depth, s));
+              dgs_launch_composite_fwd(v, c, p->bg, out->out_color, out->out_depth, s));   // (c.final_T == NULL: inference)
   return DGS_OK;
 }
 
@@ -777,7 +787,7 @@ static int forward_capacity_impl(const DgsProblem* p, const DgsForwardOut* out, 
     if (p->P > 0) {
       if (out->radii == nullptr) return fail(DGS_E_ARG, "DgsForwardOut: radii is null");
       DgsLayout L0;
-      make_layout(p->P, p->W, p->H, p->K, capacity, p->wide_records != 0, &L0);
+      make_layout(p->P, p->W, p->H, p->K, capacity, p->wide_records != 0, &L0, p->forward_only != 0);
       if (p->geom_state == nullptr || p->geom_bytes < L0.geom_total) return fail(DGS_E_CAPACITY, "geom_state too small");
       if ((phases & 2) && (p->image_state == nullptr || p->image_bytes < L0.image_total))
         return fail(DGS_E_CAPACITY, "image_state too small");
@@ -796,7 +806,7 @@ static int forward_capacity_impl(const DgsProblem* p, const DgsForwardOut* out, 
   if (rc != DGS_OK) return rc;
   if (p->P > 0) {
     DgsLayout L;
-    make_layout(p->P, p->W, p->H, p->K, 0, p->wide_records != 0, &L);
+    make_layout(p->P, p->W, p->H, p->K, 0, p->wide_records != 0, &L, p->forward_only != 0);
     DgsCarve c;
     carve(p, L, &c);
     hipError_t e = dgs_launch_finalize_count(c, p->tile_cull != 0, capacity, out->drop_counter, out->status_dev, host_dev,
@@ -907,8 +917,9 @@ static hipError_t backward_composite_overlapped(const DgsProblem* p, const DgsBa
 // which != 0: 1 = compositing backward + per-pair totals, 2 = per-Gaussian kernel for [g_begin, g_end), 4 = pose sums
 static int backward_impl(const DgsProblem* p, const DgsBackwardIO* io, int which, int32_t g_begin, int32_t g_end,
                          hipStream_t s) {
-  int rc = check_problem(p);
+  int rc = check_problem(p, p != nullptr && p->raw_params != 0);
   if (rc != DGS_OK) return rc;
+  if (p->forward_only) return fail(DGS_E_ARG, "backward: the problem is forward_only (nothing was kept for a backward)");
   if (io == nullptr) return fail(DGS_E_ARG, "null DgsBackwardIO");
   if (io->dL_dviewmatrix == nullptr || io->dL_dprojmatrix == nullptr)
     return fail(DGS_E_ARG, "dL_dviewmatrix / dL_dprojmatrix are null");

@@ -118,7 +118,9 @@ using CullGauss = DgsCull;
 // ------------------------------------------------------------------------------------------------ forward
 // WITHDEPTH = false: the caller does not consume the depth image (DgsForwardOut.out_depth == NULL; the default training
 // loss never reads it): the depth channel drops out of the per-pair math and nothing is stored for it.
-template <bool WITHDEPTH>
+// KEEP = false: an inference call (DgsProblem.forward_only): final_T / n_contrib, which only the backward reads, are not
+// stored (and `last` drops out of the per-pair math).
+template <bool WITHDEPTH, bool KEEP>
 __global__ void __launch_bounds__(64 * CW)
 composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
                      const uint32_t* __restrict__ point_list, const uint64_t* __restrict__ keys,
@@ -239,7 +241,7 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           C2[q] += c.x * wgt;
           if (WITHDEPTH) Dd[q] += c.y * wgt;
           T[q] = stop ? -fabsf(T[q]) : test_T;     // alpha = 0 leaves a live T unchanged
-          last[q] = (ok && !stop) ? posv : last[q];
+          if (KEEP) last[q] = (ok && !stop) ? posv : last[q];
         }
       }
     }
@@ -261,8 +263,10 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
     if (px < v.W && py < v.H) {
       const size_t pix = (size_t)py * v.W + px;
       const float Tf = fabsf(T[q]);
-      final_T[(size_t)t.k * N + pix] = Tf;
-      n_contrib[(size_t)t.k * N + pix] = last[q];
+      if (KEEP) {
+        final_T[(size_t)t.k * N + pix] = Tf;
+        n_contrib[(size_t)t.k * N + pix] = last[q];
+      }
       float* oc = out_color + (size_t)t.k * 3 * N;
       oc[pix] = C0[q] + Tf * bg0;
       oc[N + pix] = C1[q] + Tf * bg1;
@@ -610,12 +614,16 @@ hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const f
                                     float* out_depth, hipStream_t s) {
   const uint32_t per = per_xcd_blocks(v);
   if (per == 0) return hipSuccess;
-  if (out_depth != nullptr)
-    hipLaunchKernelGGL(composite_fwd_kernel<true>, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
-                       c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth);
-  else
-    hipLaunchKernelGGL(composite_fwd_kernel<false>, dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list,
-                       c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth);
+#define DGS_CFWD(WD, KP)                                                                                                  \
+  hipLaunchKernelGGL((composite_fwd_kernel<WD, KP>), dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list, \
+                     c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth)
+  const bool keep = c.final_T != nullptr && c.n_contrib != nullptr;
+  if (out_depth != nullptr) {
+    if (keep) DGS_CFWD(true, true); else DGS_CFWD(true, false);
+  } else {
+    if (keep) DGS_CFWD(false, true); else DGS_CFWD(false, false);
+  }
+#undef DGS_CFWD
   return hipGetLastError();
 }
 

@@ -99,7 +99,7 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
     c3[3] = Sigma.m[1][1];
     c3[4] = Sigma.m[1][2];
     c3[5] = Sigma.m[2][2];
-    if (live) {
+    if (live && cov3Ds != nullptr) {   // (NULL: an inference call keeps nothing for a backward)
 #pragma unroll
       for (int i = 0; i < 6; i++) cov3Ds[6 * (size_t)idx + i] = c3[i];
     }
@@ -269,7 +269,7 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
         const int e = i * 64 + lane;
         if (e < 3 * wave_count) {
           dst[e] = s_row[wv_][e];
-          dpre[e] = s_pre[wv_][e];
+          if (pre_sigmoid != nullptr) dpre[e] = s_pre[wv_][e];
         }
       }
       __builtin_amdgcn_wave_barrier();

@@ -147,12 +147,14 @@ class _RS:
 
 
 def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm, campos,
-                  raster_settings, raw=None, capacity=None):
+                  raster_settings, raw=None, capacity=None, forward_only=False):
     """raw = {"scale_lb": float, "sh_rest": [P,M-1,3] or None, "isotropic": bool}: the inputs are the cloud's raw parameters
     (DgsProblem.raw_params) and sh is the dc part [P,1,3].
     capacity: size the duplicate arrays for that many duplicates up front and run the one-call dgs_forward (no host
     read between the phases; what fused_step.FusedStep does every iteration).  The returned count then carries
-    `.capacity` (the binning blob is laid out for it) and `.overflow`."""
+    `.capacity` (the binning blob is laid out for it) and `.overflow`.
+    forward_only: an inference call (DgsProblem.forward_only): nothing is kept for a backward -- the image blob holds the
+    tile ranges alone, final_T / n_contrib / cov3D / the activation mask are not stored."""
     L = _lib.lib()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:60-62
@@ -165,7 +167,8 @@ def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, 
     depth = torch.empty((K, 1, H, W), dtype=torch.float32, device=device)
     radii = torch.empty((K, P), dtype=torch.int32, device=device)
     geom = torch.empty(L.dgs_geom_state_bytes(P, K), dtype=torch.uint8, device=device)
-    image = torch.empty(L.dgs_image_state_bytes(W, H, K), dtype=torch.uint8, device=device)
+    image = torch.empty(L.dgs_image_state_bytes_forward_only(W, H, K) if forward_only else
+                        L.dgs_image_state_bytes(W, H, K), dtype=torch.uint8, device=device)
     host_R = _pinned_word(device)
     out = _lib.DgsForwardOut()
     out.out_color = _ptr(color)
@@ -176,6 +179,7 @@ def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, 
     tile_cull = bool(TILE_CULL)
     prob = _make_problem(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm,
                          campos, rs, geom, image, None, tile_cull, raw)
+    prob.forward_only = int(bool(forward_only))
     if raw is not None:
         prob.M = 1 + (0 if raw["sh_rest"] is None else raw["sh_rest"].shape[1])
     if capacity is not None:
@@ -240,7 +244,6 @@ def _backward_impl(K, R, means3D, sh, colors_precomp, opacities_shape, scales, r
     io.dL_dprojmatrix = _ptr(g_proj)
     prob = _make_problem(K, means3D, sh, colors_precomp, None, scales, rotations, cov3D_precomp, viewm, projm, campos,
                          rs, geom, image, binning, getattr(R, "tile_cull", False))
-    prob.opacities = _ptr(means3D)   # not read by the backward; must be non-null for the argument check
     _lib.check(L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), _stream(device)), "dgs_backward")
     if BACKWARD_DEBUG is not None:
         BACKWARD_DEBUG.update(scratch=scratch, R=int(R), K=K, P=P, dL_dcov3D=g_cov3D, dL_dcolors=g_colors)
@@ -256,9 +259,30 @@ def _prep(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_prec
             _f32c(_opt(rotations)), _f32c(_opt(cov3Ds_precomp)))
 
 
+# The reference's second use of the operator is inference: test.py:117 and render_spiral.py:29 call render() under
+# torch.no_grad().  When no input can receive a gradient the entry points below skip the autograd Function and run the
+# forward with DgsProblem.forward_only = 1 (nothing stored for a backward; same images, same radii).
+FORWARD_ONLY_WHEN_NO_GRAD = True
+
+
+def _inference(*tensors):
+    return FORWARD_ONLY_WHEN_NO_GRAD and not (torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in tensors))
+
+
 # ------------------------------------------------------------------------------------- K = 1 (reference API)
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         viewmatrix, projmatrix, raster_settings):
+    if _inference(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
+                  projmatrix) and not raster_settings.debug:
+        m3, shc, colc, opc, scc, rotc, covc = _prep(means3D, sh, colors_precomp, opacities, scales, rotations,
+                                                    cov3Ds_precomp)
+        with torch.no_grad():
+            _, color, depth, radii, _, _, _ = _forward_impl(
+                1, m3, shc, colc, opc, scc, rotc, covc, _f32c(viewmatrix).reshape(1, 4, 4),
+                _f32c(projmatrix).reshape(1, 4, 4), _f32c(raster_settings.campos.to(m3.device)).reshape(1, 3),
+                raster_settings, forward_only=True)
+        return color[0], depth[0], radii[0]
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, viewmatrix, projmatrix, raster_settings)
 
@@ -339,6 +363,19 @@ class _RasterizeGaussians(torch.autograd.Function):
 # ------------------------------------------------------------------------------ K subframes, one fused launch
 def rasterize_gaussians_subframes(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                   viewmatrices, projmatrices, raster_settings):
+    if _inference(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrices,
+                  projmatrices) and not raster_settings.debug:
+        m3, shc, colc, opc, scc, rotc, covc = _prep(means3D, sh, colors_precomp, opacities, scales, rotations,
+                                                    cov3Ds_precomp)
+        viewm, projm = _f32c(viewmatrices), _f32c(projmatrices)
+        K = viewm.shape[0]
+        campos = _f32c(raster_settings.campos.to(m3.device)).reshape(-1, 3)
+        if viewm.shape != (K, 4, 4) or projm.shape != (K, 4, 4) or campos.shape[0] != K:
+            raise RuntimeError("viewmatrices / projmatrices must be [K,4,4] and raster_settings.campos [K,3]")
+        with torch.no_grad():
+            _, color, depth, radii, _, _, _ = _forward_impl(K, m3, shc, colc, opc, scc, rotc, covc, viewm, projm, campos,
+                                                            raster_settings, forward_only=True)
+        return color, depth, radii
     return _RasterizeGaussiansK.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                       cov3Ds_precomp, viewmatrices, projmatrices, raster_settings)
 
@@ -501,6 +538,19 @@ def rasterize_cloud_subframes(xyz, means2D, f_dc, f_rest, opacity, scaling, rota
                               raster_settings, scale_lb=0.0, isotropic=False):
     """isotropic: the cloud has one shared scale per Gaussian, column 0 of `scaling` (use_isotrophic,
     scene/gaussian_model.py:115-118); the gradient of `scaling` then has zeros in columns 1 and 2."""
+    if _inference(xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, viewmatrices, projmatrices):
+        m3, dc, opc, scc, rotc = (_f32c(t) for t in (xyz, f_dc, opacity, scaling, rotation))
+        rest = _f32c(f_rest) if f_rest is not None and f_rest.shape[1] > 0 else None
+        viewm, projm = _f32c(viewmatrices), _f32c(projmatrices)
+        K = viewm.shape[0]
+        campos = _f32c(raster_settings.campos.to(m3.device)).reshape(-1, 3)
+        if viewm.shape != (K, 4, 4) or projm.shape != (K, 4, 4) or campos.shape[0] != K:
+            raise RuntimeError("viewmatrices / projmatrices must be [K,4,4] and raster_settings.campos [K,3]")
+        with torch.no_grad():
+            _, color, depth, radii, _, _, _ = _forward_impl(
+                K, m3, dc.reshape(-1, 1, 3), None, opc.reshape(-1), scc, rotc, None, viewm, projm, campos, raster_settings,
+                raw={"scale_lb": float(scale_lb), "sh_rest": rest, "isotropic": bool(isotropic)}, forward_only=True)
+        return color, depth, radii
     return _RasterizeCloudK.apply(xyz, means2D, f_dc, f_rest, opacity, scaling, rotation, viewmatrices, projmatrices,
                                   raster_settings, scale_lb, bool(isotropic))
 

@@ -100,12 +100,19 @@ typedef struct DgsProblem {
                          *    whenever the three fit (DgsLayout.pack_*), and the value arrays stay unused; 1: always keep
                          *    the key (tile << 32 | emission index) and the Gaussian index in separate arrays.  Part of
                          *    the blob carving: must be the same in the forward and backward calls of one problem. */
+  int32_t forward_only; /* 1: an inference call -- the reference's test.py:117 / render_spiral.py:29 call render() under
+                         *    no_grad --: nothing is kept for a backward.  The compositing does not store final_T /
+                         *    n_contrib, preprocess does not store cov3D / the colour-activation mask, image_state needs
+                         *    only dgs_image_state_bytes_forward_only(W,H,K) bytes (the tile ranges; a full-size blob is
+                         *    accepted too), and dgs_backward* on such a problem returns DGS_E_ARG.  Outputs are
+                         *    bit-identical to forward_only = 0. */
   /* inputs, device pointers, fp32 contiguous */
   const float* means3D;        /* [P,3] */
   const float* shs;            /* [P,M,3] or NULL */
   const float* shs_rest;       /* raw_params = 1 only: [P,M-1,3] (then shs is [P,1,3]); else NULL */
   const float* colors_precomp; /* [P,3]   or NULL   (exactly one of shs / colors_precomp) */
-  const float* opacities;      /* [P] */
+  const float* opacities;      /* [P]; may be NULL in the backward calls of a raw_params = 0 problem (the reference's backward
+                                * is not handed them either, rasterize_points.cu:125-152) */
   const float* scales;         /* [P,3] or NULL */
   const float* rotations;      /* [P,4] or NULL */
   const float* cov3D_precomp;  /* [P,6] or NULL   (exactly one of scales+rotations / cov3D_precomp) */
@@ -243,6 +250,7 @@ const char* dgs_build_id(void);
 
 size_t dgs_geom_state_bytes(int32_t P, int32_t K);
 size_t dgs_image_state_bytes(int32_t W, int32_t H, int32_t K);
+size_t dgs_image_state_bytes_forward_only(int32_t W, int32_t H, int32_t K); /* DgsProblem.forward_only = 1: tile ranges only */
 size_t dgs_binning_state_bytes(uint64_t R, int32_t W, int32_t H, int32_t K);
 size_t dgs_backward_scratch_bytes(uint64_t R, int32_t P, int32_t K);
 /* wide_records: DgsProblem.wide_records of the problem the layout is for (it only decides pack_g_shift / pack_tile_shift;

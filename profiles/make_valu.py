@@ -70,8 +70,9 @@ for k, c in agg.items():
         e["lds_array_cycles"] = int(v["SQ_LDS_IDX_ACTIVE"])
         e["lds_bank_conflict_cycles"] = int(v.get("SQ_LDS_BANK_CONFLICT", 0))
         e["lds_busy_frac"] = round(v["SQ_LDS_IDX_ACTIVE"] / (256 * cyc), 3)
-    ck = "composite_fwd<false>" if k.startswith("composite_fwd_kernel<false>") else (
-        "composite_fwd<true>" if k.startswith("composite_fwd_kernel<true>") else (
+    # (round 6: the forward has a second template flag, KEEP = state for a backward; the training step runs <.., true>)
+    ck = "composite_fwd<false,true>" if k.startswith("composite_fwd_kernel<false, true>") else (
+        "composite_fwd<true,true>" if k.startswith("composite_fwd_kernel<true, true>") else (
             "composite_bwd<true,false>" if k.startswith("composite_bwd_kernel<true, false>") else None))
     if ck in census and cost and R_total:
         cen = census[ck]

@@ -1197,3 +1197,172 @@ def test_query_subframe_selection(gpu):
     assert len(full["render_pkgs"]) == 5 and full["depths"].shape == (5, 1, sc["H"], sc["W"])
     pp = m.query(0, "all", background=bg, post_process=lambda x: x * 2)
     assert torch.allclose(pp["blurred"], pp["subframes"].mean(0) * 2)
+
+
+# ----------------------------------------------------------------------- the reference's own L0 module, `_C`
+def _import_C():
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = os.path.join(root, "deblurgs_amd", "dropin")
+    if shim not in sys.path:
+        sys.path.insert(0, shim)
+    return importlib.import_module("diff_gaussian_rasterization._C")
+
+
+@pytest.mark.parametrize("variant", ["sh_scales", "colors_cov3D"])
+def test_l0_C_module_positional_calls_match_the_operator_and_the_oracle(gpu, variant):
+    """deblurgs_amd/dropin/diff_gaussian_rasterization/_C.py: rasterize_gaussians (22 positional arguments -> 7-tuple) and
+    rasterize_gaussians_backward (25 -> 10 tensors) exactly as the reference's unmodified Python calls them
+    (diff_gaussian_rasterization/__init__.py:66-101,120-160; absent inputs are EMPTY tensors), against the CPU oracle and,
+    bit for bit, against this package's own operator."""
+    import torch
+    from helpers import _t, hip_settings
+    from deblurgs_amd.diff_gaussian_rasterization import GaussianRasterizer
+    _C = _import_C()
+    sc = small_scene(P=1800, W=144, H=104, K=1, seed=12)
+    P, H, W = sc["P"], sc["H"], sc["W"]
+    rng = np.random.default_rng(3)
+    kw = {}
+    if variant == "colors_cov3D":
+        st0 = oracle_forward(sc, 0, render=False)
+        cov = st0["cov3D"].copy()
+        cov[st0["depths"] == 0] = np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], np.float32)
+        kw = dict(colors_precomp=rng.random((P, 3)).astype(np.float32), cov3D_precomp=cov)
+    gC, gD = _grads(sc, 1, seed=21)
+    ora = oracle_forward_backward(sc, 1, gC, gD, **kw)
+    empty = torch.Tensor([]).to("cuda")             # what GaussianRasterizer.forward substitutes for None (:222-233)
+    bg = _t(sc["bg"])
+    m3, op = _t(sc["means3D"]), _t(sc["opacities"])
+    sh = empty if "colors_precomp" in kw else _t(sc["sh"])
+    colors = _t(kw["colors_precomp"]) if "colors_precomp" in kw else empty
+    scales = empty if "cov3D_precomp" in kw else _t(sc["scales"])
+    rots = empty if "cov3D_precomp" in kw else _t(sc["rotations"])
+    cov3D = _t(kw["cov3D_precomp"]) if "cov3D_precomp" in kw else empty
+    view, proj, campos = _t(sc["viewmatrix"][0]), _t(sc["projmatrix"][0]), _t(sc["campos"][0])
+    deg = int(sc["sh_degree"]) if "sh_degree" in sc else 2
+    res = _C.rasterize_gaussians(bg, m3, colors, op, scales, rots, 1.0, cov3D, view, proj, float(sc["tanfovx"]),
+                                 float(sc["tanfovy"]), 0.01, float(sc["z_far"]), H, W, sh, deg, campos, False, False,
+                                 False)
+    assert len(res) == 7
+    R, color, depth, radii, geomB, binB, imgB = res
+    assert isinstance(R, int) and R > 0
+    assert color.shape == (3, H, W) and depth.shape == (1, H, W) and radii.shape == (P,) and radii.dtype == torch.int32
+    for b in (geomB, binB, imgB):
+        assert b.dtype == torch.uint8 and b.dim() == 1 and b.is_cuda
+    assert np.array_equal(radii.cpu().numpy(), ora["radii"][0])
+    un = unstable_pixels(ora["states"][0])
+    assert np.abs(color.cpu().numpy() - ora["color"][0]).max(axis=0)[~un].max() <= IMG_TOL
+    assert (np.abs(depth.cpu().numpy() - ora["depth"][0])[0][~un] / float(sc["z_far"])).max() <= DEPTH_TOL
+    grads = _C.rasterize_gaussians_backward(bg, m3, radii, colors, scales, rots, 1.0, cov3D, view, proj,
+                                            float(sc["tanfovx"]), float(sc["tanfovy"]), 0.01, float(sc["z_far"]),
+                                            _t(gC[0]), _t(gD[0]), sh, deg, campos, geomB, R, binB, imgB, False, False)
+    assert len(grads) == 10 and all(isinstance(g, torch.Tensor) for g in grads)
+    (g_m2, g_col, g_op, g_m3, g_cov, g_sh, g_sc, g_rot, g_view, g_proj) = grads
+    M = 0 if "colors_precomp" in kw else sc["sh"].shape[1]
+    assert [tuple(g.shape) for g in grads] == [(P, 3), (P, 3), (P, 1), (P, 3), (P, 6), (P, M, 3), (P, 3), (P, 4), (4, 4),
+                                               (4, 4)]
+    n = lambda t: t.cpu().numpy()
+    pairs = [("dL_dmeans2D", n(g_m2)[None]), ("dL_dopacities", n(g_op)), ("dL_dmeans3D", n(g_m3)),
+             ("dL_dviewmatrix", n(g_view)[None]), ("dL_dprojmatrix", n(g_proj)[None])]
+    if variant == "sh_scales":
+        pairs += [("dL_dsh", n(g_sh)), ("dL_dscales", n(g_sc)), ("dL_drotations", n(g_rot))]
+    else:
+        pairs += [("dL_dcolors_precomp", n(g_col)), ("dL_dcov3D_precomp", n(g_cov))]
+        # what the reference's kernels never write stays the zero tensor it allocated (rasterize_points.cu:162-176)
+        assert float(g_sc.abs().max()) == 0.0 and float(g_rot.abs().max()) == 0.0 and g_sh.numel() == 0
+    for key, got in pairs:
+        assert relerr(got.reshape(ora[key].shape), ora[key]) <= GRAD_TOL, key
+    # the same bits as this package's own K = 1 operator
+    rs = hip_settings(sc, 1, campos=sc["campos"][0:1])
+    m2 = torch.zeros((P, 3), device="cuda", requires_grad=True)
+    tin = [t.clone().requires_grad_(True) for t in (m3, op)]
+    c2, d2, r2 = GaussianRasterizer(rs)(tin[0], m2, tin[1], shs=None if M == 0 else sh, colors_precomp=colors if M == 0 else None,
+                                        scales=None if "cov3D_precomp" in kw else scales,
+                                        rotations=None if "cov3D_precomp" in kw else rots,
+                                        cov3D_precomp=cov3D if "cov3D_precomp" in kw else None, viewmatrix=view,
+                                        projmatrix=proj)
+    assert torch.equal(c2, color) and torch.equal(d2, depth) and torch.equal(r2, radii)
+    ((c2 * _t(gC[0])).sum() + (d2 * _t(gD[0])).sum()).backward()
+    assert torch.equal(tin[0].grad, g_m3) and torch.equal(m2.grad, g_m2) and torch.equal(tin[1].grad.reshape(P, 1), g_op)
+
+
+def test_l0_C_module_empty_cloud_and_mark_visible(gpu):
+    """P == 0: zero-filled images and gradients, R = 0 (rasterize_points.cu:70-71,85,162-176); mark_visible against the
+    oracle."""
+    import torch
+    from helpers import _t
+    from oracle import oracle
+    _C = _import_C()
+    sc = small_scene(P=400, W=64, H=48, K=1, seed=2)
+    H, W = sc["H"], sc["W"]
+    empty = torch.Tensor([]).to("cuda")
+    z3, z1, z4 = torch.zeros((0, 3), device="cuda"), torch.zeros((0, 1), device="cuda"), torch.zeros((0, 4), device="cuda")
+    view, proj, campos, bg = _t(sc["viewmatrix"][0]), _t(sc["projmatrix"][0]), _t(sc["campos"][0]), _t(sc["bg"])
+    R, color, depth, radii, gB, bB, iB = _C.rasterize_gaussians(
+        bg, z3, empty, z1, z3.clone(), z4, 1.0, empty, view, proj, float(sc["tanfovx"]), float(sc["tanfovy"]), 0.01,
+        float(sc["z_far"]), H, W, torch.zeros((0, 9, 3), device="cuda"), 2, campos, False, False, False)
+    assert R == 0 and radii.numel() == 0 and float(color.abs().max()) == 0.0 and float(depth.abs().max()) == 0.0
+    grads = _C.rasterize_gaussians_backward(bg, z3, radii, empty, z3.clone(), z4, 1.0, empty, view, proj,
+                                            float(sc["tanfovx"]), float(sc["tanfovy"]), 0.01, float(sc["z_far"]),
+                                            torch.ones((3, H, W), device="cuda"), torch.ones((1, H, W), device="cuda"),
+                                            torch.zeros((0, 9, 3), device="cuda"), 2, campos, gB, R, bB, iB, False, False)
+    assert len(grads) == 10 and all(float(g.abs().sum()) == 0.0 for g in grads)
+    assert tuple(grads[8].shape) == (4, 4) and tuple(grads[5].shape) == (0, 9, 3)
+    sc["means3D"][::3, 2] *= -1
+    vis = _C.mark_visible(_t(sc["means3D"]), view, proj)
+    assert vis.dtype == torch.bool and np.array_equal(vis.cpu().numpy(), oracle.mark_visible(sc["means3D"], sc["viewmatrix"][0]))
+    assert _C.mark_visible(z3, view, proj).numel() == 0
+
+
+# ------------------------------------------------------------------------------------ inference (forward-only) path
+def test_forward_only_path_is_bit_identical_and_keeps_no_backward_state(gpu):
+    """The reference's second use of the operator: test.py:117 / render_spiral.py:29 call render() under no_grad.  With no
+    input that can receive a gradient the entry points run DgsProblem.forward_only = 1: same images and radii bit for bit
+    (K = 1, K fused, raw-parameter cloud call), an image blob of the tile ranges alone, and a backward on such a problem is
+    refused with an argument error."""
+    import ctypes
+    import torch
+    from helpers import _t, hip_settings
+    from deblurgs_amd import _lib
+    from deblurgs_amd import diff_gaussian_rasterization as dgr
+    sc = small_scene(P=2500, W=176, H=120, K=3, seed=8)
+    P, K = sc["P"], 3
+    names = ["means3D", "opacities", "sh", "scales", "rotations"]
+    view, proj = _t(sc["viewmatrix"][:K]), _t(sc["projmatrix"][:K])
+    rsK = hip_settings(sc, K)._replace(campos=_t(sc["campos"][:K]))
+    outs = {}
+    for grad in (True, False):
+        inp = {n: _t(sc[n]).requires_grad_(grad) for n in names}
+        m2 = torch.zeros((K, P, 3), device="cuda", requires_grad=grad)
+        c, d, r = dgr.GaussianRasterizer(rsK).forward_subframes(inp["means3D"], m2, inp["opacities"], shs=inp["sh"],
+                                                                scales=inp["scales"], rotations=inp["rotations"],
+                                                                viewmatrices=view, projmatrices=proj)
+        assert c.requires_grad == grad
+        outs[grad] = (c.detach(), d.detach(), r)
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)
+    # K = 1 under no_grad with parameters that DO require grad (what test.py does)
+    inp = {n: _t(sc[n]).requires_grad_(True) for n in names}
+    rs1 = hip_settings(sc, 1, campos=sc["campos"][1:2])
+    with torch.no_grad():
+        c1, d1, r1 = dgr.GaussianRasterizer(rs1)(inp["means3D"], torch.zeros((P, 3), device="cuda"), inp["opacities"],
+                                                 shs=inp["sh"], scales=inp["scales"], rotations=inp["rotations"],
+                                                 viewmatrix=view[1], projmatrix=proj[1])
+    assert torch.equal(c1, outs[True][0][1]) and torch.equal(d1, outs[True][1][1]) and torch.equal(r1, outs[True][2][1])
+    # the C ABI: a forward_only problem's image blob is the tile ranges alone; its backward is an argument error
+    L = _lib.lib()
+    H, W = sc["H"], sc["W"]
+    small, full = L.dgs_image_state_bytes_forward_only(W, H, K), L.dgs_image_state_bytes(W, H, K)
+    assert small < full - 2 * K * H * W * 4 + 1024 and small >= K * ((W + 15) // 16) * ((H + 15) // 16) * 8
+    m3, sh, opc, scc, rotc = (_t(sc[n]) for n in ("means3D", "sh", "opacities", "scales", "rotations"))
+    R, color, depth, radii, geom, binning, image = dgr._forward_impl(
+        K, m3, sh, None, opc.reshape(-1), scc, rotc, None, view, proj, _t(sc["campos"][:K]), rsK, forward_only=True)
+    torch.cuda.synchronize()
+    assert image.numel() == small and torch.equal(color, outs[True][0]) and torch.equal(radii, outs[True][2])
+    prob = dgr._make_problem(K, m3, sh, None, opc.reshape(-1), scc, rotc, None, view, proj, _t(sc["campos"][:K]),
+                             dgr._RS(rsK, m3.device), geom, image, binning, getattr(R, "tile_cull", False))
+    prob.forward_only = 1
+    io = _lib.DgsBackwardIO()
+    rc = L.dgs_backward(ctypes.byref(prob), ctypes.byref(io), None)
+    assert rc == -1 and b"forward_only" in L.dgs_last_error()
