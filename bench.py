@@ -482,7 +482,10 @@ def run_rank(args):
     replayed_before = loop._fused.replayed if loop._fused is not None else 0
     # the timed region never carries the stage timers (their event pairs, and -- csrc/api.hip -- the compositing backward
     # as one launch instead of parts); the per-stage durations come from a second region right after it
-    dt = timed(args.steps, profile=False)
+    # the region is run three times back to back (one region of 20 steps is 0.2 s, and box-to-box noise is as
+    # large as a round's gain); every region is exactly args.steps steps between barriers; the headline is the MEDIAN region
+    region_dts = [timed(args.steps, profile=False) for _ in range(1 if emu is not None else 3)]
+    dt = sorted(region_dts)[len(region_dts) // 2]
     per_rank = None
     if world > 1:       # every rank's own time for the region (the headline divides by the slowest)
         mine = torch.tensor([stats["dt_local"]], dtype=torch.float64, device=dev)
@@ -595,25 +598,40 @@ def run_rank(args):
             extras["other_mode"] = {"sharding": other, "error": repr(ex)}
         sync()
 
-    ref_lists = None
-    if world == 1 and emu is None and not args.no_reference_lists and dgr.TILE_CULL:
-        dgr.TILE_CULL = False
-        if loop._fused is not None:
-            loop._fused._poll(block=True)
-            loop._fused.invalidate()        # the reference's lists are longer: learn their count afresh
+    # ---- the same step doing the REFERENCE's render work: the headline step leaves out what the
+    # training loss never reads -- the depth image (the reference composites it with every render, forward.cu:373,390, and
+    # query() returns it, scene/motion.py:145-158) -- and builds tile-culled lists.  Three more regions put the values with
+    # that work next to the headline: with depth, on the reference's lists, and both (the worst case).
+    def side_region(with_depth, reference_lists, note):
+        fs = loop._fused
+        if fs is None:
+            return None
+        keep_cull, keep_depth = dgr.TILE_CULL, fs.always_depth
+        fs._poll(block=True)
+        fs.invalidate()                     # other lists / other outputs: learn the counts afresh, drop captured steps
+        dgr.TILE_CULL = keep_cull and not reference_lists
+        fs.always_depth = bool(with_depth)
         try:
             for _ in range(3):
                 step()
             n0 = max(10, args.steps // 4)
             dt0 = timed(n0, profile=False)
-            ref_lists = {"value": round(K * n0 / dt0, 2), "ms_per_step": round(dt0 / n0 * 1e3, 3), "steps": n0,
-                         "note": "same step with DgsProblem.tile_cull = 0: the duplicate lists, sort keys and tile ranges "
-                                 "are the reference's bit for bit; images and gradients are bitwise equal to the headline "
-                                 "run's (tests/test_gpu_configs.py)"}
+            return {"value": round(K * n0 / dt0, 2), "ms_per_step": round(dt0 / n0 * 1e3, 3), "steps": n0,
+                    "depth_output": bool(with_depth), "tile_cull": bool(dgr.TILE_CULL), "note": note}
         finally:
-            dgr.TILE_CULL = True
-            if loop._fused is not None:
-                loop._fused._poll(block=True)
+            dgr.TILE_CULL, fs.always_depth = keep_cull, keep_depth
+            fs._poll(block=True)
+            fs.invalidate()
+
+    ref_lists = with_depth = ref_lists_depth = None
+    if world == 1 and emu is None and not args.no_reference_lists and dgr.TILE_CULL and not args.autograd_path:
+        with_depth = side_region(True, False, "the headline step + the K depth images composited and stored "
+                                              "(composite_fwd_kernel<true, true>), as every render of the reference does")
+        ref_lists = side_region(False, True, "same step with DgsProblem.tile_cull = 0: the duplicate lists, sort keys and "
+                                             "tile ranges are the reference's bit for bit; images and gradients are bitwise "
+                                             "equal to the headline run's (tests/test_gpu_configs.py)")
+        ref_lists_depth = side_region(True, True, "the reference's lists AND the depth images: every piece of render work "
+                                                  "the reference does per subframe (the worst case for this line)")
 
     if rank == 0:
         # R from a state-level forward (the operator keeps it in its autograd ctx)
@@ -639,12 +657,34 @@ def run_rank(args):
                 continue
             avg_ms = ms / calls
             gbs = bytes_by_stage[name] / (avg_ms * 1e-3) / 1e9
+            # model_GBps: the byte MODEL of SURVEY 8d over the measured time -- not achieved bandwidth (for geometry_bwd the
+            # model counts the K-summed Pv reads the fused kernel does not repeat); traffic_* (below) is counter-based
             stages[name] = {"avg_ms": round(avg_ms, 4), "launches": calls, "alg_bytes": int(bytes_by_stage[name]),
-                            "GBps": round(gbs, 1), "ms_per_step": round(ms / max(stats["profiled_steps"], 1), 4)}
+                            "model_GBps": round(gbs, 1), "ms_per_step": round(ms / max(stats["profiled_steps"], 1), 4),
+                            "traffic_bytes": None, "traffic_GBps": None}
             if name == "contrib_reduce":
                 moved = 48 * R_tot * frac_k + 64 * Pv_tot
                 stages[name]["moved_bytes"] = int(moved)
                 stages[name]["moved_GBps"] = round(moved / (avg_ms * 1e-3) / 1e9, 1)
+        # counter-based HBM bytes per step and stage: the committed FETCH_SIZE / WRITE_SIZE passes of this same command
+        # (profiles/traffic_rNN.json, `_per_step`; PMC counters cannot be collected from inside this process), over THIS
+        # run's stage times -- same provenance rule as roofline.traffic
+        traffic_doc, traffic_file = None, None
+        import glob as _glob
+        for path in sorted(_glob.glob(os.path.join(ROOT, "profiles", "traffic_r[0-9][0-9].json")))[::-1]:
+            try:
+                doc = json.load(open(path))
+            except Exception:
+                continue
+            if doc.get("_config") == args.config and "_per_step" in doc and world == 1 and emu is None \
+                    and args.sh_degree == doc.get("_sh_degree", 2):
+                traffic_doc, traffic_file = doc, os.path.basename(path)
+                break
+        if traffic_doc is not None:
+            for name, nbytes in traffic_doc["_per_step"].items():
+                if name in stages and stages[name]["ms_per_step"] > 0:
+                    stages[name]["traffic_bytes"] = int(nbytes)
+                    stages[name]["traffic_GBps"] = round(nbytes / (stages[name]["ms_per_step"] * 1e-3) / 1e9, 1)
         dom = max(stages, key=lambda n: stages[n]["avg_ms"])
         total_bytes = sum(bytes_by_stage.values())
         ms_per_step = dt / args.steps * 1e3
@@ -682,6 +722,9 @@ def run_rank(args):
                        "dropped_steps": (loop._fused.dropped if loop._fused is not None else 0),
                        "retried_steps": loop.retried,
                        "tile_cull": bool(dgr.TILE_CULL),
+                       # what the timed step renders: the K colour images; the depth images only if something reads them
+                       # (the reference always composites them: see value_with_depth)
+                       "depth_output": bool(loop._fused is not None and loop._fused.always_depth) or args.autograd_path,
                        # csrc/api.hip: how many parts the timed region's compositing backward ran in (1 = one launch; > 1: a
                        # large view enqueued eagerly, each part's row totals on a side stream beside the next part's
                        # compositing, bit-identical -- DESIGN.md 7); the per-stage averages below are taken with the stage
@@ -690,7 +733,7 @@ def run_rank(args):
                        # executable graph does not give its memory back on this runtime, tools/graph_fork_leak.hip)
                        "backward_in_parts": (int(_lib.lib().dgs_backward_parts(_lib.context(), int(round(K * frac_k)), int(R_tot * frac_k),
                                                                                int(bool(dgr.TILE_CULL)))) if
-                                             (not graph_info or os.environ.get("DGS_BWD_OVERLAP") == "3") else 1),
+                                             (not graph_info or _lib.context_overlap_mode() == 3) else 1),
                        "profiled_region_ms_per_step": stats.get("profiled_ms_per_step"),
                        "sharding": (args.shard if world > 1 else "none"), "ranks_in_process_group": world,
                        "ar_chunks": (args.ar_chunks if world > 1 and loop._fused is not None else None),
@@ -698,25 +741,45 @@ def run_rank(args):
                        "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
                        "Pv_total": Pv_tot, "R_total": int(R_tot),
                        "pixel_gaussian_evals_upper_bound_per_step": int(256 * R_tot)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(stages[dom]["GBps"] / HBM_PEAK_GBS, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": stages[dom]["model_GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(stages[dom]["model_GBps"] / HBM_PEAK_GBS, 5), "traffic": None,
                          "alg_bytes_per_launch": stages[dom]["alg_bytes"], "avg_launch_ms": stages[dom]["avg_ms"],
                          "avg_launch_ms_source": "HIP events on the launch stream inside this run (dgs_profile_*)" +
                                                  (", recorded in the eager region that follows the replayed one" if graph_info else "") +
                                                  "; with the stage timers on the compositing backward runs as ONE launch "
                                                  "per step (as it does inside a captured graph; an eagerly enqueued step "
                                                  "runs it in parts, see config.backward_in_parts), and "
-                                                 "profiles/r05_kernel_stats.csv is taken the same way (DGS_BWD_OVERLAP=0)",
+                                                 "profiles/r06_kernel_stats.csv is taken the same way (DGS_BWD_OVERLAP=0)",
                          "note": "the dominant kernel (compositing) is bound by VALU issue, not by HBM (SURVEY 8d): `frac` is "
                                  "the honest HBM fraction of its byte model, `valu` (when the round's PMC profile of this "
                                  "config is committed) the fraction of the VALU issue peak it reaches"},
             "pipeline_hbm": {"alg_bytes_per_step": int(total_bytes),
-                             "achieved_GBps": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                             "frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                             "model_GBps": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                             "frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                             # counter-based: every kernel of the step (loss image and Adam included), committed passes
+                             "traffic_bytes_per_step": (int(traffic_doc["_per_step_total"]) if traffic_doc is not None
+                                                        else None),
+                             "traffic_GBps": (round(traffic_doc["_per_step_total"] / (ms_per_step * 1e-3) / 1e9, 1)
+                                              if traffic_doc is not None else None),
+                             "traffic_source": (f"profiles/{traffic_file}: {traffic_doc.get('_source', '')}"
+                                                if traffic_doc is not None else None)},
+            "regions": {"ms_per_step": [round(x / args.steps * 1e3, 3) for x in region_dts],
+                        "min_ms_per_step": round(min(region_dts) / args.steps * 1e3, 3),
+                        "median_ms_per_step": round(ms_per_step, 3),
+                        "max_ms_per_step": round(max(region_dts) / args.steps * 1e3, 3),
+                        "value_min": round((K if subframes_mode else world * K) * args.steps / max(region_dts), 2),
+                        "value_max": round((K if subframes_mode else world * K) * args.steps / min(region_dts), 2),
+                        "note": "the timed region (exactly `steps` steps between barriers) run three times back to back; "
+                                "value / ms_per_step are the median region's"},
+            "build_id": _lib.build_id(),
             "stages": stages,
         }
+        if with_depth is not None:
+            result["value_with_depth"] = with_depth
         if ref_lists is not None:
             result["value_reference_lists"] = ref_lists
+        if ref_lists_depth is not None:
+            result["value_reference_lists_with_depth"] = ref_lists_depth
         if per_rank is not None:
             result["config"]["per_rank"] = per_rank
         if world > 1:
@@ -824,7 +887,7 @@ def main():
     if selftest:
         kind, _, who = selftest.partition(":")
         if kind == "die" and os.environ.get("RANK") == who:
-            sys.exit(3)
+            sys.exit(5)                # (any code but 0 and EXIT_EXTRAS_HUNG)
         time.sleep(3600)
     run_rank(args)
 

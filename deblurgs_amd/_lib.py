@@ -235,6 +235,7 @@ def build_id():
 #   DGS_BWD_OVERLAP = 0 | 1 | 2 | 3    DgsContextOptions.bwd_overlap (default 1)
 #   DGS_BWD_PARTS   = "10,4"           DgsContextOptions.bwd_parts (subframes per part; the rest is the last part)
 _contexts = {}
+_context_modes = {}     # handle value -> bwd_overlap it was created with (the struct is opaque on this side)
 
 
 def context_options_from_env(environ=None):
@@ -252,10 +253,12 @@ def create_context(options=None):
     h = ctypes.c_void_p()
     check(lib().dgs_context_create(ctypes.byref(options) if options is not None else None, ctypes.byref(h)),
           "dgs_context_create")
+    _context_modes[h.value] = int(options.bwd_overlap) if options is not None else 1
     return h
 
 
 def destroy_context(h):
+    _context_modes.pop(h.value, None)
     check(lib().dgs_context_destroy(h), "dgs_context_destroy")
 
 
@@ -270,6 +273,44 @@ def context(device=None):
     if key not in _contexts:
         _contexts[key] = create_context(context_options_from_env())
     return _contexts[key]
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def context_options(bwd_overlap=1, bwd_parts=(), device=None):
+    """Swaps the package's context of a device for one with these options for the duration of the block (tests and A/B
+    tools: what DGS_BWD_OVERLAP / DGS_BWD_PARTS do for a whole process).  The device must be idle at both ends."""
+    import torch
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    key = int(device)
+    o = DgsContextOptions()
+    o.bwd_overlap = int(bwd_overlap)
+    o.bwd_n_parts = min(len(bwd_parts), MAX_BWD_PARTS - 1)
+    for i in range(o.bwd_n_parts):
+        o.bwd_parts[i] = int(bwd_parts[i])
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    old = _contexts.get(key)
+    _contexts[key] = create_context(o)
+    try:
+        yield _contexts[key]
+    finally:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        destroy_context(_contexts[key])
+        if old is not None:
+            _contexts[key] = old
+        else:
+            del _contexts[key]
+
+
+def context_overlap_mode(device=None):
+    """bwd_overlap of the package's context for the device."""
+    h = context(device)
+    return _context_modes.get(h.value, 1)
 
 
 def reset_contexts():

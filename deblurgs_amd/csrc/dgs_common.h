@@ -24,7 +24,8 @@ struct __attribute__((aligned(16))) DgsRow {
   float x, y;            // pixel-space mean (ndc2Pix)
   float cx, cy, cz, op;  // conic (a, b, c of the inverse 2-D covariance) and opacity
   float r, g, b, depth;  // activated colour, view-space depth
-  uint32_t dup_offset;   // unused (the first-duplicate offsets live in DgsCarve::point_offsets, by natural index)
+  uint32_t dup_offset;   // relu colour activation: bits 0..2 = the clamp mask of r, g, b (1 = the channel passed the clamp:
+                         // what the SH backward multiplies by, backward.cu:35-47); 0 with the sigmoid activation
   int32_t radius;        // ceil(3 sigma_max) in pixels
 };
 static_assert(sizeof(DgsRow) == 4 * DGS_ROW_F, "row must be 48 bytes");

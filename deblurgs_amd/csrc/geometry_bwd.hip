@@ -280,6 +280,7 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
   struct RowPf {
     uint32_t nt;
     int32_t rad;    // fused densification statistics only
+    uint32_t cmask; // relu activation: clamp-mask bits of the pair's colour (DgsRow::dup_offset)
     float4 ga, gb;  // x, y, cx, cy | cz, op, r, g
   };
   // densification statistics (train.py:188-193, scene/gaussian_model.py:456-458; DgsBackwardIO.stats_*): the thread has
@@ -300,6 +301,7 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     r.rad = (stats && valid) ? radii[o] : 0;
     r.ga = rowp[0];   // unconditional (no dependent hop); rows of invisible pairs are never used
     r.gb = rowp[1];
+    r.cmask = (shs != nullptr && !v.use_sigmoid) ? rows[o].dup_offset : 0u;
     return r;
   };
   struct SumPf {
@@ -331,7 +333,9 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
     const SumPf cs = sum1;
     row1 = row2;
     if (k + 2 < v.K) row2 = load_row(k + 2);
-    if (k + 1 < v.K) sum1 = load_sums(k + 1);   // (two subframes ahead, 249 VGPRs: same time -- the kernel waits on its own
+    // (the slot of an invisible pair -- 22 % of them at the metric size, 64 bytes each -- is not fetched: row1 is subframe
+    // k + 1's row by now, loaded two iterations ago)
+    if (k + 1 < v.K && row1.nt > 0) sum1 = load_sums(k + 1);   // (two subframes ahead, 249 VGPRs: same time -- the kernel waits on its own
                                                 // dependent arithmetic at two waves per SIMD, not on these loads; without
                                                 // any SH state, 149 VGPRs and three waves, it still takes 0.50 of 0.68 ms)
     const uint32_t ntiles = cur.nt;
@@ -434,7 +438,14 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
       dmean_z += (F[8] * m_w - F[11] * mul1) * g2x + (F[9] * m_w - F[11] * mul2) * g2y + ddepth * V[10];
 
       if (!SPLIT && shs != nullptr) {  // computeColorFromSH backward (backward.cu:20-140)
-        DGS_SH_BACKWARD(pre_sigmoid + 3 * o)
+        // the activation's derivative input: the pre-activation values (sigmoid) or the clamp mask (relu; from the row)
+        float ps3[3];
+        if (v.use_sigmoid) {
+          ps3[0] = pre_sigmoid[3 * o]; ps3[1] = pre_sigmoid[3 * o + 1]; ps3[2] = pre_sigmoid[3 * o + 2];
+        } else {
+          ps3[0] = (cur.cmask & 1u) ? 1.0f : 0.0f; ps3[1] = (cur.cmask & 2u) ? 1.0f : 0.0f; ps3[2] = (cur.cmask & 4u) ? 1.0f : 0.0f;
+        }
+        DGS_SH_BACKWARD(ps3)
       }
       a_col[0] += dcol[0];
       a_col[1] += dcol[1];
@@ -517,9 +528,16 @@ geometry_bwd_kernel(DgsView v, const float* __restrict__ means3D, const float* _
       const float4* cp = reinterpret_cast<const float4*>(contrib + o * DGS_SUMS_F);
       f.r1 = cp[1];
       f.r2 = cp[2];
-      f.ps[0] = pre_sigmoid[3 * o];
-      f.ps[1] = pre_sigmoid[3 * o + 1];
-      f.ps[2] = pre_sigmoid[3 * o + 2];
+      if (v.use_sigmoid) {
+        f.ps[0] = pre_sigmoid[3 * o];
+        f.ps[1] = pre_sigmoid[3 * o + 1];
+        f.ps[2] = pre_sigmoid[3 * o + 2];
+      } else {   // relu: the clamp mask rides in the row's spare word
+        const uint32_t cm = rows[o].dup_offset;
+        f.ps[0] = (cm & 1u) ? 1.0f : 0.0f;
+        f.ps[1] = (cm & 2u) ? 1.0f : 0.0f;
+        f.ps[2] = (cm & 4u) ? 1.0f : 0.0f;
+      }
       return f;
     };
 #ifndef DGS_SH_PREFETCH

@@ -232,7 +232,12 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
           row.g = cg;
           row.b = cbl;
           row.depth = vz;
-          row.dup_offset = 0;
+          // relu colour activation: the three clamp-mask bits the backward needs ride in the row's spare word (round 6:
+          // the [K,P,3] float mask array -- 180 MB written here and read back by geometry_bwd at the metric size -- is then
+          // neither written nor read); the sigmoid activation keeps its pre-activation values in pre_sigmoid
+          row.dup_offset = v.use_sigmoid ? 0u
+                                         : ((pre_out[0] != 0.0f ? 1u : 0u) | (pre_out[1] != 0.0f ? 2u : 0u) |
+                                            (pre_out[2] != 0.0f ? 4u : 0u));
           row.radius = (int)my_radius;
           out_radius = (int)my_radius;
           out_tiles = area;
@@ -269,7 +274,7 @@ preprocess_fwd_kernel(DgsView v, const float* __restrict__ means3D, const float*
         const int e = i * 64 + lane;
         if (e < 3 * wave_count) {
           dst[e] = s_row[wv_][e];
-          if (pre_sigmoid != nullptr) dpre[e] = s_pre[wv_][e];
+          if (pre_sigmoid != nullptr && v.use_sigmoid) dpre[e] = s_pre[wv_][e];
         }
       }
       __builtin_amdgcn_wave_barrier();

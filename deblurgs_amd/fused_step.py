@@ -75,6 +75,10 @@ class FusedStep:
         # and beside its row totals the eagerly enqueued step is the faster one at these sizes (metric configuration:
         # 10.54-10.62 against 10.76-10.87 ms replayed).  True (TrainingLoop(graph="always")) captures anyway.
         self.capture_large = False
+        # the reference composites the depth image with every render (forward.cu:373,390) and query() returns it; the default
+        # loss never reads it (train.py:150-153, lambda_depth_tv = 0), so the fused step leaves it out unless asked
+        # (run(need_depth=True), lambda_depth_tv > 0) -- or unless this is set (bench.py's value_with_depth region)
+        self.always_depth = False
         self.eager_preferred = 0    # steps declined for that reason
         self._sel_cache = {}
         self._side = None           # side stream of the chunked gradient all-reduce
@@ -140,7 +144,7 @@ class FusedStep:
         return slot
 
     def _eager_is_faster(self, K, cap, cull):
-        if self.capture_large or os.environ.get("DGS_BWD_OVERLAP") == "3":   # (=3: the library forks inside a capture too)
+        if self.capture_large or _lib.context_overlap_mode() == 3:   # (3: the library forks inside a capture too)
             return False
         if _lib.lib().dgs_backward_parts(_lib.context(), int(K), int(cap), int(bool(cull))) <= 1:
             return False
@@ -277,7 +281,7 @@ class FusedStep:
         gkey = (int(cam_idx), subframe_indice, int(cloud.active_sh_degree), bool(m.is_optimizing()),
                 bool(m.curve_random_sample), cap, self._generation, gt.data_ptr(), bool(cull), bool(dgr.WIDE_RECORDS),
                 tuple(p.data_ptr() for p in hot), tuple(signature),
-                tuple(t.data_ptr() for t in stats) if stats is not None else ())
+                tuple(t.data_ptr() for t in stats) if stats is not None else (), bool(self.always_depth))
         ent = self._graphs.get(gkey)
         if ent is None:
             ent = self._capture(gkey, cam_idx, gt, subframe_indice, cap, optimizer, tail, stats)
@@ -351,7 +355,7 @@ class FusedStep:
         gkey = ("front", int(cam_idx), subframe_indice, int(cloud.active_sh_degree), bool(m.is_optimizing()),
                 bool(m.curve_random_sample), cap, self._generation, gt.data_ptr(), bool(cull), bool(dgr.WIDE_RECORDS),
                 tuple(p.data_ptr() for p in hot), chunks, float(self.lambda_hinge),
-                None if shard is None else (int(shard[0]), int(shard[1])))
+                None if shard is None else (int(shard[0]), int(shard[1])), bool(self.always_depth))
         ent = self._graphs.get(gkey)
         if ent is None:
             ent = self._capture_front(gkey, cam_idx, gt, subframe_indice, cap, ar, K_total, shard)
@@ -590,7 +594,7 @@ class FusedStep:
         color = torch.empty((K, 3, H, W), **f32)
         # the depth images are rendered only if somebody reads them (the reference always renders them, and its default
         # loss, lambda_depth_tv = 0, never looks at them: train.py:150-153)
-        depth = torch.empty((K, 1, H, W), **f32) if (need_depth or lambda_depth_tv > 0.0) else None
+        depth = torch.empty((K, 1, H, W), **f32) if (need_depth or self.always_depth or lambda_depth_tv > 0.0) else None
         radii = (torch.empty((K, P), dtype=torch.int32, device=dev) if (_cap is None or "radii" not in _cap)
                  else _cap["radii"][:K])
         geom = torch.empty(L.dgs_geom_state_bytes(P, K), dtype=torch.uint8, device=dev)

@@ -268,6 +268,18 @@ int dgs_oracle_threads(void) {
   return 1;
 #endif
 }
+// OpenMP threads of the parallel regions the CALLING host thread opens from now on (the ICV is per thread: several host
+// threads may each run one subframe on a share of the cores).  Round 6: on the 256-thread host of the GPU box one
+// subframe's backward takes 1.85 s with all 256 threads and 0.84 s with 32 (profiles/oracle_threads_r06.txt).
+int dgs_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
 
 uint32_t dgs_oracle_higher_msb(uint32_t n) { return getHigherMsb(n); }
 

@@ -25,9 +25,26 @@ STAGE_OF = {
     "adam_kernel": "adam", "dsort_scatter_kernel": "depth_order(scatter)", "dsort_hist_kernel": "depth_order(hist)",
 }
 STREAMING = {"blur_loss", "sort(hist)", "sort(scatter)", "adam"}
+# round 6: every kernel of the step, and the stage of bench.py's `stages` it belongs to -- `_per_step` sums ALL launches of
+# a stage's kernels over the profiled steps and divides by the step count (= launches of the compositing backward, which
+# runs once per step under DGS_BWD_OVERLAP=0); bench.py divides by its own per-step stage time: counter-based GB/s
+STAGE_OF.update({
+    "scan_reduce_kernel": "scan(aux)", "scan_top_kernel": "scan(aux)", "scan_apply_kernel": "scan(aux)",
+    "scan_apply_self_kernel": "scan(aux)", "colscan_chunk_kernel": "sort(aux)", "colscan_top_kernel": "sort(aux)",
+    "dsort_colscan_chunk_kernel": "depth_order(aux)", "dsort_colscan_top_kernel": "depth_order(aux)",
+    "dsort_copy_if_wide_kernel": "depth_order(aux)", "pose_grad_reduce_kernel": "geometry_bwd(pose)",
+})
+BENCH_STAGE = {
+    "preprocess": "preprocess", "scan(aux)": "scan", "duplicate": "duplicate", "sort(hist)": "sort", "sort(scatter)": "sort",
+    "sort(aux)": "sort", "ranges": "ranges", "composite_fwd": "composite_fwd", "composite_bwd": "composite_bwd",
+    "geometry_bwd(kernel)": "geometry_bwd", "geometry_bwd(pose)": "geometry_bwd",
+    "geometry_bwd(contrib_reduce)": "contrib_reduce", "depth_order(hist)": "depth_order",
+    "depth_order(scatter)": "depth_order", "depth_order(aux)": "depth_order", "tile_cull(count)": "tile_cull",
+    "tile_cull(gather)": "tile_cull", "blur_loss": "(loss image)", "adam": "(adam)",
+}
 
 
-def per_kernel(d, counter):
+def per_kernel(d, counter, totals=False):
     tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
     files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     for f in files[-1:]:      # the newest pass only (gpurun merges, it does not replace, earlier passes' files)
@@ -41,6 +58,8 @@ def per_kernel(d, counter):
                 continue
             tot[key] += float(r["Counter_Value"]) * 1024.0
             cnt[key] += 1
+    if totals:
+        return dict(tot), dict(cnt)
     return {k: tot[k] / cnt[k] for k in tot}
 
 
@@ -58,6 +77,25 @@ def main():
         w = write.get(k, 0.0)
         out["_detail"][k] = {"fetch_bytes": int(f), "write_bytes": int(w)}
         out[k] = int(f + w)
+    # per step and bench stage: every launch counted
+    ftot, fcnt = per_kernel(sys.argv[1], "FETCH_SIZE", totals=True)
+    wtot, wcnt = per_kernel(sys.argv[2], "WRITE_SIZE", totals=True)
+    steps_f, steps_w = max(fcnt.get("composite_bwd", 1), 1), max(wcnt.get("composite_bwd", 1), 1)
+    # (the profiled command also runs two probe forwards outside its steps: a kernel's bytes per step are its average per
+    # launch times its launches per step, the latter rounded -- 45 launches over 43 steps is one per step)
+    per_step = collections.defaultdict(float)
+    for k, v in ftot.items():
+        per_launch = v / fcnt[k] * (2.0 if k in STREAMING else 1.0)
+        per_step[BENCH_STAGE.get(k, "(other)")] += per_launch * max(1, round(fcnt[k] / steps_f))
+    for k, v in wtot.items():
+        per_step[BENCH_STAGE.get(k, "(other)")] += v / wcnt[k] * max(1, round(wcnt[k] / steps_w))
+    out["_per_step"] = {k: int(v) for k, v in sorted(per_step.items())}
+    out["_per_step_total"] = int(sum(per_step.values()))
+    out["_per_step_note"] = ("HBM-side bytes per training step by bench.py stage, all launches of the stage's kernels "
+                             f"(profiled steps: {steps_f} in the FETCH pass, {steps_w} in the WRITE pass); '(loss image)' and "
+                             "'(adam)' are the step's two kernels outside the rasteriser's stage timers")
+    if len(sys.argv) > 5:
+        out["_sh_degree"] = int(sys.argv[5])
     rnd = sys.argv[4] if len(sys.argv) > 4 else "r03"
     json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"traffic_{rnd}.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))

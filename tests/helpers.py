@@ -171,6 +171,11 @@ def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_p
         point_list=view(binning, L.point_list, R * 4, np.uint32, (R,)),
         sort_bits=L.sort_bits, T=T,
     )
+    if not use_sigmoid:
+        # relu colour activation (round 6): the clamp mask the backward multiplies by rides in the row's spare word (bits
+        # 0..2 of word 10) instead of a [K,P,3] float array; the tests read it in the oracle's form
+        bits = st["rows_u32"][:, :, 10]
+        st["pre_sigmoid"] = np.stack([(bits >> c) & 1 for c in range(3)], axis=-1).astype(np.float32)
     st["compact_keys"] = False
     if R_obj.tile_cull and L.pack_tile_shift > 0:
         # compact keys (DgsLayout.pack_*): tile | Gaussian | emission index in one word and no value array; the tests
@@ -327,8 +332,9 @@ class OracleRun:
         self.scene, self.K, self.kw = scene, K, kw
         oracle.use_openmp(True)
         try:
-            self.states = [oracle_forward(scene, k, **kw) for k in range(K)]
-            self.unstable = [oracle.unstable(st) for st in self.states]
+            # (subframes side by side, a few dozen OpenMP threads each: oracle.map_subframes)
+            self.states = oracle.map_subframes(lambda k: oracle_forward(scene, k, **kw), range(K))
+            self.unstable = oracle.map_subframes(oracle.unstable, self.states)
         finally:
             oracle.use_openmp(False)
         for st in self.states:
@@ -360,7 +366,8 @@ class OracleRun:
             for mode in ("double", "f32", "fma"):
                 oracle.set_accum_f32(mode == "f32")
                 oracle.use_fma(mode == "fma")
-                gs = [oracle.backward(st, gC[k], None if gD is None else gD[k]) for k, st in enumerate(self.states)]
+                gs = oracle.map_subframes(lambda k: oracle.backward(self.states[k], gC[k], None if gD is None else gD[k]),
+                                          range(len(self.states)))
                 r = {}
                 for name, key in (("dL_dmeans3D", "dL_dmeans3D"), ("dL_dopacities", "dL_dopacity"), ("dL_dsh", "dL_dsh"),
                                   ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations"),

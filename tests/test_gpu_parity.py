@@ -1308,7 +1308,7 @@ def test_l0_C_module_empty_cloud_and_mark_visible(gpu):
                                             torch.ones((3, H, W), device="cuda"), torch.ones((1, H, W), device="cuda"),
                                             torch.zeros((0, 9, 3), device="cuda"), 2, campos, gB, R, bB, iB, False, False)
     assert len(grads) == 10 and all(float(g.abs().sum()) == 0.0 for g in grads)
-    assert tuple(grads[8].shape) == (4, 4) and tuple(grads[5].shape) == (0, 9, 3)
+    assert tuple(grads[8].shape) == (4, 4) and tuple(grads[5].shape) == (0, 0, 3)   # M = 0 when sh.size(0) == 0 (rasterize_points.cu:157-161)
     sc["means3D"][::3, 2] *= -1
     vis = _C.mark_visible(_t(sc["means3D"]), view, proj)
     assert vis.dtype == torch.bool and np.array_equal(vis.cpu().numpy(), oracle.mark_visible(sc["means3D"], sc["viewmatrix"][0]))

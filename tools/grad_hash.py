@@ -12,18 +12,25 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+def hashes(name="cfg2"):
+    """One line per output: name, SHA-256 prefix, shape."""
     from deblurgs_amd import synthetic
     import helpers
-    name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
     sc = synthetic.make_config(name, seed=0)
     K = sc["K"]
     rng = np.random.default_rng(5)
     dL = rng.standard_normal((K, 3, sc["H"], sc["W"])).astype(np.float32)
     out = helpers.hip_cloud_forward_backward(sc, K, dL, keep_on_device=True)
+    lines = []
     for key in sorted(out):
         a = out[key].cpu().numpy()
-        print(f"{key:16s} {hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:24]}  {a.shape}")
+        lines.append(f"{key:16s} {hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:24]}  {a.shape}")
+    return lines
+
+
+def main():
+    for ln in hashes(sys.argv[1] if len(sys.argv) > 1 else "cfg2"):
+        print(ln)
 
 
 if __name__ == "__main__":
