@@ -36,6 +36,7 @@
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
+#include <memory>
 #include <parallel/algorithm>
 #endif
 
@@ -468,7 +469,13 @@ void dgs_oracle_render_backward(int W, int H, const uint32_t* ranges, const uint
   // one row of double accumulators per (tile, Gaussian) duplicate = per position of the sorted list
   uint32_t Rtot = 0;
   for (int t = 0; t < gx * gy; t++) Rtot = std::max(Rtot, ranges[2 * t + 1]);
-  std::vector<double> dacc((size_t)Rtot * 10, 0.0);
+  // (allocated without a serial zero-fill: 320 MB per metric subframe; the pages are first touched -- and zeroed -- in
+  // parallel.  Round 6: the serial fill and the serial per-Gaussian sum below were most of what was left of a call once
+  // the tile loop ran on a few dozen threads)
+  std::unique_ptr<double[]> dacc_mem(new double[(size_t)Rtot * 10]);
+  double* const dacc = dacc_mem.get();
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)Rtot * 10; i++) dacc[i] = 0.0;
   const bool f32 = g_accum_f32;  // emulate fp32 accumulation in the same order (noise-floor estimate)
 #define DGS_ACC(slot, dst, val)                                   \
   do {                                                            \
@@ -556,15 +563,25 @@ void dgs_oracle_render_backward(int W, int H, const uint32_t* ranges, const uint
     uint32_t maxg = 0;
     for (uint32_t s = 0; s < Rtot; s++) maxg = std::max(maxg, point_list[s]);
     std::vector<double> gsum(((size_t)maxg + 1) * 10, 0.0);
-    for (uint32_t s = 0; s < Rtot; s++) {
-      const size_t g = point_list[s];
-      for (int i = 0; i < 10; i++) {
-        gsum[g * 10 + i] += dacc[(size_t)s * 10 + i];
-        if (f32) gsum[g * 10 + i] = (double)(float)gsum[g * 10 + i];
+    std::vector<uint8_t> seen((size_t)maxg + 1, 0);
+    // every thread owns a contiguous range of Gaussians and walks the whole list for them: each Gaussian's rows are still
+    // added in list order by one thread (same sums as the serial loop, bit for bit, for any thread count)
+#pragma omp parallel
+    {
+      const int nt = omp_get_num_threads(), me = omp_get_thread_num();
+      const uint64_t span = (uint64_t)maxg + 1;
+      const uint32_t g0 = (uint32_t)(span * me / nt), g1 = (uint32_t)(span * (me + 1) / nt);
+      for (uint32_t s = 0; s < Rtot; s++) {
+        const uint32_t gi = point_list[s];
+        if (gi < g0 || gi >= g1) continue;
+        const size_t g = gi;
+        seen[g] = 1;
+        for (int i = 0; i < 10; i++) {
+          gsum[g * 10 + i] += dacc[(size_t)s * 10 + i];
+          if (f32) gsum[g * 10 + i] = (double)(float)gsum[g * 10 + i];
+        }
       }
     }
-    std::vector<uint8_t> seen((size_t)maxg + 1, 0);
-    for (uint32_t s = 0; s < Rtot; s++) seen[point_list[s]] = 1;
 #pragma omp parallel for schedule(static)
     for (int64_t g = 0; g <= (int64_t)maxg; g++) {
       if (!seen[g]) continue;

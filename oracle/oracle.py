@@ -51,9 +51,11 @@ def _load(path):
     return L
 
 
-# OpenMP threads per oracle call and host threads that may run calls side by side (subframes are independent): the
-# oracle's loops stop scaling -- and then lose -- beyond a few dozen threads (GPU box, 256 hardware threads, one metric
-# subframe: backward 1.85 s with 256 threads, 1.10 s with 128, 0.84 s with 32; profiles/oracle_threads_r06.txt)
+# OpenMP threads per oracle call.  The oracle's loops stop scaling -- and then lose -- beyond a few dozen threads: on the GPU
+# box's host (2 x EPYC 9575F, 256 hardware threads) eight metric subframes take, forward / masks / backward,
+# 15.5 / 10.2 / 14.3 s with 256 threads and 5.1 / 5.9 / 6.9 s with 32; running subframes SIDE BY SIDE on host threads of
+# their own (8 x 32, 16 x 16, active or passive waiting) is slower than one after the other on 32 (8.4 / 8.9 / 9.0 s):
+# profiles/oracle_threads_r06.txt.  DGS_ORACLE_THREADS overrides.
 MAX_THREADS_PER_CALL = int(os.environ.get("DGS_ORACLE_THREADS", "32"))
 
 
@@ -61,35 +63,18 @@ def threads_per_call():
     return max(1, min(MAX_THREADS_PER_CALL, os.cpu_count() or 1))
 
 
-def parallel_calls():
-    """How many oracle calls (one subframe each) may run side by side on this host."""
-    return max(1, min(8, (os.cpu_count() or 1) // threads_per_call()))
-
-
 def set_threads(n=None):
-    """OpenMP threads for the oracle calls of the CALLING host thread (per-thread setting)."""
+    """OpenMP threads for the oracle calls of the CALLING host thread (the setting is per thread)."""
     L = lib()
     L.dgs_oracle_set_threads.restype = ctypes.c_int
     return int(L.dgs_oracle_set_threads(int(n if n is not None else threads_per_call())))
 
 
 def map_subframes(fn, items):
-    """fn over the items (one oracle call each), in order, on parallel_calls() host threads with threads_per_call() OpenMP
-    threads each (ctypes releases the GIL during a call).  The mode switches (use_openmp / use_fma / set_accum_f32) are
-    process-wide and must not change while this runs."""
-    items = list(items)
-    n = min(parallel_calls(), len(items))
-    if not _use_omp or n <= 1:
-        if _use_omp:
-            set_threads()
-        return [fn(x) for x in items]
-    from concurrent.futures import ThreadPoolExecutor
-
-    def work(x):
+    """fn over the items (one oracle call each), one after the other, with the thread count that serves a call best."""
+    if _use_omp:
         set_threads()
-        return fn(x)
-    with ThreadPoolExecutor(max_workers=n) as ex:
-        return list(ex.map(work, items))
+    return [fn(x) for x in items]
 
 
 def use_openmp(on=True):
