@@ -50,7 +50,8 @@ class DgsContextOptions(ctypes.Structure):
 class DgsForwardOut(ctypes.Structure):
     _fields_ = [("out_color", ctypes.c_void_p), ("out_depth", ctypes.c_void_p), ("radii", ctypes.c_void_p),
                 ("num_rendered_host", ctypes.c_void_p), ("drop_counter", ctypes.c_void_p),
-                ("status_dev", ctypes.c_void_p), ("status_host_indirect", ctypes.c_void_p)]
+                ("status_dev", ctypes.c_void_p), ("status_host_indirect", ctypes.c_void_p),
+                ("debug_contrib_checksum", ctypes.c_void_p)]
 
 
 class DgsBackwardIO(ctypes.Structure):

@@ -702,6 +702,9 @@ static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, ui
   int rc = check_problem(p);
   if (rc != DGS_OK) return rc;
   if (out == nullptr || out->out_color == nullptr) return fail(DGS_E_ARG, "DgsForwardOut: out_color is null");
+  if (out->debug_contrib_checksum != nullptr && (p->tile_cull || p->forward_only || out->out_depth == nullptr))
+    return fail(DGS_E_ARG, "debug_contrib_checksum needs tile_cull = 0 (positions in the reference's lists), out_depth and a "
+                           "problem that keeps its state");
   const size_t N = (size_t)p->W * p->H;
   if (p->P == 0) {  // the reference returns zero-filled images when P == 0 (rasterize_points.cu:70-71,85)
     hipError_t e = hipMemsetAsync(out->out_color, 0, (size_t)p->K * 3 * N * 4, s);
@@ -754,7 +757,8 @@ static int forward_render_impl(const DgsProblem* p, const DgsForwardOut* out, ui
   if (phases & 1) DGS_STAGE(DGS_STAGE_RANGES, "identifyTileRanges", dgs_launch_ranges(v, c, R, s, n_dev, key_lo));
   if (phases & 2)
     DGS_STAGE(DGS_STAGE_COMPOSITE_FWD, "composite forward",
-              dgs_launch_composite_fwd(v, c, p->bg, out->out_color, out->out_depth, s));   // (c.final_T == NULL: inference)
+              dgs_launch_composite_fwd(v, c, p->bg, out->out_color, out->out_depth, s,   // (c.final_T == NULL: inference)
+                                       out->debug_contrib_checksum));
   return DGS_OK;
 }
 

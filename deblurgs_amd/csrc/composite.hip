@@ -120,13 +120,15 @@ using CullGauss = DgsCull;
 // loss never reads it): the depth channel drops out of the per-pair math and nothing is stored for it.
 // KEEP = false: an inference call (DgsProblem.forward_only): final_T / n_contrib, which only the backward reads, are not
 // stored (and `last` drops out of the per-pair math).
-template <bool WITHDEPTH, bool KEEP>
+// CHK = true (parity tests only, DgsForwardOut.debug_contrib_checksum): per pixel, the wrap-around sum of
+// pos * 2654435761 over the list positions of the pairs that contribute -- which per-pair decisions this traversal took.
+template <bool WITHDEPTH, bool KEEP, bool CHK = false>
 __global__ void __launch_bounds__(64 * CW)
 composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ ranges,
                      const uint32_t* __restrict__ point_list, const uint64_t* __restrict__ keys,
                      const DgsRow* __restrict__ rows,
                      const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                     float* __restrict__ out_color, float* __restrict__ out_depth) {
+                     float* __restrict__ out_color, float* __restrict__ out_depth, uint32_t* __restrict__ checksum = nullptr) {
   // one 48-byte LDS row per list entry: (x, y, A, B | C, op, r, g | b, depth, -, -): one address per read
   __shared__ float4 s_row[CW][64 * 3];
   TileCtx t;
@@ -141,11 +143,12 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
   // -T by the pair that would take it below 1e-4 (forward.cu:362-367), after which T (1 - alpha) < 1e-4 holds for every
   // later pair by itself and |T| is the final transmittance.  No separate per-lane flag to test and update per pair.
   float T[4], C0[4], C1[4], C2[4], Dd[4];
-  uint32_t last[4];
+  uint32_t last[4], chk[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     C0[q] = C1[q] = C2[q] = Dd[q] = 0.0f;
     last[q] = 0;
+    chk[q] = 0;
     const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
     T[q] = (px < v.W && py < v.H) ? 1.0f : -1.0f;
   }
@@ -242,6 +245,7 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           if (WITHDEPTH) Dd[q] += c.y * wgt;
           T[q] = stop ? -fabsf(T[q]) : test_T;     // alpha = 0 leaves a live T unchanged
           if (KEEP) last[q] = (ok && !stop) ? posv : last[q];
+          if (CHK) chk[q] += (ok && !stop) ? posv * 2654435761u : 0u;
         }
       }
     }
@@ -272,6 +276,7 @@ composite_fwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
       oc[N + pix] = C1[q] + Tf * bg1;
       oc[2 * N + pix] = C2[q] + Tf * bg2;
       if (WITHDEPTH) out_depth[(size_t)t.k * N + pix] = Dd[q] + Tf * v.z_far;
+      if (CHK) checksum[(size_t)t.k * N + pix] = chk[q];
     }
   }
 }
@@ -611,13 +616,19 @@ static uint32_t per_xcd_blocks(const DgsView& v) {
 }
 
 hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,
-                                    float* out_depth, hipStream_t s) {
+                                    float* out_depth, hipStream_t s, uint32_t* checksum) {
   const uint32_t per = per_xcd_blocks(v);
   if (per == 0) return hipSuccess;
 #define DGS_CFWD(WD, KP)                                                                                                  \
   hipLaunchKernelGGL((composite_fwd_kernel<WD, KP>), dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges, c.point_list, \
                      c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth)
   const bool keep = c.final_T != nullptr && c.n_contrib != nullptr;
+  if (checksum != nullptr) {   // the parity tests' variant: depth and state always on
+    if (out_depth == nullptr || !keep) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((composite_fwd_kernel<true, true, true>), dim3(per * 8), dim3(64 * CW), 0, s, v, per, c.ranges,
+                       c.point_list, c.keys_sorted, c.rows, bg, c.final_T, c.n_contrib, out_color, out_depth, checksum);
+    return hipGetLastError();
+  }
   if (out_depth != nullptr) {
     if (keep) DGS_CFWD(true, true); else DGS_CFWD(true, false);
   } else {

@@ -223,7 +223,7 @@ hipError_t dgs_launch_cull_offsets(const DgsView& v, const DgsCarve& c, uint32_t
 hipError_t dgs_launch_duplicate_tight(const DgsView& v, const DgsCarve& c, const uint32_t* order, uint32_t cap,
                                       hipStream_t s);
 hipError_t dgs_launch_composite_fwd(const DgsView& v, const DgsCarve& c, const float* bg, float* out_color,
-                                    float* out_depth, hipStream_t s);
+                                    float* out_depth, hipStream_t s, uint32_t* checksum = nullptr);
 hipError_t dgs_launch_composite_bwd(const DgsView& v, const DgsCarve& c, const float* bg, const float* dL_dpix,
                                     const float* dL_ddepth, float* contrib, hipStream_t s, int k0 = 0, int k1 = -1);
 hipError_t dgs_launch_geometry_bwd(const DgsProblem& p, const DgsView& v, const DgsCarve& c, const DgsBackwardIO& io,

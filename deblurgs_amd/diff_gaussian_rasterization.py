@@ -147,14 +147,16 @@ class _RS:
 
 
 def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm, campos,
-                  raster_settings, raw=None, capacity=None, forward_only=False):
+                  raster_settings, raw=None, capacity=None, forward_only=False, debug_checksum=False):
     """raw = {"scale_lb": float, "sh_rest": [P,M-1,3] or None, "isotropic": bool}: the inputs are the cloud's raw parameters
     (DgsProblem.raw_params) and sh is the dc part [P,1,3].
     capacity: size the duplicate arrays for that many duplicates up front and run the one-call dgs_forward (no host
     read between the phases; what fused_step.FusedStep does every iteration).  The returned count then carries
     `.capacity` (the binning blob is laid out for it) and `.overflow`.
     forward_only: an inference call (DgsProblem.forward_only): nothing is kept for a backward -- the image blob holds the
-    tile ranges alone, final_T / n_contrib / cov3D / the activation mask are not stored."""
+    tile ranges alone, final_T / n_contrib / cov3D / the activation mask are not stored.
+    debug_checksum (parity tests; tile_cull off): the returned count carries `.contrib_checksum`, an int32 [K, H*W] tensor
+    of DgsForwardOut.debug_contrib_checksum -- which pairs contributed to each pixel."""
     L = _lib.lib()
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")   # rasterize_points.cu:60-62
@@ -175,6 +177,8 @@ def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, 
     out.out_depth = _ptr(depth)
     out.radii = _ptr(radii)
     out.num_rendered_host = ctypes.c_void_p(host_R.data_ptr())
+    chk = torch.zeros((K, H * W), dtype=torch.int32, device=device) if debug_checksum else None
+    out.debug_contrib_checksum = _ptr(chk)
     stream = _stream(device)
     tile_cull = bool(TILE_CULL)
     prob = _make_problem(K, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewm, projm,
@@ -203,6 +207,7 @@ def _forward_impl(K, means3D, sh, colors_precomp, opacities, scales, rotations, 
     prob.binning_state = _ptr(binning)
     prob.binning_bytes = binning.numel()
     _lib.check(L.dgs_forward_render(ctypes.byref(prob), ctypes.byref(out), R, stream), "dgs_forward_render")
+    R.contrib_checksum = chk
     return R, color, depth, radii, geom, binning, image
 
 

@@ -150,6 +150,12 @@ typedef struct DgsForwardOut {
                                 * replays a captured graph stores a different block's address there before every replay
                                 * (through its own device-side scalar block): every replay then reports into a pinned
                                 * slot of its own without any copy behind it. */
+  uint32_t* debug_contrib_checksum; /* optional [K, H*W], tile_cull = 0 only: per pixel, the wrap-around sum of
+                                * pos * 2654435761 over the 1-based positions pos (inside the tile's list) of the pairs that
+                                * contribute to the pixel.  What the parity tests compare with the CPU oracle's to find the
+                                * pixels where the two traversals took a different per-pair decision (an exp() ulp at one of
+                                * the three thresholds of forward.cu:354-368); NULL (the product): the compositing kernel
+                                * without that sum. */
 } DgsForwardOut;
 
 typedef struct DgsBackwardIO {

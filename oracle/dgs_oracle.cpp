@@ -414,7 +414,14 @@ void dgs_oracle_bin(int P, int W, int H, int R, const int* radii, const float* m
 // FORWARD::render (forward.cu:273-392): per pixel front-to-back compositing of colour and depth.
 void dgs_oracle_render(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
                        const float* features, const float* depths, const float* conic_opacity, const float* bg,
-                       float z_far, float* final_T, uint32_t* n_contrib, float* out_color, float* out_depth) {
+                       float z_far, float* final_T, uint32_t* n_contrib, float* out_color, float* out_depth,
+                       uint32_t* contrib_checksum) {
+  // contrib_checksum (optional, test infrastructure for test infrastructure): per pixel, the wrap-around sum of
+  // pos * 2654435761 over the list positions pos (1-based, inside the tile's list) of the pairs that CONTRIBUTE to the pixel --
+  // those that pass the three tests below.  Two traversals of the same list took the same per-pair decisions at a pixel iff
+  // their checksums agree (up to a 2^-32 collision): the parity tests compare it with the HIP forward's
+  // (DgsForwardOut.debug_contrib_checksum) to find the pixels where an exp() ulp flipped a threshold, instead of masking
+  // every pixel that sits within a margin of one.
   const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
 #pragma omp parallel for collapse(2) schedule(dynamic, 4)
   for (int ty = 0; ty < gy; ty++)
@@ -427,6 +434,7 @@ void dgs_oracle_render(int W, int H, const uint32_t* ranges, const uint32_t* poi
           const uint32_t pix_id = (uint32_t)W * py + px;
           const float pfx = (float)px, pfy = (float)py;
           float T = 1.0f;
+          uint32_t chk = 0;
           uint32_t contributor = 0, last_contributor = 0;
           float C[3] = {0, 0, 0};
           float Dacc = 0.0f;
@@ -445,9 +453,11 @@ void dgs_oracle_render(int W, int H, const uint32_t* ranges, const uint32_t* poi
             Dacc += depths[g] * alpha * T;
             T = test_T;
             last_contributor = contributor;
+            chk += contributor * 2654435761u;
           }
           final_T[pix_id] = T;
           n_contrib[pix_id] = last_contributor;
+          if (contrib_checksum != nullptr) contrib_checksum[pix_id] = chk;
           for (int ch = 0; ch < 3; ch++) out_color[(size_t)ch * H * W + pix_id] = C[ch] + T * bg[ch];
           out_depth[pix_id] = Dacc + T * z_far;
         }

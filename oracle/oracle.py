@@ -183,11 +183,12 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfov
         st["n_contrib"] = np.zeros(N, np.uint32)
         st["color"] = np.zeros((3, H, W), np.float32)
         st["depth"] = np.zeros((1, H, W), np.float32)
+        st["contrib_checksum"] = np.zeros(N, np.uint32)     # which pairs contributed to each pixel (see dgs_oracle_render)
         feats = colors_precomp if colors_precomp is not None else st["rgb"]
         L.dgs_oracle_render(W, H, _p(st["ranges"], _u32p), _p(st["point_list"], _u32p), _p(st["means2D"], _f32p),
                             _p(feats, _f32p), _p(st["depths"], _f32p), _p(st["conic_opacity"], _f32p), _p(bg, _f32p),
                             ctypes.c_float(z_far), _p(st["final_T"], _f32p), _p(st["n_contrib"], _u32p),
-                            _p(st["color"], _f32p), _p(st["depth"], _f32p))
+                            _p(st["color"], _f32p), _p(st["depth"], _f32p), _p(st["contrib_checksum"], _u32p))
     return st
 
 

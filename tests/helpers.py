@@ -116,16 +116,17 @@ def wide_records(flag):
 
 
 def hip_forward_state(scene, K, sh_degree=None, use_sigmoid=False, colors_precomp=None, cov3D_precomp=None,
-                      scale_modifier=1.0, cull=False, capacity=None):
+                      scale_modifier=1.0, cull=False, capacity=None, checksum=False):
     """Runs the fused forward through the C ABI and returns outputs + every saved sub-array as numpy.  cull=False
     (default) keeps the reference's duplicate lists so that keys / point_list / ranges compare bit for bit; with
     cull=True the low key word is the duplicate's emission index instead of the depth bits."""
     with tile_cull(cull):
         return _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_precomp, scale_modifier,
-                                  capacity)
+                                  capacity, checksum)
 
 
-def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_precomp, scale_modifier, capacity=None):
+def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_precomp, scale_modifier, capacity=None,
+                       checksum=False):
     import torch
     from deblurgs_amd import _lib
     from deblurgs_amd import diff_gaussian_rasterization as dgr
@@ -138,7 +139,8 @@ def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_p
     cov = None if cov3D_precomp is None else _t(cov3D_precomp)
     R, color, depth, radii, geom, binning, image = dgr._forward_impl(
         K, _t(scene["means3D"]), sh, col, _t(scene["opacities"]).reshape(-1), sc, rot, cov,
-        _t(scene["viewmatrix"][:K]), _t(scene["projmatrix"][:K]), _t(scene["campos"][:K]), rs, capacity=capacity)
+        _t(scene["viewmatrix"][:K]), _t(scene["projmatrix"][:K]), _t(scene["campos"][:K]), rs, capacity=capacity,
+        debug_checksum=checksum)
     torch.cuda.synchronize()
     P, W, H = scene["P"], scene["W"], scene["H"]
     N = W * H
@@ -176,6 +178,8 @@ def _hip_forward_state(scene, K, sh_degree, use_sigmoid, colors_precomp, cov3D_p
         # 0..2 of word 10) instead of a [K,P,3] float array; the tests read it in the oracle's form
         bits = st["rows_u32"][:, :, 10]
         st["pre_sigmoid"] = np.stack([(bits >> c) & 1 for c in range(3)], axis=-1).astype(np.float32)
+    if checksum:
+        st["contrib_checksum"] = R_obj.contrib_checksum.cpu().numpy().view(np.uint32)
     st["compact_keys"] = False
     if R_obj.tile_cull and L.pack_tile_shift > 0:
         # compact keys (DgsLayout.pack_*): tile | Gaussian | emission index in one word and no value array; the tests
@@ -328,18 +332,35 @@ class OracleRun:
     algorithm differ from each other; they are large exactly where a gradient component is ill-conditioned (scale /
     rotation behind the covariance chain, the view matrix)."""
 
-    def __init__(self, scene, K, **kw):
+    def __init__(self, scene, K, margin_masks=True, **kw):
+        """margin_masks=False: the caller will install the exact disagreement masks (use_exact_masks) and the oracle's
+        threshold-margin masks are not computed."""
         self.scene, self.K, self.kw = scene, K, kw
         oracle.use_openmp(True)
         try:
-            # (subframes side by side, a few dozen OpenMP threads each: oracle.map_subframes)
             self.states = oracle.map_subframes(lambda k: oracle_forward(scene, k, **kw), range(K))
-            self.unstable = oracle.map_subframes(oracle.unstable, self.states)
+            self.unstable = (oracle.map_subframes(oracle.unstable, self.states) if margin_masks else [None] * K)
         finally:
             oracle.use_openmp(False)
         for st in self.states:
             st.pop("keys_unsorted", None)
             st.pop("vals_unsorted", None)
+
+    def use_exact_masks(self, hip_checksum, hip_n_contrib, ks=None):
+        """Replaces the margin masks (every pixel whose ORACLE traversal sits within a margin of a threshold: 0.5 % of the
+        pixels at the metric size) by the pixels where the HIP traversal and the oracle's really took a different per-pair
+        decision: their contributor checksums (DgsForwardOut.debug_contrib_checksum / dgs_oracle_render) or their last
+        contributors differ.  hip_* are [K', H*W] arrays of a tile_cull = 0 forward (positions in the reference's lists),
+        for the subframes ks of this run (default: all).  Returns the exempt pixel count per subframe."""
+        ks = list(range(self.K)) if ks is None else list(ks)
+        counts = []
+        for i, k in enumerate(ks):
+            st = self.states[k]
+            d = (np.asarray(hip_checksum[i]).view(np.uint32).reshape(-1) != st["contrib_checksum"]) | \
+                (np.asarray(hip_n_contrib[i]).view(np.uint32).reshape(-1) != st["n_contrib"])
+            self.unstable[k] = d.reshape(st["H"], st["W"])
+            counts.append(int(d.sum()))
+        return counts
 
     def subset(self, idx):
         r = OracleRun.__new__(OracleRun)
@@ -638,7 +659,7 @@ CLOUD_KEYS = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "dL_dme
               "dL_dviewmatrix", "dL_dprojmatrix"]
 
 
-def hip_state_on_device(scene, K, cull=True, raw=True):
+def hip_state_on_device(scene, K, cull=True, raw=True, checksum=False):
     """Forward through the C ABI; returns the outputs and the carved state arrays as torch views ON THE DEVICE (for
     full-size property checks without multi-GB host copies).  raw=True: the cloud's raw parameters, as benchmarked."""
     import torch
@@ -652,11 +673,12 @@ def hip_state_on_device(scene, K, cull=True, raw=True):
             c = GaussianCloud.from_scene(scene, "cuda")
             R, color, depth, radii, geom, binning, image = dgr._forward_impl(
                 K, c._xyz, c._features_dc, None, c._opacity.reshape(-1), c._scaling, c._rotation, None, view, proj, cam,
-                rs, raw={"scale_lb": 0.0, "sh_rest": c._features_rest if c._features_rest.shape[1] > 0 else None})
+                rs, raw={"scale_lb": 0.0, "sh_rest": c._features_rest if c._features_rest.shape[1] > 0 else None},
+                debug_checksum=checksum)
         else:
             R, color, depth, radii, geom, binning, image = dgr._forward_impl(
                 K, _t(scene["means3D"]), _t(scene["sh"]), None, _t(scene["opacities"]).reshape(-1), _t(scene["scales"]),
-                _t(scene["rotations"]), None, view, proj, cam, rs)
+                _t(scene["rotations"]), None, view, proj, cam, rs, debug_checksum=checksum)
     torch.cuda.synchronize()
     P, W, H = scene["P"], scene["W"], scene["H"]
     T = ((W + 15) // 16) * ((H + 15) // 16)
@@ -669,7 +691,7 @@ def hip_state_on_device(scene, K, cull=True, raw=True):
         point_list = ((keys >> gs) & ((1 << (ts - gs)) - 1)).int()
         keys = ((keys >> ts) << 32) | (keys & ((1 << gs) - 1))
     return dict(R=int(R), K=K, T=T, compact_keys=bool(cull and L.pack_tile_shift > 0), sort_bits=L.sort_bits, sort_passes=L.sort_passes, color=color, depth=depth,
-                radii=radii, _blobs=(geom, binning, image),
+                radii=radii, _blobs=(geom, binning, image), contrib_checksum=getattr(R, "contrib_checksum", None),
                 tiles_touched=v(geom, L.tiles_touched, K * P * 4, torch.int32, (K, P)),
                 tt_tight=v(geom, L.tt_tight, K * P * 4, torch.int32, (K * P,)),
                 rows=v(geom, L.geom_rows, K * P * 48, torch.float32, (K, P, 12)),

@@ -42,7 +42,7 @@ def test_struct_sizes_match_the_header_layout():
     # 6 ints + 5 floats + 5 ints + 1 float = 68 bytes (+4 padding), then 12 pointers, then 3 x (pointer + size_t)
     assert ctypes.sizeof(_lib.DgsProblem) == 80 + 12 * 8 + 3 * 16 + 8   # + forward_only (76 -> padded to 80), context (ABI 14)
     assert ctypes.sizeof(_lib.DgsContextOptions) == 4 * (2 + _lib.MAX_BWD_PARTS - 1)
-    assert ctypes.sizeof(_lib.DgsForwardOut) == 56     # + drop_counter, status_dev, status_host_indirect
+    assert ctypes.sizeof(_lib.DgsForwardOut) == 64     # + drop_counter, status_dev, status_host_indirect, debug_contrib_checksum
     assert ctypes.sizeof(_lib.DgsBackwardIO) == 8 + 8 * 3 + 16 + 11 * 8 + 8 + 3 * 8 + 8   # + hinge scale, stats_* (padded)
     assert ctypes.sizeof(_lib.DgsLayout) == 29 * 8 + 16     # + sort_bits, sort_passes, pack_g_shift, pack_tile_shift
 

@@ -96,7 +96,7 @@ def forward_against_oracle(st_color, st_depth, st_ncontrib, st_finalT, run, sc, 
         DISAGREE["colour_off_unmasked"] += int((off & ~un).sum())
         if st_ncontrib is not None:
             DISAGREE["n_contrib_off"] += int((st_ncontrib[k] != o["n_contrib"]).sum())
-        assert frac < 0.01, f"unstable pixel fraction {frac}"          # exempted pixels are counted, not assumed rare
+        assert frac < 1e-3, f"exempt pixel fraction {frac}"          # exempted pixels are counted, not assumed rare
         dc = np.abs(st_color[k] - o["color"]).max(axis=0)
         dd = np.abs(st_depth[k][0] - o["depth"][0]) / sc["z_far"]
         assert dc[~un].max() <= IMG_TOL, f"colour k={k}: {dc[~un].max()}"
@@ -135,7 +135,7 @@ def test_config_as_benchmarked(gpu, cfg):
     st1 = hip_state_on_device(sc, K, cull=True, raw=True)
     st1.update(P=P, W=W, H=H)
     check_fused_binning_properties(st1, True, cfg)
-    st0 = hip_state_on_device(sc, K, cull=False, raw=True)
+    st0 = hip_state_on_device(sc, K, cull=False, raw=True, checksum=True)
     st0.update(P=P, W=W, H=H)
     check_fused_binning_properties(st0, False, cfg)
     for key in ("color", "depth", "radii", "final_T", "tiles_touched"):
@@ -151,8 +151,12 @@ def test_config_as_benchmarked(gpu, cfg):
     mark("hip states + binning properties")
 
     # ---- (2) forward of ALL K subframes against the oracle (kernel-activated parameters)
-    run = OracleRun(act, K)
-    mark("oracle forward + masks")
+    run = OracleRun(act, K, margin_masks=False)
+    # the exempt pixels: where this forward and the oracle's took a different per-pair decision (contributor checksums /
+    # last contributors differ) -- NOT every pixel within a margin of a threshold (0.5 % of them at the metric size)
+    exempt = run.use_exact_masks(st0["contrib_checksum"].cpu().numpy(), st0["n_contrib"].cpu().numpy())
+    assert sum(exempt) < 1e-4 * K * H * W, f"exempt pixels {sum(exempt)} of {K * H * W}"
+    mark("oracle forward + exact masks")
     radii = st1["radii"].cpu().numpy()
     tt = st0["tiles_touched"].cpu().numpy().view(np.uint32)
     off = 0
@@ -205,7 +209,7 @@ def test_config_as_benchmarked(gpu, cfg):
     for key in CLOUD_KEYS + ["color", "depth"]:
         assert np.array_equal(hip0[key], hip[key]), f"tile_cull 0 vs 1: {key}"
     print(f"\n[{cfg}{'_sh3' if sh3 else ''}] lib {os.path.basename(os.environ.get('DGS_LIB_PATH', 'libdgs_hip.so'))}: of "
-          f"{fwd_stats['pixels']} pixels {fwd_stats['masked']} are masked (oracle within its own margins), "
+          f"{fwd_stats['pixels']} pixels {fwd_stats['masked']} are exempt (a per-pair decision differs from the oracle's), "
           f"{fwd_stats['colour_off']} differ from the oracle by more than {IMG_TOL} in colour ({fwd_stats['colour_off_unmasked']} "
           f"of them unmasked), {fwd_stats['n_contrib_off']} in n_contrib")
     print(f"[{cfg}] unstable fraction {frac:.2e}; errors (key, hip, oracle-fp32-noise):")
@@ -217,8 +221,8 @@ def test_config_as_benchmarked(gpu, cfg):
 
 
 def test_cfg5_stress_as_benchmarked(gpu):
-    """5M Gaussians, 3840x2160, K=31, curve order 5: properties of the benchmarked variant at full size, then the first,
-    middle and last subframe forward and the middle subframe's backward against the oracle."""
+    """5M Gaussians, 3840x2160, K=31, curve order 5: properties of the benchmarked variant at full size, then eight of the
+    subframes forward and the middle subframe's backward against the oracle."""
     import torch
     t0 = time.time()
     sc = synthetic.make_config("cfg5")
@@ -231,30 +235,42 @@ def test_cfg5_stress_as_benchmarked(gpu):
     from deblurgs_amd import _lib
     assert _lib.layout(P, W, H, 1, 0).sort_bits == KEY_BITS_K1["cfg5"]
     assert st["sort_bits"] == 32 + 20 and st["sort_passes"] == 3        # K*T = 1 004 400 tiles -> 20 tile bits
-    ks = [0, K // 2, K - 1]
-    sub = dict(act)
+    # forward: eight of the 31 subframes against the oracle (round 5: three); exempt pixels = where the per-pair decisions
+    # differ (contributor checksums of a tile_cull = 0 forward of those subframes)
+    ks = [0, 4, 9, 13, K // 2, 19, 25, K - 1]
+    mid = ks.index(K // 2)
+    sub, sub_raw = dict(act), dict(sc)
     for name in ("viewmatrix", "projmatrix", "campos"):
         sub[name] = act[name][ks]
-    run = OracleRun(sub, len(ks))
+        sub_raw[name] = sc[name][ks]
+    sub_raw["K"] = len(ks)
+    run = OracleRun(sub, len(ks), margin_masks=False)
     radii = st["radii"][ks].cpu().numpy()
     for i in range(len(ks)):
         assert np.array_equal(radii[i], run.states[i]["radii"])
-    frac = forward_against_oracle(st["color"][ks].cpu().numpy(), st["depth"][ks].cpu().numpy(), None,
-                                  st["final_T"][ks].cpu().numpy(), run, sc, range(len(ks)))
+    color, depth, final_T = (st[n][ks].cpu().numpy() for n in ("color", "depth", "final_T"))
     R = st["R"]
     del st
+    torch.cuda.empty_cache()
+    stc = hip_state_on_device(sub_raw, len(ks), cull=False, raw=True, checksum=True)
+    assert np.array_equal(stc["color"].cpu().numpy(), color), "tile_cull 0 vs 1 at cfg5"
+    exempt = run.use_exact_masks(stc["contrib_checksum"].cpu().numpy(), stc["n_contrib"].cpu().numpy())
+    assert sum(exempt) < 1e-4 * len(ks) * H * W, exempt
+    frac = forward_against_oracle(color, depth, stc["n_contrib"].cpu().numpy().view(np.uint32), final_T, run, sc,
+                                  range(len(ks)))
+    del stc
     torch.cuda.empty_cache()
     # backward: upstream gradient on the middle subframe only, so the per-Gaussian sums are that subframe's
     rng = np.random.default_rng(4)
     g_mid = rng.normal(size=(1, 3, H, W)).astype(np.float32)
-    g_mid[0][:, run.unstable[1]] = 0.0
+    g_mid[0][:, run.unstable[mid]] = 0.0
     gC = np.zeros((K, 3, H, W), np.float32)
     gC[K // 2] = g_mid[0]
     hip = hip_cloud_forward_backward(sc, K, gC, cull=True, conic_ks=[K // 2])
-    ora = cloud_grads_from_activated(act, run.subset([1]).backward(g_mid))
+    ora = cloud_grads_from_activated(act, run.subset([mid]).backward(g_mid))
     if os.environ.get("DGS_PARITY_ROW"):      # debugging aid: the pixels of one Gaussian that sit closest to the alpha threshold
         gdbg = int(os.environ["DGS_PARITY_ROW"])
-        stm = run.states[1]
+        stm = run.states[mid]
         mx, my = (float(t) for t in stm["means2D"][gdbg])
         ca, cb, cc, op = (float(t) for t in stm["conic_opacity"][gdbg])
         rad = int(stm["radii"][gdbg])
@@ -273,7 +289,7 @@ def test_cfg5_stress_as_benchmarked(gpu):
             py_, px_ = int(ys[iy]), int(xs[ix])
             terms = 0.5 * abs(ca * dx[0, ix] ** 2) + 0.5 * abs(cc * dy[iy, 0] ** 2) + abs(cb * dx[0, ix] * dy[iy, 0])
             print(f"       pixel ({px_}, {py_}): alpha {alpha[iy, ix]:.9g} (1/255 = {1 / 255:.9g}, rel {rel[iy, ix]:.2e}) power "
-                  f"{power[iy, ix]:.6g} largest term {terms:.4g} unstable {bool(run.unstable[1][py_, px_])} "
+                  f"{power[iy, ix]:.6g} largest term {terms:.4g} unstable {bool(run.unstable[mid][py_, px_])} "
                   f"upstream |g| {float(np.abs(g_mid[0][:, py_, px_]).max()):.3g}")
     for key in ("dL_dmeans2D", "dL_dviewmatrix", "dL_dprojmatrix"):
         rest = np.delete(hip[key], K // 2, axis=0)
