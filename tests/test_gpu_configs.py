@@ -205,7 +205,7 @@ def test_config_as_benchmarked(gpu, cfg):
     mark("gradient comparisons")
     hip = hip_full
     # ---- (4) the reference's lists give the same gradients bit for bit at this size
-    hip0 = hip_cloud_forward_backward(sc, K, gC, cull=False)
+    hip0 = hip_cloud_forward_backward(sc, K, gC, cull=False, conic_ks=bwd_ks if len(bwd_ks) < K else None)
     for key in CLOUD_KEYS + ["color", "depth"]:
         assert np.array_equal(hip0[key], hip[key]), f"tile_cull 0 vs 1: {key}"
     print(f"\n[{cfg}{'_sh3' if sh3 else ''}] lib {os.path.basename(os.environ.get('DGS_LIB_PATH', 'libdgs_hip.so'))}: of "

@@ -1042,6 +1042,41 @@ def test_two_ranks_subframes_equal_the_single_process_step(gpu, tmp_path):
         assert x.shape == y.shape and float((x - y).abs().max()) <= 2e-3 * (float(x.abs().max()) + 1e-12)
 
 
+def test_two_ranks_step_at_the_metric_size_equals_the_single_process_steps(gpu, tmp_path):
+    """BASELINE.json cfg4's workload -- the metric configuration (1M Gaussians, 1920x1080, K = 15) sharded over ranks --
+    through the suite, not only through a log: two ranks on the one device (gloo), one iteration with
+    all K subframes, both sharding modes, against one-rank runs of the same step on the same parameters.
+      "subframes": the two ranks' summed gradients = the single-process gradients of that view (up to the order of the
+                   cross-rank sums);
+      "views":     the two ranks' averaged gradients = the mean of the two views' single-process gradients.
+    (What this cannot show is RCCL over xGMI: the collectives are gloo's, staged through the host.)"""
+    import sys
+    import torch
+    root, tool, env = _two_rank_env()
+    common = ["--config", "metric", "--no-densify", "--iters", "1", "--curve-start", "1", "--same-seed", "--graph", "off"]
+    out = {}
+    for name, extra in (("sub2", ["--ranks", "2", "--mode", "subframes", "--ar-chunks", "4"]),
+                        ("one_v1", ["--ranks", "1", "--mode", "subframes"]),
+                        ("views2", ["--ranks", "2", "--mode", "views", "--ar-chunks", "4"]),
+                        ("one_v0", ["--ranks", "1", "--mode", "views", "--cam-offset", "1"])):
+        path = str(tmp_path / (name + ".pt"))
+        _run([sys.executable, tool] + common + extra + ["--out", path], env, timeout=600)
+        out[name] = torch.load(path)["grads_first"]
+
+    def close(x, y, what):
+        assert (x is None) == (y is None), what
+        if x is not None and x.numel():
+            err, scale = float((x - y).abs().max()), float(y.abs().max()) + 1e-30
+            assert err <= 2e-5 * scale, (what, err, scale)
+    # iteration 1: "subframes" ranks and the one-rank "subframes" run all take view (1 + 0) % 2 = 1
+    for i, (x, y) in enumerate(zip(out["sub2"], out["one_v1"])):
+        close(x, y, f"subframes, tensor {i}")
+    # "views": rank 0 takes view 1, rank 1 view 0 (= the one-rank run with --cam-offset 1 ... (1 + 0 + 1) % 2 = 0)
+    for i, (x, a, b) in enumerate(zip(out["views2"], out["one_v1"], out["one_v0"])):
+        if x is not None and x.numel():
+            close(x, (a + b) / 2, f"views, tensor {i}")
+
+
 @pytest.mark.parametrize("mode", _MODES)
 def test_two_ranks_chunked_allreduce_equals_the_single_collective(gpu, mode, tmp_path):
     """The chunked reduction of the gradient bucket, overlapped with the backward's tail on a side stream, gives the same

@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--force-overflow", type=int, default=0,
                     help="at this iteration rank 1 pretends its view used to need a quarter of the duplicates: its capacity "
                          "overflows, the MAX-reduced flag must make EVERY rank drop the step and correct its step counters")
+    ap.add_argument("--config", default=None,
+                    help="a BASELINE.json configuration of deblurgs_amd.synthetic (metric, cfg2, cfg3) instead of the small "
+                         "3000-Gaussian scene: the sharded step at the size bench.py times (tests/test_gpu_train.py)")
+    ap.add_argument("--cam-offset", type=int, default=0, help="added to every rank's view index (one-rank reference runs)")
     ap.add_argument("--depth-tv", type=float, default=0.0, help="lambda_depth_tv (one more collective per step in subframes mode)")
     ap.add_argument("--p2p-direct", action="store_true",
                     help="REPRODUCTION AID, not a product path: replace sharding._p2p by round 3's behaviour (batch_isend_irecv "
@@ -87,14 +91,20 @@ def main():
         sharding._p2p = _p2p_direct
     dev = torch.device("cuda", 0 if os.environ.get("DGS_DIST_ONE_DEVICE", "0") == "1" else local)
     torch.cuda.set_device(dev)
-    K = 5
-    sc = synthetic.make_scene(3000, 128, 96, K=K, seed=21, sigma_px=3.0)
+    K, C = 5, 3
+    if args.config:
+        sc = synthetic.make_config(args.config, seed=0)
+        K, C = sc["K"], synthetic.CONFIGS[args.config]["C"]
+        traj = synthetic.make_trajectory(K, C, sc["projection_matrix"], seed=0)
+        sc["ctrl_trans"], sc["ctrl_rot"] = traj["ctrl_trans"], traj["ctrl_rot"]
+    else:
+        sc = synthetic.make_scene(3000, 128, 96, K=K, seed=21, sigma_px=3.0)
     cloud = GaussianCloud.from_scene(sc, dev)
     ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device=dev)
     n_views = max(world, 2)
     torch.manual_seed(100)                        # the SAME module (ground truths, curves) on every rank
     gt = torch.rand(n_views, 3, sc["H"], sc["W"], device=dev) * 0.5
-    m = CameraMotionModule(ref, gt, curve_order=3, num_subframes=K, device=dev, curve_random_sample=args.random_sample)
+    m = CameraMotionModule(ref, gt, curve_order=C, num_subframes=K, device=dev, curve_random_sample=args.random_sample)
     with torch.no_grad():
         base = torch.from_numpy(sc["ctrl_trans"])[None].to(dev)
         m._trans._control_points.copy_(base + 0.01 * torch.arange(n_views, device=dev).reshape(-1, 1, 1))
@@ -128,7 +138,7 @@ def main():
     for it in range(1, args.iters + 1):
         snap["it"] = it
         torch.manual_seed(it if args.same_seed else 7919 * (rank + 1) + it)   # ranks draw DIFFERENT random numbers
-        cam = (it + rank) % n_views if args.mode == "views" else it % n_views
+        cam = (it + rank + args.cam_offset) % n_views if args.mode == "views" else (it + args.cam_offset) % n_views
         if it == args.force_overflow and rank == min(1, world - 1) and loop._fused is not None:
             loop._fused._poll(block=True)
             assert loop._fused._seen, "no duplicate count learnt yet: nothing to shrink"
@@ -168,7 +178,7 @@ def main():
         assert same, "replicas diverged"
         assert args.no_densify or len(set(sizes)) > 1, "densify_and_prune never changed the cloud"
         assert world == 1 or not inplace or all(inplace[1:]), "the gradient bucket must be reduced in place"
-        assert cloud.optimizer.state[m._nu]["step"] > 0 and moved[0] > 0
+        assert args.iters < 5 or (cloud.optimizer.state[m._nu]["step"] > 0 and moved[0] > 0)
         if args.out:
             torch.save({"params": [p.detach().cpu() for p in tensors], "sizes": sizes, "grads_first": snap.get("grads"),
                         "replayed": 0 if loop._fused is None else loop._fused.replayed,
