@@ -66,12 +66,33 @@ __device__ __forceinline__ bool load_tile_ctx(const DgsView& v, const uint2* __r
 // origin, otherwise it sits on one of the four edges, where q is a 1-D quadratic with a closed-form clamped
 // minimiser.  A slack on r2 and a relative slack on q keep it conservative under fp32 rounding, so the exact
 // per-pixel tests of the reference still decide every pair that survives.
+// DGS_LOG2_CONIC=1 (rounds 2-5, now an A/B build only): the conic sits in LDS pre-multiplied by -0.5 log2(e) (-log2(e) for
+// the cross term), so that the quadratic form feeds v_exp_f32 directly -- one VALU instruction fewer per pass.  But the three
+// products round the COEFFICIENTS (6e-8 relative each), and for a needle -- a nearly singular conic, terms of +-5000 that
+// cancel to a power of -2 -- that is 3e-4 in the exponent, the same sign at every pixel of the Gaussian: dL_dconic of one
+// such Gaussian came out 2e-4 off at the metric size (1.03e-4 of its column; tools/r06_calls/find_pixel.py bisected it to
+// "no pixel: all of them").  Default since round 6: the conic is scaled by the exact factors -0.5 / -1 / -0.5 only, the
+// quadratic form is the reference's `power` (forward.cu:351) evaluated with the same five instructions, and ONE multiply by
+// log2(e) -- whose rounding is not amplified by the cancellation -- follows it.
+#ifndef DGS_LOG2_CONIC
+#define DGS_LOG2_CONIC 0
+#endif
+#if DGS_LOG2_CONIC
 constexpr float K_LOG2E = -1.4426950408889634f;        // cross term:  -b dx dy        -> log2 domain
 constexpr float K_HALF_LOG2E = -0.7213475204444817f;   // square terms: -0.5 a dx^2 ...
-// log2(e) * (-0.5 (a dx^2 + c dy^2) - b dx dy) from the pre-scaled conic (A, B, C) = (-0.5 l a, -l b, -0.5 l c)
+#else
+constexpr float K_LOG2E = -1.0f;                       // exact scalings: the coefficients keep their bits
+constexpr float K_HALF_LOG2E = -0.5f;
+#endif
+// (-0.5 (a dx^2 + c dy^2) - b dx dy) [* log2(e)] from the pre-scaled conic (A, B, C) = (-0.5 a, -b, -0.5 c) [* log2(e)],
+// as the argument of v_exp_f32 (2^x)
 __device__ __forceinline__ float dgs_power2(float A, float B, float C, float dx, float dy) {
   const float u = fmaf(B, dy, A * dx);
+#if DGS_LOG2_CONIC
   return fmaf(C * dy, dy, dx * u);
+#else
+  return fmaf(C * dy, dy, dx * u) * 1.4426950408889634f;
+#endif
 }
 
 // DGS_EXACT_POWER=1 (A/B build only, tools/r05_calls/parity_ab.sh; never the shipped library): the three places where the
@@ -84,6 +105,12 @@ __device__ __forceinline__ float dgs_power2(float A, float B, float C, float dx,
 // DESIGN.md 5 has the measured effect on the unstable-pixel mask, on dL_dconic and on the step time.
 #ifndef DGS_EXACT_POWER
 #define DGS_EXACT_POWER 0
+#endif
+// DGS_DIV_REFINE=1 (A/B build only): T / (1 - alpha) with one residual correction behind the hardware reciprocal.  Round 6:
+// +0.38 ms on the compositing backward (5.31 against 4.93 ms, three interleaved runs) and dL_dconic's column figure at the
+// metric size does not move by a digit (1.0289e-4 both ways): the recurrence's rounding is not what that figure measures.
+#ifndef DGS_DIV_REFINE
+#define DGS_DIV_REFINE 0
 #endif
 #if DGS_EXACT_POWER
 __device__ __forceinline__ float dgs_power_ref(float a, float b, float c, float dx, float dy) {
@@ -482,6 +509,15 @@ composite_bwd_kernel(DgsView v, uint32_t per_xcd, const uint2* __restrict__ rang
           const float alpha = dgs_min_raw(0.99f, au);
 #if DGS_EXACT_POWER
           T[q] = T[q] / (1.0f - alpha);
+#elif DGS_DIV_REFINE
+          // T / (1 - alpha) by the hardware reciprocal plus one residual correction: q = T r, q' = q + (T - d q) r.  The plain
+          // product T * v_rcp_f32(d) carries up to ~1.5 ulp per pair and the recurrence compounds it over the hundreds of
+          // pairs behind a pixel (dL_dconic sat at 1.03e-4 of its column scale at the metric size with the exact exempt set);
+          // the corrected quotient is the division's to within an ulp for two more FMAs per pass.
+          const float one_m = 1.0f - alpha;
+          const float inv1ma = __builtin_amdgcn_rcpf(one_m);
+          const float q0 = T[q] * inv1ma;
+          T[q] = fmaf(fmaf(-one_m, q0, T[q]), inv1ma, q0);
 #else
           const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
           T[q] = T[q] * inv1ma;
