@@ -49,7 +49,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="metric", help="metric | cfg2 | cfg3 | cfg5 | cfg1")
-    ap.add_argument("--shard", default="views", choices=["views", "subframes"])
+    ap.add_argument("--shard", default="views", choices=["views", "subframes", "mesh"])
+    ap.add_argument("--mesh-subframes", type=int, default=2,
+                    help="--shard mesh: Gs, the ranks that split ONE view's subframes (rank = v * Gs + s; Gv = gpus / Gs rows "
+                         "are a mini-batch of views)")
     ap.add_argument("--K", type=int, default=None)
     ap.add_argument("--sh-degree", type=int, default=2)
     ap.add_argument("--P", type=int, default=None, help="override the number of Gaussians (stress variants)")
@@ -362,8 +365,19 @@ def run_rank(args):
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
         assert int(ones.item()) == world, "all-reduce did not reach every rank"
-    subframes_mode = (world > 1 or emu is not None) and args.shard == "subframes"
-    shard_id = emu if emu is not None else (rank, world)       # (rank, world) of the slice this process computes
+    # "mesh" (round 6): Gv x Gs ranks, rank = v * Gs + s -- row v's Gs ranks split view v's subframes, the rows are a batch
+    mesh_dims = None
+    if args.shard == "mesh" and world > 1 and emu is None:
+        gs_ = max(1, min(args.mesh_subframes, world))
+        if world % gs_ != 0:
+            raise SystemExit(f"bench.py: --shard mesh needs --gpus divisible by --mesh-subframes ({world} / {gs_})")
+        mesh_dims = (world // gs_, gs_)
+    if args.shard == "mesh" and mesh_dims is None:
+        raise SystemExit("bench.py: --shard mesh needs --gpus > 1 (and no --emulate-shard)")
+    # slices of ONE view per rank ("subframes", and the rows of a mesh): what the per-rank byte model and the probe see
+    subframes_mode = (world > 1 or emu is not None) and args.shard in ("subframes", "mesh")
+    shard_id = emu if emu is not None else ((rank % mesh_dims[1], mesh_dims[1]) if mesh_dims else (rank, world))
+    views_per_step = (mesh_dims[0] if mesh_dims else (1 if subframes_mode else world))     # views rendered per step, whole job
 
     over = {} if args.K is None else {"K": args.K}
     if args.P is not None:
@@ -387,7 +401,7 @@ def run_rank(args):
         return mo
 
     # "subframes": every rank works on the SAME view; "views": rank g on its own
-    motion = make_view(0 if subframes_mode else (rank if emu is None else emu[0]))
+    motion = make_view((rank // mesh_dims[1]) if mesh_dims else (0 if subframes_mode else (rank if emu is None else emu[0])))
     params = cloud.hot_parameters()
     # The timed step is the PRODUCT's training iteration, deblurgs_amd.training.TrainingLoop.step (train.py:104-208):
     # scheduled hyper-parameters, the view's K subframes rendered and back-propagated (by default through
@@ -406,8 +420,8 @@ def run_rank(args):
                                       curve_alignment_lr=0.0)
     LR_SCALE = 1e-6
 
-    def make_loop(mode_, motion_):
-        lp = TrainingLoop(cloud, motion_, opt, cameras_extent=1.0, spatial_lr_scale=1.0, distributed=mode_,
+    def make_loop(mode_, motion_, mesh_=None):
+        lp = TrainingLoop(cloud, motion_, opt, cameras_extent=1.0, spatial_lr_scale=1.0, distributed=mode_, mesh=mesh_,
                           fused_step=False if args.autograd_path else "auto", log_losses=False,
                           graph=False if args.no_graph else ("always" if args.graph_always else "auto"),
                           ar_chunks=args.ar_chunks,
@@ -423,7 +437,7 @@ def run_rank(args):
         return lp
 
     mode = args.shard if (world > 1 or emu is not None) else False
-    loop = make_loop(mode, motion)
+    loop = make_loop(mode, motion, mesh_dims)
 
     stats = {"it": 0}
     ar_events = []
@@ -535,7 +549,7 @@ def run_rank(args):
         if rank == 0:   # for the record, should an extra region never return: the headline region's figures, on stderr
             print(json.dumps({"headline_before_extras": {
                 "n_gpus": world, "sharding": args.shard, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                "value": round((K if subframes_mode else world * K) * args.steps / dt, 2)}}), file=sys.stderr, flush=True)
+                "value": round(views_per_step * K * args.steps / dt, 2)}}), file=sys.stderr, flush=True)
         n_bucket = sum(p.numel() for p in params)
 
         def ab_allreduce(kind, iters=8):
@@ -568,34 +582,44 @@ def run_rank(args):
                                               "2 (G-1)/G * bytes / time"}
         except Exception as ex:            # (never lose the headline line to a secondary region)
             extras["allreduce_ab"] = {"error": repr(ex)}
-        other = "subframes" if args.shard == "views" else "views"
-        try:
-            if loop._fused is not None:
-                loop._fused._poll(block=True)
-                loop._fused.invalidate()           # the headline loop's graphs and pool go back to the driver
-            motion2 = make_view(0 if other == "subframes" else rank)
-            loop2 = make_loop(other, motion2)
-            it2 = {"it": 10 ** 6}
+        # every sharding mode but the headline's, timed on the same ranks (the mesh: Gv x 2 when the ranks allow it)
+        others = [m_ for m_ in ("views", "subframes") if m_ != args.shard]
+        if world >= 4 and world % 2 == 0 and args.shard != "mesh":
+            others.append("mesh")
+        extras["other_modes"] = {}
+        for other in others:
+            try:
+                if loop._fused is not None:
+                    loop._fused._poll(block=True)
+                    loop._fused.invalidate()           # the headline loop's graphs and pool go back to the driver
+                dims2 = (world // 2, 2) if other == "mesh" else None
+                motion2 = make_view(0 if other == "subframes" else (rank // 2 if other == "mesh" else rank))
+                loop2 = make_loop(other, motion2, dims2)
+                it2 = {"it": 10 ** 6}
 
-            def step2():
-                it2["it"] += 1
-                loop2.step(it2["it"], 0)
-            for _ in range(max(args.warmup, 4)):
-                step2()
-            n2 = max(10, args.steps // 4)
-            dt2 = timed(n2, profile=False, step_fn=step2)
-            extras["other_mode"] = {
-                "sharding": other, "scaling": "strong" if other == "subframes" else "weak", "steps": n2,
-                "value": round((K if other == "subframes" else world * K) * n2 / dt2, 2),
-                "ms_per_step": round(dt2 / n2 * 1e3, 3),
-                "graph": None if loop2._fused is None else {"captured": loop2._fused.captured,
-                                                            "replayed": loop2._fused.replayed},
-                "note": ("strong scaling: ONE view per step, its K subframes split over the GPUs (BASELINE.json cfg4's "
-                         "wording; the reference's single-view step exactly)" if other == "subframes" else
-                         "weak scaling: one view per GPU per step (a G-view mini-batch)")}
-            del loop2, motion2
-        except Exception as ex:
-            extras["other_mode"] = {"sharding": other, "error": repr(ex)}
+                def step2():
+                    it2["it"] += 1
+                    loop2.step(it2["it"], 0)
+                for _ in range(max(args.warmup, 4)):
+                    step2()
+                n2 = max(10, args.steps // 4)
+                dt2 = timed(n2, profile=False, step_fn=step2)
+                views2 = {"subframes": 1, "views": world, "mesh": world // 2}[other]
+                extras["other_modes"][other] = {
+                    "sharding": other if dims2 is None else f"mesh {dims2[0]} views x {dims2[1]} subframe slices",
+                    "scaling": {"subframes": "strong", "views": "weak", "mesh": "mesh"}[other], "steps": n2,
+                    "value": round(views2 * K * n2 / dt2, 2), "views_per_step": views2,
+                    "ms_per_step": round(dt2 / n2 * 1e3, 3),
+                    "graph": None if loop2._fused is None else {"captured": loop2._fused.captured,
+                                                                "replayed": loop2._fused.replayed},
+                    "note": {"subframes": "strong scaling: ONE view per step, its K subframes split over the GPUs "
+                                          "(BASELINE.json cfg4's wording; the reference's single-view step exactly)",
+                             "views": "weak scaling: one view per GPU per step (a G-view mini-batch)",
+                             "mesh": "G/2 views per step, each view's K subframes split over two GPUs (loss exchange inside "
+                                     "the pair, gradient bucket summed over all GPUs / number of views)"}[other]}
+                del loop2, motion2
+            except Exception as ex:
+                extras["other_modes"][other] = {"sharding": other, "error": repr(ex)}
         sync()
 
     # ---- the same step doing the REFERENCE's render work: the headline step leaves out what the
@@ -701,7 +725,7 @@ def run_rank(args):
         dom = max(stages, key=lambda n: stages[n]["avg_ms"])
         total_bytes = sum(bytes_by_stage.values())
         ms_per_step = dt / args.steps * 1e3
-        value = (K if subframes_mode else world * K) * args.steps / dt
+        value = views_per_step * K * args.steps / dt
         result = {
             "metric": "subframe-renders/sec (fwd+bwd), 1M Gaussians, K=15, 1080p, 1/2/4/8 GPU",
             "value": round(value, 2),
@@ -711,13 +735,15 @@ def run_rank(args):
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "strong" if subframes_mode else "weak",
+            "scaling": ("mesh" if mesh_dims else ("strong" if subframes_mode else "weak")),
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: P={P} Gaussians, {W}x{H}, K={K} subframes fused, curve_order={C}, "
                                    f"SH degree {args.sh_degree} (M={s}); " +
-                                   ("one blurry view per step, its K subframes split over the GPUs" if subframes_mode
+                                   (f"{mesh_dims[0]} blurry views per step, each view's K subframes split over {mesh_dims[1]} GPUs"
+                                    if mesh_dims else
+                                    "one blurry view per step, its K subframes split over the GPUs" if subframes_mode
                                     else "one blurry view per GPU per step"),
                        "step": ("query + fused loss + backward" + (" + grad all-reduce" if world > 1 else "") +
                                 ("" if args.no_optimizer else " + densification stats + fused Adam (all groups; learning "
@@ -780,8 +806,8 @@ def run_rank(args):
                         "min_ms_per_step": round(min(region_dts) / args.steps * 1e3, 3),
                         "median_ms_per_step": round(ms_per_step, 3),
                         "max_ms_per_step": round(max(region_dts) / args.steps * 1e3, 3),
-                        "value_min": round((K if subframes_mode else world * K) * args.steps / max(region_dts), 2),
-                        "value_max": round((K if subframes_mode else world * K) * args.steps / min(region_dts), 2),
+                        "value_min": round(views_per_step * K * args.steps / max(region_dts), 2),
+                        "value_max": round(views_per_step * K * args.steps / min(region_dts), 2),
                         "note": "the timed region (exactly `steps` steps between barriers) run three times back to back; "
                                 "value / ms_per_step are the median region's"},
             "build_id": _lib.build_id(),
@@ -868,6 +894,13 @@ def run_rank(args):
             extras = dict(extras, error="an extra region did not return within DGS_BENCH_EXTRAS_TIMEOUT_S; the headline "
                                         "figures above were measured before it started")
         if result is not None:
+            # both sharding modes as first-class values keyed by mode: whichever the one multi-GPU run
+            # favours can be read as the headline; `value` above is the --shard mode's
+            result["by_mode"] = {args.shard: {"sharding": args.shard, "scaling": result["scaling"], "steps": args.steps,
+                                              "value": result["value"], "ms_per_step": result["ms_per_step"],
+                                              "views_per_step": views_per_step, "regions": result.get("regions")}}
+            for name_, res_ in (extras.pop("other_modes", None) or {}).items():
+                result["by_mode"][name_] = res_
             result["extras"] = extras
             result["config"]["rccl"] = parse_rccl_log(rccl_log)      # (again: now with the extra regions' collectives)
     final_line = json.dumps(result) if result is not None else None

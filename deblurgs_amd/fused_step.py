@@ -79,6 +79,9 @@ class FusedStep:
         # loss never reads it (train.py:150-153, lambda_depth_tv = 0), so the fused step leaves it out unless asked
         # (run(need_depth=True), lambda_depth_tv > 0) -- or unless this is set (bench.py's value_with_depth region)
         self.always_depth = False
+        # "mesh" sharding: the process group of this rank's ROW (the ranks that split one view's subframes); None = the
+        # default group ("subframes" mode: all ranks share the view)
+        self.loss_group = None
         self.eager_preferred = 0    # steps declined for that reason
         self._sel_cache = {}
         self._side = None           # side stream of the chunked gradient all-reduce
@@ -191,7 +194,7 @@ class FusedStep:
         f32 = dict(dtype=torch.float32, device=dev)
         color = torch.zeros((0, 3, H, W), **f32)
         _, l1, sm = sharding.subframe_sharded_loss_grad(color, gt.to(dev, torch.float32).contiguous(), K_total,
-                                                        float(lambda_t))
+                                                        float(lambda_t), self.loss_group)
         # The collectives below are issued in EXACTLY the order run() issues them on a rank that holds subframes -- loss
         # block, depth-smoothness value, gradient bucket (whole or in chunks) -- because RCCL pairs collectives by issue
         # order on the communicator: a different order here would pair a one-element all-reduce with a bucket slice.
@@ -199,7 +202,7 @@ class FusedStep:
         if lambda_depth_tv > 0.0:      # this rank's share of the depth-smoothness value is zero
             import torch.distributed as dist
             depth_tv = torch.zeros((), **f32)
-            dist.all_reduce(depth_tv)
+            dist.all_reduce(depth_tv, group=self.loss_group)
         if ar is None:
             for p in cloud.hot_parameters():
                 p.grad = torch.zeros_like(p)
@@ -688,7 +691,7 @@ class FusedStep:
                                                 _ptr(dsub), _ptr(work), stream), "dgs_blur_loss_grad")
             else:   # the loss block across the ranks holding the view's other subframes
                 from . import sharding
-                dsub, l1, sm = sharding.subframe_sharded_loss_grad(color, gtc, K_total, lam)
+                dsub, l1, sm = sharding.subframe_sharded_loss_grad(color, gtc, K_total, lam, self.loss_group)
                 dsub = dsub.contiguous()
                 losses = torch.stack([l1.reshape(()), sm.reshape(())]).float()
                 blur = None
@@ -725,7 +728,7 @@ class FusedStep:
                 g_depth, depth_tv = g_depth.contiguous(), depth_tv.detach()
                 if shard is not None:
                     import torch.distributed as dist
-                    dist.all_reduce(depth_tv)          # the value only (logging); the gradient is local
+                    dist.all_reduce(depth_tv, group=self.loss_group)   # the value only (logging); the gradient is local
             io.radii, io.dL_dout_color, io.dL_dout_depth = ctypes.c_void_p(radii.data_ptr()), _ptr(dsub), _ptr(g_depth)
             io.scratch, io.scratch_bytes = ctypes.c_void_p(scratch.data_ptr()), scratch.numel()
             io.dL_dmeans3D, io.dL_dmeans2D, io.dL_dsh = _ptr(g_xyz), _ptr(g_means2D), _ptr(g_dc)

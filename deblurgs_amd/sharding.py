@@ -15,6 +15,11 @@ Two modes, both with all Gaussian and trajectory parameters replicated on every 
                after it the same flat gradient all-reduce (per-Gaussian + curve parameters).  Semantics are
                exactly the reference's single-view step.
 
+  "mesh"       (round 6) Gv x Gs ranks, rank = v * Gs + s: the Gs ranks of row v split the K subframes of view v like
+               "subframes" (their loss exchange runs inside the row's own process group), the Gv rows are a mini-batch
+               like "views"; the gradient bucket is SUMMED over all ranks and divided by Gv (the sum over a row is one
+               view's gradient, the mean runs over the views).  Gs = 1 is "views", Gv = 1 is "subframes".
+
 Collective choice: one bucket of P*(11+3M) floats (152 MB at P=1M, M=9) per step, so RCCL can use
 every xGMI link at once; nothing is reduced per tensor.
 """
@@ -183,8 +188,36 @@ def _p2p(sends, recvs, group=None):
         torch.cuda.current_stream(dev).synchronize()
 
 
+def _divisor(average, group=None):
+    """`average` of the reductions below: False = sum, True = mean over the group, a number = sum divided by it (the
+    "mesh" mode's mean over the Gv views of a sum over all Gv * Gs ranks)."""
+    if average is True:
+        return float(dist.get_world_size(group))
+    if average is False or average is None:
+        return 1.0
+    return float(average)
+
+
+def mesh_groups(views, subframes):
+    """Process groups of a Gv x Gs mesh over the default group (rank = v * Gs + s): EVERY rank creates every row's group,
+    in the same order (torch.distributed's rule).  Returns (v, s, row_group) of the calling rank; Gs == 1 -> row_group None
+    (a row of one rank has nothing to exchange)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if views * subframes != world:
+        raise ValueError(f"mesh {views} x {subframes} needs {views * subframes} ranks, the process group has {world}")
+    v, s = divmod(rank, subframes)
+    mine = None
+    if subframes > 1:
+        for row in range(views):
+            g = dist.new_group(ranks=list(range(row * subframes, (row + 1) * subframes)))
+            if row == v:
+                mine = g
+    return v, s, mine
+
+
 def _rank_ordered_sum_(recv, own, rank, world, average):
-    """own <- sum over the ranks of (own on row `rank`, recv[s] elsewhere), added in rank order, / world if average.
+    """own <- sum over the ranks of (own on row `rank`, recv[s] elsewhere), added in rank order, / world if average
+    (/ the number given if `average` is one: _divisor).
     Device tensors: ONE launch (dgs_rank_ordered_sum); CPU tensors (the gloo tests): the same arithmetic in torch."""
     if own.is_cuda:
         import ctypes
@@ -192,14 +225,15 @@ def _rank_ordered_sum_(recv, own, rank, world, average):
         stream = ctypes.c_void_p(torch.cuda.current_stream(own.device).cuda_stream)
         _lib.check(_lib.lib().dgs_rank_ordered_sum(ctypes.c_void_p(recv.data_ptr()), recv.stride(0),
                                                    ctypes.c_void_p(own.data_ptr()), own.numel(), world, rank,
-                                                   float(world) if average else 1.0, stream), "dgs_rank_ordered_sum")
+                                                   float(world) if average is True else _divisor(average), stream),
+                   "dgs_rank_ordered_sum")
         return
     n = own.numel()
     acc = (own if rank == 0 else recv[0, :n]).clone()
     for s in range(1, world):
         acc += own if s == rank else recv[s, :n]
     if average:
-        acc /= world
+        acc /= (world if average is True else _divisor(average))
     own.copy_(acc)
 
 
@@ -294,12 +328,12 @@ def _allreduce(flat, average, group):
     if ALLREDUCE_MODE == "p2p" and flat.dim() == 1 and flat.is_contiguous() and flat.numel() >= P2P_MIN_NUMEL:
         p2p_allreduce_(flat, average, group, force=FORCE_COLLECTIVES)
         return
-    if average and dist.get_backend(group) == "nccl":
+    if average is True and dist.get_backend(group) == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:
-            flat /= dist.get_world_size(group)
+            flat /= _divisor(average, group)
 
 
 def allreduce_slices(tensors, average=False, group=None):
@@ -316,10 +350,13 @@ def allreduce_slices(tensors, average=False, group=None):
                 _allreduce(t, average, group)
         return
     if dist.get_backend(group) == "nccl" and hasattr(dist, "_coalescing_manager"):
-        op = dist.ReduceOp.AVG if average else dist.ReduceOp.SUM
+        op = dist.ReduceOp.AVG if average is True else dist.ReduceOp.SUM
         with dist._coalescing_manager(group=group, device=tensors[0].device, async_ops=False):
             for t in tensors:
                 dist.all_reduce(t, op=op, group=group)
+        if average and average is not True:        # "mesh": a sum over all ranks, a mean over the views
+            for t in tensors:
+                t /= _divisor(average, group)
         return
     for t in tensors:
         _allreduce(t, average, group)

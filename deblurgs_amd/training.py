@@ -29,7 +29,7 @@ def default_optimization_params(**overrides):
 class TrainingLoop:
     def __init__(self, gaussians, cam_motion_module, opt, cameras_extent, white_background=False, spatial_lr_scale=None,
                  distributed=False, tone_mapping=None, fused_step="auto", speculative=True, log_losses=True, graph="auto",
-                 ar_chunks=1, graph_min_reuse=8, emulate_shard=None):
+                 ar_chunks=1, graph_min_reuse=8, emulate_shard=None, mesh=None):
         """distributed = "views" (or True): every rank steps on its own view (the caller passes each rank its cam_idx);
         the per-Gaussian AND trajectory gradients are averaged over ranks (one flat all-reduce + one few-KB one) before
         the Adam step and the densification statistics are combined before every densify_and_prune, so the replicas
@@ -69,8 +69,27 @@ class TrainingLoop:
         Not carried over from train.py: logging / visualiser / checkpoint-saving calls and `args.flag`."""
         self.gaussians, self.motion, self.opt, self.extent = gaussians, cam_motion_module, opt, cameras_extent
         self.mode = {True: "views", False: None, None: None}.get(distributed, distributed)
-        if self.mode not in (None, "views", "subframes"):
-            raise ValueError("distributed must be False, 'views' or 'subframes'")
+        if self.mode not in (None, "views", "subframes", "mesh"):
+            raise ValueError("distributed must be False, 'views', 'subframes' or 'mesh'")
+        # distributed = "mesh", mesh = (Gv, Gs) (round 6): rank = v * Gs + s; the Gs ranks of row v split the subframes of
+        # ONE view (the caller passes every rank of a row the same cam_idx) and exchange the loss block inside the row's own
+        # process group; the Gv rows are a mini-batch of views.  Gradients: summed over all ranks, divided by Gv.
+        self.mesh = None
+        self._row_group, self._row_src = None, 0
+        if self.mode == "mesh":
+            from . import sharding
+            import torch.distributed as dist
+            gv, gs = (int(mesh[0]), int(mesh[1]))
+            v, s_, grp = sharding.mesh_groups(gv, gs)
+            if gs == 1:
+                self.mode = "views"
+            elif gv == 1:
+                self.mode = "subframes"
+            else:
+                self.mesh = (gv, gs, v, s_)
+                self._row_group, self._row_src = grp, v * gs
+        # how the gradient bucket is combined: mean over the views of a mini-batch, sum over the slices of one view
+        self._avg = {"views": True, "subframes": False, "mesh": float(self.mesh[0]) if self.mesh else False}.get(self.mode, False)
         self.distributed = self.mode is not None
         self._stat_prev = None
         self.white_background = white_background
@@ -113,6 +132,7 @@ class TrainingLoop:
                     self._fused = FusedStep(gaussians, cam_motion_module, lambda_hinge=max(opt.lambda_hinge, 0.0),
                                             speculative=speculative)
                     self._fused.capture_large = self._graph_always
+                    self._fused.loss_group = self._row_group
             except NotImplementedError:
                 if fused_step is True:
                     raise
@@ -154,7 +174,7 @@ class TrainingLoop:
         if self._fused is not None:
             return self._step_fused(iteration, cam_idx, subframe_indice, lambda_t_smooth, densification_threshold)
         L_hinge = losses.hinge_l2(g._opacity) if opt.lambda_hinge > 0.0 else None
-        if self.mode == "subframes":
+        if self.mode in ("subframes", "mesh"):
             return self._step_subframe_sharded(iteration, cam_idx, subframe_indice, lambda_t_smooth, L_hinge,
                                                densification_threshold)
         dev = g._xyz.device
@@ -189,7 +209,7 @@ class TrainingLoop:
         if n > 0 and uniform is None:
             uniform = torch.rand(n).to(bg.device)
         buf = torch.cat([bg.reshape(3).float()] + ([uniform.reshape(n).float()] if n > 0 else []))
-        dist.broadcast(buf, src=0)
+        dist.broadcast(buf, src=self._row_src, group=self._row_group)    # ("mesh": the first rank of this view's row)
         return buf[:3].contiguous(), (buf[3:].contiguous() if n > 0 else None)
 
     def _step_fused(self, iteration, cam_idx, subframe_indice, lambda_t_smooth, densification_threshold, exact=False):
@@ -214,14 +234,15 @@ class TrainingLoop:
         shard = None
         if self.distributed:
             self._drain_dist_flags(lag=2)
-        if self.mode == "subframes":
+        if self.mode in ("subframes", "mesh"):
             import torch.distributed as dist
-            shard = self.emulate_shard or (dist.get_rank(), dist.get_world_size())
+            shard = self.emulate_shard or ((self.mesh[3], self.mesh[1]) if self.mesh else
+                                           (dist.get_rank(), dist.get_world_size()))
             bg, uniform = draws_on_device()
             bg, uniform = self._shared_draws(bg, uniform)
         ar = None
         if self.distributed and self.ar_chunks > 1:      # the bucket is reduced inside run(), chunk by chunk
-            ar = {"chunks": self.ar_chunks, "average": self.mode != "subframes"}
+            ar = {"chunks": self.ar_chunks, "average": self._avg}
         # single process: the backward updates the densification statistics itself (no [K,P,3] screen gradient stored);
         # sharded runs keep the separate launch (the statistics are snapshotted before it for their all-reduce)
         stats = None
@@ -290,9 +311,9 @@ class TrainingLoop:
             # "views": a mini-batch of views, gradients averaged; "subframes": partial sums of one view's gradient
             extra = [p for p in self.motion.parameters() if p.requires_grad]
             if ar is not None:         # (the bucket was reduced inside run(), also by a rank without subframes)
-                sharding.allreduce_small_grads(extra, average=self.mode != "subframes")
+                sharding.allreduce_small_grads(extra, average=self._avg)
             else:
-                sharding.flat_allreduce_grads(g.hot_parameters(), average=self.mode != "subframes", extra=extra)
+                sharding.flat_allreduce_grads(g.hot_parameters(), average=self._avg, extra=extra)
         g.optimizer.skip_flag_ptr = skip
         r = {"viewspace_points_all": fr["viewspace_grad"], "radii_all": fr["radii"], "K_total": fr["K"],
              "skip_flag_ptr": skip}
@@ -399,14 +420,15 @@ class TrainingLoop:
         import torch.distributed as dist
         from . import sharding
         g, opt = self.gaussians, self.opt
-        rank, world = self.emulate_shard or (dist.get_rank(), dist.get_world_size())
+        rank, world = self.emulate_shard or ((self.mesh[3], self.mesh[1]) if self.mesh else
+                                             (dist.get_rank(), dist.get_world_size()))
         # one view, one background, one alignment jitter: every rank uses rank 0's draws (the fused path does the same)
         bg, uniform = self._shared_draws(self._bg_host.to(g._xyz.device),
                                          None if self._uni_host is None else self._uni_host.to(g._xyz.device))
         r = self.motion.query(cam_idx=cam_idx, subframe_indice=subframe_indice, compute_blurred=False,
                               shard=(rank, world), background=bg, uniform=uniform)
         gt = self._ground_truth(cam_idx, r["gt"], iteration)
-        dS, l1, sm = sharding.subframe_sharded_loss_grad(r["subframes"], gt, r["K_total"], lambda_t_smooth)
+        dS, l1, sm = sharding.subframe_sharded_loss_grad(r["subframes"], gt, r["K_total"], lambda_t_smooth, self._row_group)
         roots, seeds = [], []
         if r["subframes"].shape[0] > 0:
             roots.append(r["subframes"])
@@ -421,7 +443,7 @@ class TrainingLoop:
                 roots.append(opt.lambda_depth_tv * local)
                 seeds.append(None)
                 depth_tv = local.detach()
-            dist.all_reduce(depth_tv)
+            dist.all_reduce(depth_tv, group=self._row_group)
         if roots:
             torch.autograd.backward(roots, seeds)
         l1, sm = float(l1), float(sm)
@@ -429,7 +451,7 @@ class TrainingLoop:
             # every rank holds the whole cloud: the hinge gradient is added once, on rank 0, and reaches the others
             # through the gradient sum (after the rasteriser's backward, so that it accumulates into the bucket)
             (opt.lambda_hinge * L_hinge * (1.0 if rank == 0 else 0.0)).backward()
-        sharding.flat_allreduce_grads(g.hot_parameters(), average=False,
+        sharding.flat_allreduce_grads(g.hot_parameters(), average=self._avg,
                                       extra=[p for p in self.motion.parameters() if p.requires_grad])
         self._tail(iteration, r, densification_threshold)
         loss = l1 + lambda_t_smooth * sm + (opt.lambda_hinge * float(L_hinge) if L_hinge is not None else 0.0)

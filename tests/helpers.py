@@ -411,6 +411,14 @@ class OracleRun:
 
 CHAIN_KEYS = {"dL_dmeans3D", "xyz", "dL_dscales", "scaling", "dL_drotations", "rotation", "dL_dcov3D_precomp",
               "dL_dcov3D"}     # (xyz and dL_dcov3D turn out well-conditioned everywhere; they are kept here so that it shows)
+# dL_dconic (the compositing backward's own sink) joined the conditioning-aware keys in round 6: with the exempt PIXELS cut from
+# every pixel within a margin of a threshold (0.5 %) to the pixels whose decisions really differ (1e-5), rows on which two
+# fp32 builds of the REFERENCE differ by several 1e-4 -- sums of signed w dx^2 terms that cancel -- are no longer hidden
+# behind the mask (cfg5: the worst row is 1.5e-4 off here where the reference's own builds are 3.7e-4 apart).  The rows the
+# reference agrees with itself on (noise <= WELL_ROW) keep the flat bars; the rows in between must stay within
+# MID_NOISE_MULT x the reference's own noise.
+NOISE_AWARE_DIRECT = {"dL_dconic"}
+MID_NOISE_MULT = 10.0
 ILL_ROW = 1e-3         # a Gaussian is ill-conditioned for a chain output when two correct fp32 builds of the reference ITSELF
                        # (fp32 vs double accumulation; FMA contraction on vs off) differ by more than this on its row
 ILL_FRAC = 5e-4        # at most this fraction of the Gaussians that receive a gradient may be ill-conditioned (+ ILL_MIN)
@@ -503,7 +511,7 @@ def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, floor=ROW_FLOOR, report=Non
             return col, (float(err_row[sel].max()) if sel.any() else 0.0)
 
         noise_row = np.maximum(row_errors(n, b, floor)[0], row_errors(f, b, floor)[0])
-        if key not in CHAIN_KEYS:
+        if key not in CHAIN_KEYS and key not in NOISE_AWARE_DIRECT:
             col, row = flat(np.ones(a.shape[0], bool))
             if report is not None:
                 rep = {"col": col, "row": row, "noise_row_max": float(noise_row.max())}
@@ -541,6 +549,10 @@ def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, floor=ROW_FLOOR, report=Non
                                  "colmax": colmax.tolist()}
         if report is not None:
             report.append((key, rep))
+        if key in NOISE_AWARE_DIRECT and mid.any():
+            _check(rep["mid_row_over_noise"] <= MID_NOISE_MULT,
+                   f"{key}: a row between the well- and ill-conditioned ones is {rep['mid_row_over_noise']:.1f} x the reference's "
+                   f"own fp32 noise off (allowed {MID_NOISE_MULT})", failures)
         _check(ill.sum() <= ill_min + ill_frac * active,
                f"{key}: {int(ill.sum())} of {active} Gaussians are ill-conditioned (two fp32 builds of the reference differ "
                f"by more than {ILL_ROW} on their row)", failures)

@@ -1042,6 +1042,26 @@ def test_two_ranks_subframes_equal_the_single_process_step(gpu, tmp_path):
         assert x.shape == y.shape and float((x - y).abs().max()) <= 2e-3 * (float(x.abs().max()) + 1e-12)
 
 
+def test_four_ranks_mesh_equals_the_two_rank_view_batch(gpu, tmp_path):
+    """The hybrid mesh: 2 views x 2-way subframe sharding on four ranks (one device, gloo).  Row v's two
+    ranks split the subframes of view v and exchange the loss block inside the row's own group; the bucket is summed over
+    all four and divided by the two views.  That is the 2-rank "views" step on the same two views: same gradients at the
+    first full iteration up to the order of the cross-rank sums, replicas bit-identical through densifications."""
+    import sys
+    import torch
+    root, tool, env = _two_rank_env()
+    a, b = str(tmp_path / "views2.pt"), str(tmp_path / "mesh22.pt")
+    common = ["--iters", "14", "--curve-start", "2", "--same-seed", "--ar-chunks", "4", "--densify-interval", "6"]
+    _run([sys.executable, tool, "--ranks", "2", "--mode", "views"] + common + ["--out", a], env)
+    out = _run([sys.executable, tool, "--ranks", "4", "--mode", "mesh", "--mesh-views", "2"] + common + ["--out", b], env)
+    assert "identical: True" in out and "densified: True" in out, out
+    da, db = torch.load(a), torch.load(b)
+    for i, (x, y) in enumerate(zip(da["grads_first"], db["grads_first"])):
+        assert (x is None) == (y is None), i
+        if x is not None and x.numel():
+            assert float((x - y).abs().max()) <= 2e-5 * (float(x.abs().max()) + 1e-30), (i, float((x - y).abs().max()))
+
+
 def test_two_ranks_step_at_the_metric_size_equals_the_single_process_steps(gpu, tmp_path):
     """BASELINE.json cfg4's workload -- the metric configuration (1M Gaussians, 1920x1080, K = 15) sharded over ranks --
     through the suite, not only through a log: two ranks on the one device (gloo), one iteration with
@@ -1216,8 +1236,10 @@ def test_two_ranks_bench_in_the_drivers_launch_form(gpu):
     pr = line["config"]["per_rank"]
     assert len(pr["ms_per_step_by_rank"]) == 2 and pr["min_ms_per_step"] <= pr["max_ms_per_step"] <= line["ms_per_step"] * 1.01
     ex = line["extras"]
-    assert ex["other_mode"]["sharding"] == "subframes" and ex["other_mode"]["scaling"] == "strong"
-    assert ex["other_mode"]["value"] > 0, ex["other_mode"]
+    bm = line["by_mode"]              # both sharding modes as first-class values, keyed by mode
+    assert set(bm) == {"views", "subframes"} and bm["views"]["value"] == line["value"]
+    assert bm["subframes"]["sharding"] == "subframes" and bm["subframes"]["scaling"] == "strong"
+    assert bm["subframes"]["value"] > 0, bm["subframes"]
     ab = ex["allreduce_ab"]
     assert ab["collective"]["values_ok"] and ab["p2p"]["values_ok"], ab
     assert ab["collective"]["bytes"] == ab["p2p"]["bytes"] == 4 * 100_000 * (11 + 27)

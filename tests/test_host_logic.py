@@ -173,6 +173,63 @@ def test_view_sharding_averages_gradients(tmp_path):
         assert torch.allclose(a, b / 2, atol=1e-6)
 
 
+def _worker_mesh(rank, world, port, K, out):
+    """2 views x 2-way subframe sharding on four gloo ranks: row v splits view v's subframes (loss block inside the row's
+    group), the bucket is summed over all four and divided by the two views."""
+    sharding = _setup(rank, world, port)
+    gv, gs = 2, 2
+    v, s_, grp = sharding.mesh_groups(gv, gs)
+    assert (v, s_) == divmod(rank, gs) and grp is not None
+    torch.manual_seed(0)
+    params = [torch.randn(20, 3, requires_grad=True), torch.randn(7, requires_grad=True)]
+    torch.manual_seed(100 + v)          # the view of this ROW: both of its ranks hold the same poses and target
+    view = (torch.eye(4)[None].repeat(K, 1, 1) + 0.01 * torch.randn(K, 4, 4)).requires_grad_(True)
+    proj = (torch.eye(4)[None].repeat(K, 1, 1) + 0.01 * torch.randn(K, 4, 4)).requires_grad_(True)
+    gt = torch.rand(3, 6, 5)
+    k0, k1 = sharding.shard_range(K, s_, gs)
+    sub = _standin_render(params, view, proj)[k0:k1]
+    l1, sm = sharding.subframe_sharded_loss_backward(sub, gt, K, k0, 0.05, group=grp)
+    sharding.flat_allreduce_grads(params, average=float(gv))       # sum over all ranks / number of views
+    # both all-reduce paths give the same mean-of-sums
+    y = torch.full((3000,), float(rank + 1))
+    sharding.p2p_allreduce_(y, average=float(gv))
+    assert torch.allclose(y, torch.full((3000,), (1 + 2 + 3 + 4) / 2.0))
+    vals = torch.tensor([l1, sm])
+    every = [torch.zeros(2) for _ in range(world)]
+    dist.all_gather(every, vals)
+    if rank == 0:
+        torch.save(dict(g=[p.grad.clone() for p in params], losses=every), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mesh_sharding_is_a_view_batch_of_subframe_sharded_views(tmp_path):
+    """sharding.mesh_groups + the numeric `average` of the reductions: a 2 x 2 mesh gives the mean over the two views of
+    each view's full single-process gradient, and every rank of a row sees its view's loss values."""
+    from deblurgs_amd import losses
+    K = 5
+    out = str(tmp_path / "mesh.pt")
+    mp.spawn(_worker_mesh, args=(4, 29671, K, out), nprocs=4, join=True)
+    got = torch.load(out)
+    acc, vals = None, []
+    for v in range(2):
+        torch.manual_seed(0)
+        params = [torch.randn(20, 3, requires_grad=True), torch.randn(7, requires_grad=True)]
+        torch.manual_seed(100 + v)
+        view = (torch.eye(4)[None].repeat(K, 1, 1) + 0.01 * torch.randn(K, 4, 4)).requires_grad_(True)
+        proj = (torch.eye(4)[None].repeat(K, 1, 1) + 0.01 * torch.randn(K, 4, 4)).requires_grad_(True)
+        gt = torch.rand(3, 6, 5)
+        total, blur, l1, sm = losses.blur_loss_torch(_standin_render(params, view, proj), gt, 0.05)
+        total.backward()
+        vals.append((float(l1), float(sm)))
+        g = [p.grad for p in params]
+        acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+    for a, b in zip(got["g"], acc):
+        assert torch.allclose(a, b / 2, atol=1e-6), (a - b / 2).abs().max()
+    for rank, lv in enumerate(got["losses"]):
+        assert abs(float(lv[0]) - vals[rank // 2][0]) < 1e-6 and abs(float(lv[1]) - vals[rank // 2][1]) < 1e-6
+
+
 def _worker_p2p_allreduce(rank, world, port, out):
     sharding = _setup(rank, world, port)
     res = {}

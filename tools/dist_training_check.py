@@ -25,7 +25,9 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ranks", type=int, default=2)
-    ap.add_argument("--mode", default="views", choices=["views", "subframes"])
+    ap.add_argument("--mode", default="views", choices=["views", "subframes", "mesh"])
+    ap.add_argument("--mesh-views", type=int, default=2,
+                    help="--mode mesh: Gv rows of ranks / Gv (each row splits one view's subframes; rank = v * Gs + s)")
     ap.add_argument("--iters", type=int, default=33)
     ap.add_argument("--no-densify", action="store_true")
     ap.add_argument("--out", default=None)
@@ -101,7 +103,9 @@ def main():
         sc = synthetic.make_scene(3000, 128, 96, K=K, seed=21, sigma_px=3.0)
     cloud = GaussianCloud.from_scene(sc, dev)
     ref = RefCamera(sc["W"], sc["H"], sc["FoVx"], sc["FoVy"], device=dev)
-    n_views = max(world, 2)
+    gv = args.mesh_views if args.mode == "mesh" else world
+    vrow = rank // max(world // max(gv, 1), 1) if args.mode == "mesh" else rank     # the view index this rank works on
+    n_views = max(gv if args.mode == "mesh" else world, 2)
     torch.manual_seed(100)                        # the SAME module (ground truths, curves) on every rank
     gt = torch.rand(n_views, 3, sc["H"], sc["W"], device=dev) * 0.5
     m = CameraMotionModule(ref, gt, curve_order=C, num_subframes=K, device=dev, curve_random_sample=args.random_sample)
@@ -116,7 +120,8 @@ def main():
         densify_grad_threshold_final=1e-5, opacity_reset_interval=1000, curve_alignment_lr=1e-3, curve_alignment_start=4,
         lambda_depth_tv=args.depth_tv)
     loop = TrainingLoop(cloud, m, opt, cameras_extent=1.0, distributed=args.mode if world > 1 else False,
-                        ar_chunks=args.ar_chunks, graph={"auto": "auto", "always": "always", "off": False}[args.graph])
+                        ar_chunks=args.ar_chunks, graph={"auto": "auto", "always": "always", "off": False}[args.graph],
+                        mesh=(gv, world // gv) if args.mode == "mesh" else None)
     inplace = []
     _orig = sharding.flat_allreduce_grads
 
@@ -138,7 +143,8 @@ def main():
     for it in range(1, args.iters + 1):
         snap["it"] = it
         torch.manual_seed(it if args.same_seed else 7919 * (rank + 1) + it)   # ranks draw DIFFERENT random numbers
-        cam = (it + rank + args.cam_offset) % n_views if args.mode == "views" else (it + args.cam_offset) % n_views
+        cam = ((it + vrow + args.cam_offset) % n_views if args.mode in ("views", "mesh") else
+               (it + args.cam_offset) % n_views)
         if it == args.force_overflow and rank == min(1, world - 1) and loop._fused is not None:
             loop._fused._poll(block=True)
             assert loop._fused._seen, "no duplicate count learnt yet: nothing to shrink"
