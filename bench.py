@@ -670,6 +670,30 @@ def run_rank(args):
         ref_lists_depth = side_region(True, True, "the reference's lists AND the depth images: every piece of render work "
                                                   "the reference does per subframe (the worst case for this line)")
 
+    # ---- the reference's second use of the operator: inference (test.py:117, render_spiral.py:29 call render() under
+    # no_grad).  The K subframes of the view through gaussian_renderer.render_subframes with nothing that can receive a
+    # gradient: DgsProblem.forward_only = 1 (no final_T / n_contrib / cov3D / mask stores), the exact two-phase forward
+    # with its one host read per call, depth images included (render() returns them).
+    fwd_only = None
+    if world == 1 and emu is None and not args.autograd_path:
+        from deblurgs_amd import gaussian_renderer
+        with torch.no_grad():
+            wv_, fp_, cc_ = (t.contiguous() for t in motion.get_trajectory_matrices(0))
+            bg_ = torch.zeros(3, device=dev)
+            for _ in range(3):
+                gaussian_renderer.render_subframes(wv_, fp_, cc_, ref_cam, cloud, bg_)
+            nf = max(10, args.steps // 4)
+            sync()
+            t0 = time.time()
+            for _ in range(nf):
+                gaussian_renderer.render_subframes(wv_, fp_, cc_, ref_cam, cloud, bg_)
+            torch.cuda.synchronize()
+            dtf = time.time() - t0
+        fwd_only = {"value": round(K * nf / dtf, 2), "unit": "subframe-renders/sec (forward only)",
+                    "ms_per_call": round(dtf / nf * 1e3, 3), "calls": nf,
+                    "note": "K subframes per call, colour + depth images, DgsProblem.forward_only = 1, tile culling as the "
+                            "headline, the exact two-phase forward (one host read of the duplicate count per call)"}
+
     if rank == 0:
         # R from a state-level forward (the operator keeps it in its autograd ctx)
         with torch.no_grad():
@@ -813,6 +837,9 @@ def run_rank(args):
             "build_id": _lib.build_id(),
             "stages": stages,
         }
+        if fwd_only is not None:
+            result["forward_only_renders_per_s"] = fwd_only["value"]
+            result["forward_only"] = fwd_only
         if with_depth is not None:
             result["value_with_depth"] = with_depth
         if ref_lists is not None:

@@ -2,7 +2,7 @@
 # Collects the round's committed evidence on the GPU box into gpurun_out/profiles_<round>/ (copy what is to be judged into
 # profiles/ afterwards): kernel-trace summary, VALU counters, FETCH / WRITE counters (separate passes, kernel-trace only),
 # the per-class issue costs, and the derived json files.   usage: tools/collect_profiles.sh [round]
-rnd=${1:-r05}
+rnd=${1:-r06}
 root=$(cd "$(dirname "$0")/.." && pwd)
 cd $root
 export TMPDIR=/tmp
@@ -30,7 +30,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -o pmc --output-format c
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -o pmc --output-format csv -- $B > $out/write.log 2>&1
 R=$(grep -o '"R_total": [0-9]*' $out/valu.log | head -1 | grep -o '[0-9]*$')
 python3 profiles/make_valu.py $out/valu metric $rnd $R > $out/make_valu.log 2>&1
-python3 profiles/make_traffic.py $out/fetch $out/write metric $rnd > $out/make_traffic.log 2>&1
+python3 profiles/make_traffic.py $out/fetch $out/write metric $rnd 2 > $out/make_traffic.log 2>&1
 cp profiles/valu_$rnd.json profiles/traffic_$rnd.json profiles/valu_peak_$rnd.json profiles/isa_census_$rnd.json $out/ 2>/dev/null
 unset DGS_BWD_OVERLAP
 tail -3 $out/make_valu.log; echo "R_total=$R"; ls $out

@@ -107,9 +107,14 @@ def census(asm):
         if "composite" not in name:
             continue
         short = "composite_fwd" if "fwd" in name else "composite_bwd"
-        m = re.search(r"kernelILb(\d)(?:ELb(\d))?", name)
+        m = re.search(r"kernelILb(\d)(?:ELb(\d))?(?:ELb(\d))?", name)
         if m:
-            short += "<" + ",".join("true" if x == "1" else "false" for x in m.groups() if x is not None) + ">"
+            flags = [x for x in m.groups() if x is not None]
+            if "fwd" in name and len(flags) == 3:
+                if flags[2] == "1":
+                    continue           # the parity tests' checksum variant of the forward: not a product kernel
+                flags = flags[:2]      # <WITHDEPTH, KEEP>
+            short += "<" + ",".join("true" if x == "1" else "false" for x in flags) + ">"
         maxd = max(b[1] for b in blocks)
         passes = [b for b in blocks if b[3] and b[1] == maxd]
         add = lambda bs: {c: sum(b[2].get(c, 0) for b in bs) for c in CLASSES}

@@ -15,6 +15,11 @@ Model (every assumption is in the output):
   * "subframes": before the backward, the partial blur image [3,H,W] is all-reduced and one boundary subframe travels to
     each neighbour (blur_bytes / link, both directions at once); after it the whole bucket's all-reduce is exposed (the
     per-Gaussian kernel of 1-2 subframes is too short to hide anything).
+  * "mesh" (round 6, G >= 4): G/2 rows of two ranks, a row splits ONE view's subframes (the measured slice of a 2-rank
+    "subframes" step), exchanges its blur image and boundary frame inside the pair, and the bucket is all-reduced over all
+    G ranks, fully exposed (as for "subframes"); the job renders G/2 views per step.
+  THE LINK MODEL IS UNVERIFIED: no xGMI transfer has ever been timed by this project (one-GPU boxes only); every predicted
+  speed-up below inherits that.
   speed-up = renders per second of G GPUs / renders per second of the single-GPU step (bench.py's default: TrainingLoop's own graph policy) measured in the
   same invocation on the same box.
 """
@@ -57,8 +62,9 @@ def main():
     t1 = base["ms_per_step"]
     doc = {"config": a.config, "K": K, "single_gpu": {"ms_per_step": t1, "value": base["value"],
                                                        "graph": base["config"].get("graph")},
-           "model": {"link_GBps_per_direction": a.link_GBps, "chunks": a.chunks,
-                     "assumptions": "see the docstring of tools/predict_scaling.py; no xGMI transfer has been timed"},
+           "model": {"link_GBps_per_direction": a.link_GBps, "chunks": a.chunks, "link_model": "UNVERIFIED",
+                     "assumptions": "see the docstring of tools/predict_scaling.py; the xGMI link model is UNVERIFIED: no "
+                                    "xGMI transfer has been timed"},
            "rows": []}
     views = run_bench(common + ["--shard", "views", "--ar-chunks", str(a.chunks), "--emulate-shard", "0/8"])
     ev = views["emulated_shard"]
@@ -96,9 +102,28 @@ def main():
             row_s[kind] = {"exposed_comm_ms": round(comm, 3), "step_ms": round(step, 3),
                            "renders_per_s": round(K / step * 1e3, 1), "speedup": round(t1 / step, 2)}
         doc["rows"].append(row_s)
+        # ---- mesh: G/2 views per step, each view's subframes split over a pair of ranks
+        if G >= 4 and G % 2 == 0:
+            sizes2 = [shard_range(K, r, 2)[1] - shard_range(K, r, 2)[0] for r in range(2)]
+            r2 = max(range(2), key=lambda r: (sizes2[r], -r))
+            if "pair_slice" not in doc:
+                doc["pair_slice"] = run_bench(common + ["--shard", "subframes", "--ar-chunks", str(a.chunks), "--emulate-shard",
+                                                        f"{r2}/2"])["emulated_shard"]
+            pair = doc["pair_slice"]
+            t_blur2 = ar(blur, 2)
+            row_m = {"G": G, "sharding": f"mesh {G // 2}x2", "views_per_step": G // 2, "slice_ms": pair["ms_per_step"],
+                     "allreduce_ms": t_ar, "blur_allreduce_ms": t_blur2, "boundary_ms": blur / link * 1e3}
+            for kind in ("direct", "ring"):
+                comm = t_blur2[kind] + blur / link * 1e3 + t_ar[kind]
+                step = pair["ms_per_step"] + comm
+                row_m[kind] = {"exposed_comm_ms": round(comm, 3), "step_ms": round(step, 3),
+                               "renders_per_s": round((G // 2) * K / step * 1e3, 1),
+                               "speedup": round((G // 2) * t1 / step, 2)}
+            doc["rows"].append(row_m)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(doc, open(a.out, "w"), indent=1)
-    print(f"single GPU: {t1:.3f} ms per K={K} step ({base['value']:.1f} renders/s)")
+    print(f"single GPU: {t1:.3f} ms per K={K} step ({base['value']:.1f} renders/s)   [xGMI link model UNVERIFIED: "
+          f"{a.link_GBps:.1f} GB/s per link and direction assumed]")
     print("| G | sharding | rank's own work (ms) | exchanges direct / ring (ms) | step direct / ring (ms) | speed-up direct / ring |")
     print("|---|---|---|---|---|---|")
     for r in doc["rows"]:
