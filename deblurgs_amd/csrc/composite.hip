@@ -95,7 +95,7 @@ __device__ __forceinline__ float dgs_power2(float A, float B, float C, float dx,
 #endif
 }
 
-// DGS_EXACT_POWER=1 (A/B build only, tools/r05_calls/parity_ab.sh; never the shipped library): the three places where the
+// DGS_EXACT_POWER=1 (A/B build only, git history: tools/r05_calls/parity_ab.sh; never the shipped library): the three places where the
 // per-pair arithmetic departs from the letter of the reference are put back --
 //   * `power` in the natural domain with the reference's own expression and term order, every operation rounded on its
 //     own (forward.cu:351 / backward.cu:572: -0.5f * (a dx dx + c dy dy) - b dx dy), then ONE multiply by log2(e) in front
