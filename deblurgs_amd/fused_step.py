@@ -217,12 +217,12 @@ class FusedStep:
                 p.grad = flat[offs[i]:offs[i] + sizes[i]].view(p.shape)
             if int(ar.get("chunks", 1)) <= 1 or P < 512:
                 if P > 0:
-                    sharding._allreduce(flat, bool(ar.get("average", False)), ar.get("group"))
+                    sharding._allreduce(flat, ar.get("average", False), ar.get("group"))
             else:
                 widths = [n // max(P, 1) for n in sizes]
                 for b0, b1 in sharding.chunk_bounds(P, int(ar["chunks"])):
                     sharding.allreduce_slices([flat[offs[i] + b0 * c:offs[i] + b1 * c] for i, c in enumerate(widths)],
-                                              bool(ar.get("average", False)), ar.get("group"))
+                                              ar.get("average", False), ar.get("group"))
         if m.is_optimizing():
             m._trans._control_points.grad, m._rot._control_points.grad = torch.zeros_like(ct_all), torch.zeros_like(cr_all)
             if nu_raw.numel() > 0:
@@ -784,7 +784,7 @@ class FusedStep:
                             if t_ar is not None and ci == 0:
                                 t_ar[0].record(side)
                             sharding.allreduce_slices([flat[offs[i] + b0 * c:offs[i] + b1 * c] for i, c in enumerate(widths)],
-                                                      bool(ar.get("average", False)), ar.get("group"))
+                                                      ar.get("average", False), ar.get("group"))
                     _lib.check(L.dgs_backward_pose(ctypes.byref(prob), ctypes.byref(io), stream), "dgs_backward_pose")
                     done = torch.cuda.Event()
                     done.record(side)
@@ -794,7 +794,7 @@ class FusedStep:
                     stream_obj.wait_event(done)
                 elif ar is not None and P > 0:
                     from . import sharding
-                    sharding._allreduce(flat, bool(ar.get("average", False)), ar.get("group"))
+                    sharding._allreduce(flat, ar.get("average", False), ar.get("group"))
                 if P == 0:
                     flat.zero_()
                     if g_means2D is not None:

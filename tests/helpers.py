@@ -327,7 +327,7 @@ class OracleRun:
     """The checker side of a backward parity test, on the OpenMP oracle (deterministic, double accumulation):
     forward of the K subframes, the unstable-pixel masks, and the backward three times -- "double": accumulating in
     double (the value the HIP result is compared with); "f32": accumulating in emulated fp32 in the same order AND with
-    every exp() moved by one ulp (round 6: what builds with different exp() implementations differ by); "fma":
+    every exp() moved by two ulps (round 6: CUDA documents expf to 2 ulp; what builds with different exp() implementations differ by); "fma":
     the same source built with multiply-adds contracted into FMAs, which is what nvcc's default (--fmad=true) makes of
     the reference.  |f32 - double| and |fma - double| are the two ways in which correct fp32 builds of the reference
     algorithm differ from each other; they are large exactly where a gradient component is ill-conditioned (scale /
