@@ -526,23 +526,9 @@ void dgs_oracle_render_backward(int W, int H, const uint32_t* ranges, const uint
             const float* co = conic_opacity + 4 * (size_t)g;
             const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
             if (power > 0.0f) continue;
-            float G = std::exp(power);
-            float alpha = std::min(0.99f, co[3] * G);
+            const float G = std::exp(power);
+            const float alpha = std::min(0.99f, co[3] * G);
             if (alpha < 1.0f / 255.0f) continue;
-#ifdef _OPENMP
-            if (f32) {
-              // The noise-floor mode also moves exp() by two ulps, up or down by the parity of (pixel, list position): what
-              // two correct builds of the reference may differ by when their exp() implementations do -- CUDA documents
-              // expf() to 2 ulp (CUDA C++ Programming Guide, "Mathematical Functions", single precision), glibc's is
-              // < 1 ulp, an exp2-based evaluation (v_exp_f32 behind a multiply by log2(e)) a few.  The DECISIONS above are
-              // taken with the unperturbed value.  Round 6: a
-              // sub-pixel splat whose scale / rotation chain amplifies its few pixels' values a thousandfold sat 1.5e-4 off
-              // with a noise estimate of 2e-5 -- the estimate knew about accumulation order and FMA contraction only.
-              const float toward = ((pix_id + s) & 1u) ? 2.0f : 0.0f;
-              G = std::nextafter(std::nextafter(G, toward), toward);
-              alpha = std::min(0.99f, co[3] * G);
-            }
-#endif
             T = T / (1.f - alpha);
             const float dchannel_dcolor = alpha * T;
             float dL_dalpha = 0.0f;

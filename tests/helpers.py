@@ -326,8 +326,7 @@ ROW_FLOOR = 0.1
 class OracleRun:
     """The checker side of a backward parity test, on the OpenMP oracle (deterministic, double accumulation):
     forward of the K subframes, the unstable-pixel masks, and the backward three times -- "double": accumulating in
-    double (the value the HIP result is compared with); "f32": accumulating in emulated fp32 in the same order AND with
-    every exp() moved by two ulps (round 6: CUDA documents expf to 2 ulp; what builds with different exp() implementations differ by); "fma":
+    double (the value the HIP result is compared with); "f32": accumulating in emulated fp32 in the same order; "fma":
     the same source built with multiply-adds contracted into FMAs, which is what nvcc's default (--fmad=true) makes of
     the reference.  |f32 - double| and |fma - double| are the two ways in which correct fp32 builds of the reference
     algorithm differ from each other; they are large exactly where a gradient component is ill-conditioned (scale /
@@ -456,7 +455,7 @@ def _check(cond, msg, failures):
 
 
 def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, floor=ROW_FLOOR, report=None, row_tol=ROW_TOL, ill_frac=ILL_FRAC,
-                       ill_min=ILL_MIN, well_frac=WELL_FRAC):
+                       ill_min=ILL_MIN, well_frac=WELL_FRAC, chain_tol=None):
     """hip[key] against ora["double"][key] with FLAT bars: every gradient component (column) within `tol` = 1e-4 of its
     own largest magnitude, every Gaussian (row) within `row_tol` = 1e-3 of its own gradient (floored at `floor` x the
     column scale); pose matrices per [4,4] matrix relative to its largest entry.
@@ -575,7 +574,8 @@ def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, floor=ROW_FLOOR, report=Non
                 keep[over] = False
                 col, row = flat(keep)
                 rep["exceptions"] = over.tolist()
-        _check(col <= tol, f"{key} col on well-conditioned rows: {col:.2e} > {tol:.0e}", failures)
+        ctol = tol if (chain_tol is None or key not in CHAIN_KEYS) else chain_tol
+        _check(col <= ctol, f"{key} col on well-conditioned rows: {col:.2e} > {ctol:.0e}", failures)
         _check(row <= row_tol, f"{key} row on well-conditioned rows: {row:.2e} > {row_tol:.0e}", failures)
     if REPORT_ONLY and failures:
         print("PARITY REPORT (no assertion):")
