@@ -428,16 +428,29 @@ EXC_MULT = 3.0         # ... each within this multiple of the row bar
 POSE_NOISE_MULT = 4.0  # dL_dviewmatrix sums the chain over ALL Gaussians, the ill-conditioned ones included
 
 
-def row_errors(a, b, floor=ROW_FLOOR):
-    """Per-row version of grad_errors: (err[rows], colmax[cols]).  Each component is normalised by its column scale, a
-    row's error is measured against the row's own largest normalised component, floored at `floor`."""
-    a = np.asarray(a, np.float64)
+def row_errors(a, b, floor=ROW_FLOOR, _ref=None):
+    """Per-row version of grad_errors: (err[rows], dn_rowmax[rows], colmax[cols]).  Each component is normalised by its
+    column scale, a row's error is measured against the row's own largest normalised component, floored at `floor`.
+    _ref: what depends on b alone (row_reference(b)), when several arrays are held against the same b."""
     b = np.asarray(b, np.float64)
-    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
-    colmax = np.abs(b).max(axis=0)
+    b = b.reshape(b.shape[0], -1)
+    colmax, scale, bn_rowmax = _ref if _ref is not None else row_reference(b)
+    d = np.subtract(np.asarray(a, np.float64).reshape(b.shape), b)
+    np.abs(d, out=d)
+    d /= scale
+    dn_rowmax = d.max(axis=1)
+    return dn_rowmax / np.maximum(bn_rowmax, floor), dn_rowmax, colmax
+
+
+def row_reference(b):
+    """(colmax, scale, largest normalised component per row) of the reference array of row_errors."""
+    b = np.asarray(b, np.float64)
+    b = b.reshape(b.shape[0], -1)
+    ab = np.abs(b)
+    colmax = ab.max(axis=0)
     scale = np.where(colmax > 0, colmax, 1.0)
-    dn, bn = np.abs(a - b) / scale, np.abs(b) / scale
-    return dn.max(axis=1) / np.maximum(bn.max(axis=1), floor), dn.max(axis=1), colmax
+    ab /= scale
+    return colmax, scale, ab.max(axis=1)
 
 
 WELL_ROW = 5e-5        # end to end, a chain output is held to the flat bars on the Gaussians whose row two correct fp32 builds
@@ -492,7 +505,8 @@ def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, floor=ROW_FLOOR, report=Non
             a, b, n, f = (x.reshape(-1, x.shape[-1]) for x in (a, b, n, f))
             if key == "dL_dmeans2D":
                 a, b, n, f = a[:, :2], b[:, :2], n[:, :2], f[:, :2]
-        err_row, _, colmax = row_errors(a, b, floor)
+        ref_b = row_reference(b)
+        err_row, _, colmax = row_errors(a, b, floor, ref_b)
         if os.environ.get("DGS_PARITY_ROW") and REPORT_ONLY:      # one Gaussian across all outputs (debugging aid)
             rsel = int(os.environ["DGS_PARITY_ROW"])
             rows_ = [rsel] if a.shape[0] == b.shape[0] and key not in ("dL_dmeans2D", "dL_dconic") else \
@@ -510,7 +524,7 @@ def assert_grads_close(hip, ora, keys, tol=GRAD_TOL, floor=ROW_FLOOR, report=Non
             col = float((d[sel][:, nz].max(axis=0) / colmax[nz]).max()) if nz.any() and sel.any() else 0.0
             return col, (float(err_row[sel].max()) if sel.any() else 0.0)
 
-        noise_row = np.maximum(row_errors(n, b, floor)[0], row_errors(f, b, floor)[0])
+        noise_row = np.maximum(row_errors(n, b, floor, ref_b)[0], row_errors(f, b, floor, ref_b)[0])
         if key not in CHAIN_KEYS and key not in NOISE_AWARE_DIRECT:
             col, row = flat(np.ones(a.shape[0], bool))
             if report is not None:
