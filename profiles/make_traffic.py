@@ -81,14 +81,18 @@ def main():
     ftot, fcnt = per_kernel(sys.argv[1], "FETCH_SIZE", totals=True)
     wtot, wcnt = per_kernel(sys.argv[2], "WRITE_SIZE", totals=True)
     steps_f, steps_w = max(fcnt.get("composite_bwd", 1), 1), max(wcnt.get("composite_bwd", 1), 1)
-    # (the profiled command also runs two probe forwards outside its steps: a kernel's bytes per step are its average per
-    # launch times its launches per step, the latter rounded -- 45 launches over 43 steps is one per step)
+    # Launches per step: the profiled command also runs forwards outside its steps (two probes, the forward-only region),
+    # so a forward-chain kernel is counted per launch of the compositing forward and a backward-chain kernel per launch of
+    # the compositing backward (one of each per step); the two kernels outside the rasteriser run once per step.
+    FORWARD = {"preprocess", "scan(aux)", "duplicate", "sort(hist)", "sort(scatter)", "sort(aux)", "ranges", "composite_fwd",
+               "depth_order(hist)", "depth_order(scatter)", "depth_order(aux)", "tile_cull(count)", "tile_cull(gather)"}
     per_step = collections.defaultdict(float)
-    for k, v in ftot.items():
-        per_launch = v / fcnt[k] * (2.0 if k in STREAMING else 1.0)
-        per_step[BENCH_STAGE.get(k, "(other)")] += per_launch * max(1, round(fcnt[k] / steps_f))
-    for k, v in wtot.items():
-        per_step[BENCH_STAGE.get(k, "(other)")] += v / wcnt[k] * max(1, round(wcnt[k] / steps_w))
+    for tot, cnt, stream_x2 in ((ftot, fcnt, True), (wtot, wcnt, False)):
+        n_fwd, n_bwd = max(cnt.get("composite_fwd", 1), 1), max(cnt.get("composite_bwd", 1), 1)
+        for k, v in tot.items():
+            per_launch = v / cnt[k] * (2.0 if (stream_x2 and k in STREAMING) else 1.0)
+            launches = cnt[k] / (n_fwd if k in FORWARD else n_bwd)
+            per_step[BENCH_STAGE.get(k, "(other)")] += per_launch * max(1, round(launches))
     out["_per_step"] = {k: int(v) for k, v in sorted(per_step.items())}
     out["_per_step_total"] = int(sum(per_step.values()))
     out["_per_step_note"] = ("HBM-side bytes per training step by bench.py stage, all launches of the stage's kernels "
