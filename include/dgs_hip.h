@@ -249,7 +249,7 @@ typedef struct DgsLayout {
 
 int dgs_abi_version(void);
 const char* dgs_last_error(void);
-/* SHA-256 (64 hex digits) over the sources this binary was built from -- deblurgs_amd/csrc/*.hip, *.h, include/dgs_hip.h --
+/* SHA-256 (64 hex digits) over the sources this binary was built from -- every .hip and .h file of deblurgs_amd/csrc, include/dgs_hip.h --
  * and the compiler flag table of deblurgs_amd/build.py, computed by the build and compiled in.  A loader that has the
  * sources at hand (deblurgs_amd/_lib.py) recomputes it and refuses a stale binary; bench.py prints it. */
 const char* dgs_build_id(void);

@@ -279,3 +279,17 @@ def test_l0_C_module_has_the_reference_signatures():
     assert list(inspect.signature(_C.rasterize_gaussians_backward).parameters) == bwd and len(bwd) == 25
     assert list(inspect.signature(_C.mark_visible).parameters) == ["means3D", "viewmatrix", "projmatrix"]
     assert sorted(_C.__all__) == ["mark_visible", "rasterize_gaussians", "rasterize_gaussians_backward"]
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/dgs_hip.h is the drop-in boundary: it must compile as C99 on its own (gcc is in the image)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "h.c"
+    src.write_text('#include "%s"\nint main(void) { DgsProblem p; DgsContextOptions o; (void)p; (void)o; return 0; }\n'
+                   % os.path.join(ROOT, "include", "dgs_hip.h"))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-o", str(tmp_path / "h.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
