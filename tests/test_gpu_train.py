@@ -882,8 +882,17 @@ def test_training_matches_the_cpu_reference_loop_on_a_toy_deblurring_scene(gpu):
         return evaluate(cl, mm), cl._xyz.shape[0]
 
     after_cpu, n_cpu = run_cpu(init)
-    moved = dict(init, xyz=(init["xyz"] * (1.0 + 1e-6 * rng.standard_normal(init["xyz"].shape))).astype(np.float32))
-    after_cpu2, n_cpu2 = run_cpu(moved)
+    # The second CPU run -- the same loop from a start moved by 1e-6 -- only measures how far the REFERENCE carries a
+    # rounding-level difference; it costs as much as the first (40-60 s of the suite's budget), so the
+    # suite takes its result from a committed fixture of this very run (tests/golden/toy_training_spread.json; the live run
+    # on another host differs from it by the same mechanism it measures) and DGS_TOY_SPREAD_LIVE=1 runs it live.
+    import json
+    if os.environ.get("DGS_TOY_SPREAD_LIVE", "0") == "1":
+        moved = dict(init, xyz=(init["xyz"] * (1.0 + 1e-6 * rng.standard_normal(init["xyz"].shape))).astype(np.float32))
+        after_cpu2, n_cpu2 = run_cpu(moved)
+    else:
+        fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "toy_training_spread.json")))
+        after_cpu2, n_cpu2 = tuple(fx["after_cpu_moved_start_psnr_blur_sharp"]), int(fx["points_cpu_moved_start"])
     spread = (abs(after_cpu[0] - after_cpu2[0]), abs(after_cpu[1] - after_cpu2[1]), abs(n_cpu - n_cpu2))
     print(f"\n[toy training] PSNR (blur, sharp): start {before}, GPU {after_gpu}, CPU reference {after_cpu} / from a start "
           f"moved by 1e-6: {after_cpu2}; points {init['xyz'].shape[0]} -> GPU {n_gpu} / CPU {n_cpu} / {n_cpu2}; "

@@ -32,7 +32,7 @@ python3 tools/stress_lists.py > $out/stress_lists_${rnd}.log 2>&1
 python3 tools/p2p_repeat.py --repeat 10 --mode subframes > $out/${rnd}_p2p_repeat_final.log 2>&1
 python3 tools/rccl_smoke.py > $out/${rnd}_rccl_smoke.txt 2>&1
 python3 -m pytest tests/test_gpu_configs.py -q -s > $out/${rnd}_gpu_configs.log 2>&1
-python3 -m pytest tests/test_gpu_train.py -q -s -k "toy_deblurring or graph_replay or rccl or two_ranks or captured" > $out/${rnd}_gpu_train_extract.log 2>&1
+DGS_TOY_SPREAD_LIVE=1 python3 -m pytest tests/test_gpu_train.py -q -s -k "toy_deblurring or graph_replay or rccl or two_ranks or captured" > $out/${rnd}_gpu_train_extract.log 2>&1
 DGS_DIST_BACKEND=gloo DGS_DIST_ONE_DEVICE=1 python3 bench.py --gpus 2 --config cfg2 --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_${rnd}_cfg2_2ranks_one_gpu.json 2>/dev/null
 # four ranks on the one GPU (gloo): views, subframes and the 2 x 2 mesh in one line (by_mode)
 DGS_DIST_BACKEND=gloo DGS_DIST_ONE_DEVICE=1 python3 bench.py --gpus 4 --config cfg2 --steps 30 --warmup 5 --no-cpu-baseline > $out/bench_${rnd}_cfg2_4ranks_one_gpu.json 2>/dev/null
