@@ -72,6 +72,22 @@ def unstable_pixels(st, alpha_tol=5e-7, power_tol=1e-4, T_tol=1e-8):
     return flag.reshape(H, W)
 
 
+def exempt_pixels(scene, K, states, **kw):
+    """[K] masks [H,W]: the pixels where the HIP forward and the oracle's took a DIFFERENT per-pair decision -- their
+    contributor checksums (DgsForwardOut.debug_contrib_checksum: a tile_cull = 0 forward through the C ABI; dgs_oracle_render)
+    or their last contributors differ.  What the parity tests exempt from the 1e-4 bars since round 6 (the margin rule of
+    unstable_pixels / oracle.unstable exempted every pixel NEAR a threshold: hundreds of times more).  kw: what
+    hip_forward_state takes (sh_degree, use_sigmoid, colors_precomp, cov3D_precomp, scale_modifier)."""
+    st = hip_forward_state(scene, K, checksum=True, **kw)
+    masks = []
+    for k in range(K):
+        o = states[k]
+        d = (st["contrib_checksum"][k].reshape(-1) != o["contrib_checksum"]) | \
+            (st["n_contrib"][k].reshape(-1) != o["n_contrib"])
+        masks.append(d.reshape(o["H"], o["W"]))
+    return masks
+
+
 # --------------------------------------------------------------------------------------------- HIP side
 def _t(a, device="cuda"):
     import torch
@@ -332,10 +348,12 @@ class OracleRun:
     algorithm differ from each other; they are large exactly where a gradient component is ill-conditioned (scale /
     rotation behind the covariance chain, the view matrix)."""
 
-    def __init__(self, scene, K, margin_masks=True, **kw):
+    def __init__(self, scene, K, margin_masks=True, exact=False, **kw):
         """margin_masks=False: the caller will install the exact disagreement masks (use_exact_masks) and the oracle's
-        threshold-margin masks are not computed."""
+        threshold-margin masks are not computed.  exact=True: the masks are exempt_pixels() of this scene (a HIP forward
+        with contributor checksums is run here: needs the GPU)."""
         self.scene, self.K, self.kw = scene, K, kw
+        margin_masks = margin_masks and not exact
         oracle.use_openmp(True)
         try:
             self.states = oracle.map_subframes(lambda k: oracle_forward(scene, k, **kw), range(K))
@@ -345,6 +363,8 @@ class OracleRun:
         for st in self.states:
             st.pop("keys_unsorted", None)
             st.pop("vals_unsorted", None)
+        if exact:
+            self.unstable = exempt_pixels(scene, K, self.states, **kw)
 
     def use_exact_masks(self, hip_checksum, hip_n_contrib, ks=None):
         """Replaces the margin masks (every pixel whose ORACLE traversal sits within a margin of a threshold: 0.5 % of the

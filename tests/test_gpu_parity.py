@@ -8,8 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (OracleRun, assert_grads_close, tile_cull, wide_records, hip_forward_backward, hip_forward_state, oracle_forward,
-                     oracle_forward_backward, relerr, synthetic, unstable_pixels)
+from helpers import (OracleRun, assert_grads_close, exempt_pixels, tile_cull, wide_records, hip_forward_backward, hip_forward_state,
+                     oracle_forward, oracle_forward_backward, relerr, synthetic, unstable_pixels)
 
 pytestmark = pytest.mark.gpu
 
@@ -213,9 +213,10 @@ def test_depth_order_beyond_27_key_bits_through_the_forward(gpu):
 
 def test_forward_images(scene_states):
     sc, hip, ora = scene_states
+    ex = exempt_pixels(sc, sc["K"], ora)
     for k, o in enumerate(ora):
-        unstable = unstable_pixels(o)
-        assert unstable.mean() < 0.02
+        unstable = ex[k]                      # where the two traversals took a different per-pair decision
+        assert unstable.mean() < 2e-4 and unstable.sum() <= unstable_pixels(o).sum() + 2
         dc = np.abs(hip["color"][k] - o["color"]).max(axis=0)
         dd = np.abs(hip["depth"][k][0] - o["depth"][0]) / sc["z_far"]
         assert dc[~unstable].max() <= IMG_TOL, f"colour k={k}: {dc[~unstable].max()}"
@@ -242,7 +243,7 @@ def sharp_backward_check(sc, K, keys=GRAD_KEYS, depth=True, seed=5, chain_tol=No
     scale and every Gaussian against its own magnitude, flat bars 1e-4 / 1e-3, an explicit (asserted tiny) set of ill-conditioned Gaussians for the
     outputs behind the covariance chain, upstream gradient zero on the pixels whose oracle traversal sits on a
     threshold."""
-    run = OracleRun(sc, K, **kw)
+    run = OracleRun(sc, K, exact=True, **kw)      # exempt: the pixels whose per-pair decisions differ (round 6), nothing more
     gC, gD = _grads(sc, K, seed=seed, depth=depth)
     gC, gD = run.mask(gC, gD)
     hip = hip_forward_backward(sc, K, gC, gD, **kw)
@@ -335,9 +336,9 @@ def test_variants(gpu, variant):
         keys += ["dL_dcov3D_precomp", "dL_dsh"]
     else:
         keys += ["dL_dsh", "dL_dscales", "dL_drotations"]
+    ex = exempt_pixels(sc, 2, ora["states"], **kw)
     for k in range(2):
-        un = unstable_pixels(ora["states"][k])
-        assert np.abs(hip["color"][k] - ora["color"][k]).max(axis=0)[~un].max() <= IMG_TOL
+        assert np.abs(hip["color"][k] - ora["color"][k]).max(axis=0)[~ex[k]].max() <= IMG_TOL
     for key in keys:
         assert relerr(hip[key].reshape(ora[key].shape), ora[key]) <= GRAD_TOL, key
     sharp_backward_check(sc, 2, keys=keys, seed=11, **kw)
@@ -1044,8 +1045,9 @@ def test_fuzz_shapes_against_oracle(gpu, P, W, H, K, seed, sigma, deg, kw):
     hip = hip_forward_backward(sc, K, gC, gD, **kw)
     ora = oracle_forward_backward(sc, K, gC, gD, **kw)
     assert np.array_equal(hip["radii"], ora["radii"])
+    ex = exempt_pixels(sc, K, ora["states"], **kw)
     for k in range(K):
-        un = unstable_pixels(ora["states"][k])
+        un = ex[k]
         d = np.abs(hip["color"][k] - ora["color"][k]).max(axis=0)
         assert d[~un].max() <= IMG_TOL, (k, d[~un].max())
         dd = np.abs(hip["depth"][k][0] - ora["depth"][k][0]) / sc["z_far"]
@@ -1056,7 +1058,7 @@ def test_fuzz_shapes_against_oracle(gpu, P, W, H, K, seed, sigma, deg, kw):
         e = relerr(a.reshape(b.shape), b)
         assert e <= 1e-3, f"{key}: rel err {e:.3e}"
     # and per component / per Gaussian, away from the unstable pixels, against the noise-aware bar
-    run = OracleRun(sc, K, **kw)
+    run = OracleRun(sc, K, exact=True, **kw)
     gCm, gDm = run.mask(gC, gD)
     # (the adversarial sprinkles -- needles, degenerate scales, near-plane crossers -- are a few % of this cloud: they may
     # all land in the explicit ill-conditioned set; everything else is held to the flat bars)
