@@ -893,7 +893,14 @@ def test_training_matches_the_cpu_reference_loop_on_a_toy_deblurring_scene(gpu):
     else:
         fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "toy_training_spread.json")))
         after_cpu2, n_cpu2 = tuple(fx["after_cpu_moved_start_psnr_blur_sharp"]), int(fx["points_cpu_moved_start"])
+        fx_pair = fx["for_reference_cpu_unmoved_in_that_run"]     # the pair of runs the fixture came from: its own distance
     spread = (abs(after_cpu[0] - after_cpu2[0]), abs(after_cpu[1] - after_cpu2[1]), abs(n_cpu - n_cpu2))
+    if os.environ.get("DGS_TOY_SPREAD_LIVE", "0") != "1":
+        # (should the live run land next to the fixture's moved-start result by chance, the distance the fixture's own
+        # pair of runs was apart still stands for what the reference loop does to a 1e-6 difference)
+        spread = (max(spread[0], abs(fx_pair["psnr_blur_sharp"][0] - after_cpu2[0])),
+                  max(spread[1], abs(fx_pair["psnr_blur_sharp"][1] - after_cpu2[1])),
+                  max(spread[2], abs(fx_pair["points"] - n_cpu2)))
     print(f"\n[toy training] PSNR (blur, sharp): start {before}, GPU {after_gpu}, CPU reference {after_cpu} / from a start "
           f"moved by 1e-6: {after_cpu2}; points {init['xyz'].shape[0]} -> GPU {n_gpu} / CPU {n_cpu} / {n_cpu2}; "
           f"captured {loop._fused.captured}, replayed {loop._fused.replayed}")
