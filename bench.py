@@ -79,6 +79,9 @@ def parse_args(argv=None):
                          "(one-rank process group): 'subframes' = its slice of the view's K subframes, 'views' = a whole "
                          "view through the sharded code path.  Prints an 'emulated_shard' line, not the metric line; "
                          "tools/predict_scaling.py turns these into DESIGN.md's predicted scaling table")
+    ap.add_argument("--extras-mesh", action="store_true",
+                    help="N >= 4 GPUs: also time the (N/2) x 2 mesh among the extra regions (off by default: its row groups "
+                         "have never met RCCL on real hardware, and an extra region that hangs costs the run its exit code 0)")
     ap.add_argument("--no-extras", action="store_true",
                     help="N > 1 GPUs: skip the extra regions behind the headline one (other sharding mode, collective vs "
                          "point-to-point all-reduce A/B)")
@@ -584,7 +587,7 @@ def run_rank(args):
             extras["allreduce_ab"] = {"error": repr(ex)}
         # every sharding mode but the headline's, timed on the same ranks (the mesh: Gv x 2 when the ranks allow it)
         others = [m_ for m_ in ("views", "subframes") if m_ != args.shard]
-        if world >= 4 and world % 2 == 0 and args.shard != "mesh":
+        if args.extras_mesh and world >= 4 and world % 2 == 0 and args.shard != "mesh":
             others.append("mesh")
         extras["other_modes"] = {}
         for other in others:

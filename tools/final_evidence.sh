@@ -35,6 +35,6 @@ python3 -m pytest tests/test_gpu_configs.py -q -s > $out/${rnd}_gpu_configs.log 
 DGS_TOY_SPREAD_LIVE=1 python3 -m pytest tests/test_gpu_train.py -q -s -k "toy_deblurring or graph_replay or rccl or two_ranks or captured" > $out/${rnd}_gpu_train_extract.log 2>&1
 DGS_DIST_BACKEND=gloo DGS_DIST_ONE_DEVICE=1 python3 bench.py --gpus 2 --config cfg2 --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_${rnd}_cfg2_2ranks_one_gpu.json 2>/dev/null
 # four ranks on the one GPU (gloo): views, subframes and the 2 x 2 mesh in one line (by_mode)
-DGS_DIST_BACKEND=gloo DGS_DIST_ONE_DEVICE=1 python3 bench.py --gpus 4 --config cfg2 --steps 30 --warmup 5 --no-cpu-baseline > $out/bench_${rnd}_cfg2_4ranks_one_gpu.json 2>/dev/null
+DGS_DIST_BACKEND=gloo DGS_DIST_ONE_DEVICE=1 python3 bench.py --gpus 4 --config cfg2 --steps 30 --warmup 5 --no-cpu-baseline --extras-mesh > $out/bench_${rnd}_cfg2_4ranks_one_gpu.json 2>/dev/null
 for f in $out/bench_${rnd}_*.json; do tail -1 $f | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$f'.split('/')[-1], d['value'], d['ms_per_step'])"; done
 tail -3 $out/${rnd}_gpu_configs.log
