@@ -7,7 +7,7 @@
  *   - plain C: raw device pointers, sizes and a HIP stream handle; no torch types.  The caller owns every
  *     byte (inputs, outputs, gradients, the three state blobs and the backward scratch); the library never
  *     allocates device memory.  Blob sizes come from the dgs_*_bytes() queries, and the carving of a blob
- *     into sub-arrays is a pure function of (P, W, H, K, R, wide_records), replayed identically by forward and backward
+ *     into sub-arrays is a pure function of (P, W, H, K, R, wide_records, forward_only), replayed identically by forward and backward
  *     (the reference does the same with GeometryState/ImageState/BinningState::fromChunk,
  *     rasterizer_impl.cu:155-194,389-391).
  *   - the duplicates are generated in (k, depth, index) order (a 15 M-pair sort of the Gaussians) so that the
