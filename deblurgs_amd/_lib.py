@@ -4,6 +4,7 @@ This is the ONLY way the package reaches device code.  There is no CPU or eager-
 library is missing or a call fails, a RuntimeError is raised (the CPU oracle under /oracle is test
 infrastructure and is never imported from here).
 """
+import contextlib
 import ctypes
 import os
 
@@ -274,9 +275,6 @@ def context(device=None):
     if key not in _contexts:
         _contexts[key] = create_context(context_options_from_env())
     return _contexts[key]
-
-
-import contextlib
 
 
 @contextlib.contextmanager

@@ -853,7 +853,17 @@ static hipError_t side_stream(DgsContext* ctx) {
   e = hipStreamCreateWithFlags(&ctx->s2, hipStreamNonBlocking);
   for (int i = 0; i < BWD_MAX_PARTS && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->done[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming);
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess) {   // give back what was created: the next large backward tries again from nothing
+    for (int i = 0; i < BWD_MAX_PARTS; i++) {
+      if (ctx->done[i] != nullptr) (void)hipEventDestroy(ctx->done[i]);
+      ctx->done[i] = nullptr;
+    }
+    if (ctx->join != nullptr) (void)hipEventDestroy(ctx->join);
+    if (ctx->s2 != nullptr) (void)hipStreamDestroy(ctx->s2);
+    ctx->join = nullptr;
+    ctx->s2 = nullptr;
+    return e;
+  }
   ctx->side_device = dev;
   ctx->side_ready = true;
   return hipSuccess;
@@ -1215,10 +1225,10 @@ int dgs_context_destroy(DgsContext* ctx) {
 int dgs_profile_enable(DgsContext* ctx, int32_t on) {
   if (ctx == nullptr) return fail(DGS_E_ARG, "profile_enable: null context");
   std::lock_guard<std::mutex> lk(ctx->mu);
-  if (on && ctx->prof.beg == nullptr) {
-    ctx->prof.beg = new (std::nothrow) hipEvent_t[PROF_MAX];
-    ctx->prof.end = new (std::nothrow) hipEvent_t[PROF_MAX];
-    ctx->prof.stage = new (std::nothrow) int[PROF_MAX];
+  if (on) {   // (each array on its own: a call that ran out of host memory half-way is completed by the next one)
+    if (ctx->prof.beg == nullptr) ctx->prof.beg = new (std::nothrow) hipEvent_t[PROF_MAX];
+    if (ctx->prof.end == nullptr) ctx->prof.end = new (std::nothrow) hipEvent_t[PROF_MAX];
+    if (ctx->prof.stage == nullptr) ctx->prof.stage = new (std::nothrow) int[PROF_MAX];
     if (ctx->prof.beg == nullptr || ctx->prof.end == nullptr || ctx->prof.stage == nullptr)
       return fail(DGS_E_ARG, "profile_enable: out of host memory");
   }
