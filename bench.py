@@ -692,10 +692,28 @@ def run_rank(args):
                 gaussian_renderer.render_subframes(wv_, fp_, cc_, ref_cam, cloud, bg_)
             torch.cuda.synchronize()
             dtf = time.time() - t0
+            # ... and the reference's own inference call shape: render() on ONE camera (K = 1), one call per frame
+            from deblurgs_amd.pose import MiniCam
+            cams1 = [MiniCam(ref_cam.image_width, ref_cam.image_height, ref_cam.FoVy, ref_cam.FoVx, ref_cam.znear,
+                             ref_cam.zfar, wv_[k_], fp_[k_], cc_[k_]) for k_ in range(K)]
+            for k_ in range(min(3, K)):
+                gaussian_renderer.render(cams1[k_], cloud, bg_)
+            n1 = max(15, args.steps // 2)
+            sync()
+            t0 = time.time()
+            for i_ in range(n1):
+                gaussian_renderer.render(cams1[i_ % K], cloud, bg_)
+            torch.cuda.synchronize()
+            dt1 = time.time() - t0
         fwd_only = {"value": round(K * nf / dtf, 2), "unit": "subframe-renders/sec (forward only)",
                     "ms_per_call": round(dtf / nf * 1e3, 3), "calls": nf,
                     "note": "K subframes per call, colour + depth images, DgsProblem.forward_only = 1, tile culling as the "
-                            "headline, the exact two-phase forward (one host read of the duplicate count per call)"}
+                            "headline, the exact two-phase forward (one host read of the duplicate count per call)",
+                    "single_camera": {"value": round(n1 / dt1, 2), "unit": "render() calls / s (K = 1, forward only)",
+                                      "ms_per_call": round(dt1 / n1 * 1e3, 3), "calls": n1,
+                                      "note": "gaussian_renderer.render(camera, cloud, bg) under no_grad, the call of the "
+                                              "reference's test.py:117 / render_spiral.py:29: activation getters + SH "
+                                              "concat + two-phase forward + host read, once per frame"}}
 
     if rank == 0:
         # R from a state-level forward (the operator keeps it in its autograd ctx)

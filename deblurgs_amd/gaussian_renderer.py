@@ -18,12 +18,15 @@ from .diff_gaussian_rasterization import (GaussianRasterizationSettings, Gaussia
 def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     """Render the scene.  Background tensor (bg_color) must be on the GPU."""
     # zero tensor whose .grad receives the 2-D (screen-space) mean gradients
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True,
-                                          device=pc.get_xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    if torch.is_grad_enabled():
+        screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True,
+                                              device=pc.get_xyz.device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    else:   # inference: nothing will ever be written to its .grad; the dict keeps the reference's zeros tensor
+        screenspace_points = torch.zeros_like(pc.get_xyz)
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     raster_settings = GaussianRasterizationSettings(
@@ -41,6 +44,16 @@ def render(viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, o
         prefiltered=False,
         debug=False,
     )
+    if override_color is None and getattr(pc, "fused_activations", False) and not torch.is_grad_enabled():
+        # inference on a cloud whose activations the kernels apply themselves (as render_subframes does): no getter
+        # launches, no dc | rest concat (108 MB per frame at 1 M Gaussians, SH degree 2) -- same images, same radii
+        raster_settings = raster_settings._replace(campos=viewpoint_camera.camera_center.reshape(1, 3))
+        images, depths, radii = rasterize_cloud_subframes(
+            pc._xyz, None, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation,
+            viewpoint_camera.world_view_transform.reshape(1, 4, 4), viewpoint_camera.full_proj_transform.reshape(1, 4, 4),
+            raster_settings, pc.scale_lower_bound, isotropic=getattr(pc, "use_isotrophic", False))
+        return {"render": images[0], "depth": depths[0], "viewspace_points": screenspace_points,
+                "visibility_filter": radii[0] > 0, "radii": radii[0]}
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     shs = None
     colors_precomp = None

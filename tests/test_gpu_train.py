@@ -363,6 +363,36 @@ def _fused_fixture(seed=3, K=5, P=3000, curve_type="se3"):
     return sc, cloud, m
 
 
+@pytest.mark.parametrize("iso", [False, True])
+def test_render_of_one_camera_under_no_grad_takes_the_raw_parameter_path_with_the_same_bits(gpu, iso):
+    """gaussian_renderer.render(camera, cloud, bg) is the reference's inference call (test.py:117, render_spiral.py:29: one
+    camera per call, under no_grad).  On a GaussianCloud it hands the raw parameters to the kernels (no getter launches, no
+    dc | rest concat) with DgsProblem.forward_only = 1: image, depth and radii are bit for bit subframe k of the K-fused call
+    (what training rasterises), and agree with the same call with gradients enabled -- the torch getters + the autograd
+    Function, whose exp() can differ from the kernels' by an ulp (GaussianCloud.device_activations) -- to 2e-5."""
+    import torch
+    from deblurgs_amd import gaussian_renderer
+    sc, cloud, m = _fused_fixture(seed=5, K=4, P=4000)
+    cloud.use_isotrophic = iso
+    bg = torch.tensor([0.1, 0.3, 0.6], device="cuda")
+    cams = m.get_trajectory(1)
+    with torch.no_grad():
+        wv, fp, cc = (t.contiguous() for t in m.get_trajectory_matrices(1))
+        fused = gaussian_renderer.render_subframes(wv, fp, cc, m.ref_cam, cloud, bg)
+    for k, cam in enumerate(cams):
+        with torch.no_grad():
+            a = gaussian_renderer.render(cam, cloud, bg)
+        b = gaussian_renderer.render(cam, cloud, bg)            # grad enabled: getters + _RasterizeGaussians
+        assert b["render"].requires_grad and not a["render"].requires_grad
+        for key in ("render", "depth", "radii"):
+            assert torch.equal(a[key], fused[key][k]), (k, key)
+        assert torch.equal(a["visibility_filter"], fused["visibility_filter"][k])
+        assert float((a["render"] - b["render"].detach()).abs().max()) <= 2e-5
+        assert float((a["depth"] - b["depth"].detach()).abs().max()) <= 2e-5 * float(b["depth"].detach().abs().max())
+        assert float((a["radii"] != b["radii"]).float().mean()) <= 1e-3
+        assert a["viewspace_points"].shape == cloud.get_xyz.shape
+
+
 @pytest.mark.parametrize("subframes,iso,curve,tv", [("all", False, "se3", 0.0), (3, False, "se3", 0.0),
                                                     (1, False, "se3", 0.0), ("all", True, "se3", 0.0),
                                                     ("all", False, "quarternion_cartesian", 0.0),
