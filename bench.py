@@ -712,8 +712,9 @@ def run_rank(args):
                     "single_camera": {"value": round(n1 / dt1, 2), "unit": "render() calls / s (K = 1, forward only)",
                                       "ms_per_call": round(dt1 / n1 * 1e3, 3), "calls": n1,
                                       "note": "gaussian_renderer.render(camera, cloud, bg) under no_grad, the call of the "
-                                              "reference's test.py:117 / render_spiral.py:29: activation getters + SH "
-                                              "concat + two-phase forward + host read, once per frame"}}
+                                              "reference's test.py:117 / render_spiral.py:29, once per frame: the cloud's "
+                                              "raw parameters go to the kernels (no getter launches, no SH concat), "
+                                              "two-phase forward with its host read; GPU-bound (about 30 small launches)"}}
 
     if rank == 0:
         # R from a state-level forward (the operator keeps it in its autograd ctx)
