@@ -1025,6 +1025,26 @@ FUZZ = [
 ]
 
 
+def _fuzz_sweep(n, seed0=9000):
+    """DGS_FUZZ_SWEEP=n appends n more cases drawn from a seeded generator (odd sizes, 1-12 subframes, splats from sub-pixel
+    to a dozen pixels, every SH degree, both colour activations): a one-off wider net, not part of the default suite."""
+    rng = np.random.default_rng(seed0)
+    out = []
+    for i in range(n):
+        deg = int(rng.integers(0, 4))
+        kw = {}
+        if rng.random() < 0.35:
+            kw["use_sigmoid"] = True
+        if rng.random() < 0.5:
+            kw["sh_degree"] = int(rng.integers(0, deg + 1))
+        out.append((int(rng.integers(200, 3000)), int(rng.integers(9, 200)), int(rng.integers(9, 140)),
+                    int(rng.integers(1, 13)), seed0 + i, float(np.exp(rng.uniform(np.log(0.3), np.log(12.0)))), deg, kw))
+    return out
+
+
+FUZZ = FUZZ + _fuzz_sweep(int(os.environ.get("DGS_FUZZ_SWEEP", "0")))
+
+
 @pytest.mark.parametrize("P,W,H,K,seed,sigma,deg,kw", FUZZ)
 def test_fuzz_shapes_against_oracle(gpu, P, W, H, K, seed, sigma, deg, kw):
     sc = synthetic.make_scene(P, W, H, K=K, seed=seed, sigma_px=sigma, sh_degree=deg)
@@ -1056,7 +1076,11 @@ def test_fuzz_shapes_against_oracle(gpu, P, W, H, K, seed, sigma, deg, kw):
         a, b = hip[key], ora[key]
         assert np.isfinite(a).all(), key
         e = relerr(a.reshape(b.shape), b)
-        assert e <= 1e-3, f"{key}: rel err {e:.3e}"
+        # (this first comparison keeps EVERY pixel's upstream gradient, also at the pixels where an exp() ulp flips one of the
+        # reference's thresholds: the nine curated scenes stay below 1e-3 with them; in the seeded sweep one flipped pixel of
+        # a 100 x 50 image is up to 7e-3 of a gradient's largest entry, so there this is the gross-error guard and the
+        # comparison below, with the flipped pixels' upstream gradients zeroed, is the parity statement)
+        assert e <= (1e-3 if seed < 9000 else 1e-2), f"{key}: rel err {e:.3e}"
     # and per component / per Gaussian, away from the unstable pixels, against the noise-aware bar
     run = OracleRun(sc, K, exact=True, **kw)
     gCm, gDm = run.mask(gC, gD)
