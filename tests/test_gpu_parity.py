@@ -122,6 +122,23 @@ def test_depth_order_segmented_sort(gpu, K, P, kind):
     assert flag == int(wide_needed), (kind, flag, wide_needed)
 
 
+def _fuzz_sweep(n, seed0=9000):
+    """DGS_FUZZ_SWEEP=n appends n more cases drawn from a seeded generator (odd sizes, 1-12 subframes, splats from sub-pixel
+    to a dozen pixels, every SH degree, both colour activations): a one-off wider net, not part of the default suite."""
+    rng = np.random.default_rng(seed0)
+    out = []
+    for i in range(n):
+        deg = int(rng.integers(0, 4))
+        kw = {}
+        if rng.random() < 0.35:
+            kw["use_sigmoid"] = True
+        if rng.random() < 0.5:
+            kw["sh_degree"] = int(rng.integers(0, deg + 1))
+        out.append((int(rng.integers(200, 3000)), int(rng.integers(9, 200)), int(rng.integers(9, 140)),
+                    int(rng.integers(1, 13)), seed0 + i, float(np.exp(rng.uniform(np.log(0.3), np.log(12.0)))), deg, kw))
+    return out
+
+
 # --------------------------------------------------------------------------------------------- stage parity
 @pytest.fixture(scope="module")
 def scene_states(gpu):
@@ -132,10 +149,13 @@ def scene_states(gpu):
 
 
 def test_preprocess_bit_exact(scene_states):
-    sc, hip, ora = scene_states
+    _check_preprocess_bits(*scene_states)
+
+
+def _check_preprocess_bits(sc, hip, ora, min_visible=100, relu=True):
     for k, o in enumerate(ora):
         vis = o["radii"] > 0
-        assert vis.sum() > 100
+        assert vis.sum() > min_visible
         assert np.array_equal(hip["radii"][k], o["radii"]), "radii"
         assert np.array_equal(hip["tiles_touched"][k], o["tiles_touched"]), "tiles_touched"
         rows = hip["rows"][k][vis]
@@ -145,13 +165,19 @@ def test_preprocess_bit_exact(scene_states):
         assert np.array_equal(rows[:, 2:6].view(np.uint32), o["conic_opacity"][vis].view(np.uint32)), "conic bits"
         assert np.abs(rows[:, 6:9] - o["rgb"][vis]).max() <= 1e-6, "rgb"
         assert np.array_equal(hip["rows_u32"][k][vis][:, 11].view(np.int32), o["radii"][vis])
-        assert np.array_equal(hip["pre_sigmoid"][k][vis], o["pre_sigmoid"][vis]), "relu mask"
+        if relu:
+            assert np.array_equal(hip["pre_sigmoid"][k][vis], o["pre_sigmoid"][vis]), "relu mask"
+        else:   # sigmoid activation: the pre-activation colours, an SH sum like rgb
+            assert np.abs(hip["pre_sigmoid"][k][vis] - o["pre_sigmoid"][vis]).max() <= 1e-5, "pre-sigmoid colours"
     wrote = np.any(ora[0]["cov3D"] != 0, axis=1)     # the oracle fills cov3D only past the near-plane cull
     assert np.array_equal(hip["cov3D"][wrote].view(np.uint32), ora[0]["cov3D"][wrote].view(np.uint32)), "cov3D bits"
 
 
 def test_binning_bit_exact(scene_states):
-    sc, hip, ora = scene_states
+    _check_binning_bits(*scene_states)
+
+
+def _check_binning_bits(sc, hip, ora):
     P, T = sc["P"], hip["T"]
     Rs = [o["num_rendered"] for o in ora]
     assert hip["R"] == sum(Rs)
@@ -370,7 +396,10 @@ def test_tile_cull_lists_are_the_contributing_subset(gpu, seed, sigma):
     """tile_cull drops only duplicates that the reference skips at every pixel (forward.cu:356-358) and keeps the
     surviving ones in the reference's order; images, radii and per-pixel transmittance do not change by one bit."""
     kw = {} if sigma is None else dict(sigma_px=sigma)
-    sc = small_scene(seed=seed, **kw)
+    _check_tile_cull_subset(small_scene(seed=seed, **kw))
+
+
+def _check_tile_cull_subset(sc, ratio=(0.3, 0.9), shell=0.35):
     K, P = sc["K"], sc["P"]
     ref = hip_forward_state(sc, K, cull=False)
     cul = hip_forward_state(sc, K, cull=True)
@@ -381,11 +410,11 @@ def test_tile_cull_lists_are_the_contributing_subset(gpu, seed, sigma):
     assert np.unique(rid).size == rid.size
     kept = np.isin(rid, cid)
     assert np.array_equal(rid[kept], cid), "surviving duplicates keep the reference's (tile, depth) order"
-    assert 0.3 < cul["R"] / ref["R"] < 0.9
+    assert ratio[0] < cul["R"] / max(ref["R"], 1) < ratio[1]
     # nothing that clearly contributes was dropped, and (almost) nothing that clearly cannot was kept
     assert not np.any(_pair_can_contribute(sc, ref, 1.001) & ~kept), "dropped a contributing duplicate"
     cannot = ~_pair_can_contribute(sc, ref, 0.5)
-    assert (cannot & kept).sum() <= 0.35 * kept.sum()     # the tile test is exact; 0.5/255 leaves a thin shell
+    assert (cannot & kept).sum() <= shell * kept.sum()     # the tile test is exact; 0.5/255 leaves a thin shell
     # the low key word is the duplicate's emission index: a permutation of [0, R), segment by segment
     u = (cul["keys"] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     assert np.array_equal(np.sort(u), np.arange(cul["R"]))
@@ -409,6 +438,23 @@ def test_tile_cull_lists_are_the_contributing_subset(gpu, seed, sigma):
     rng = cul["ranges"].reshape(-1, 2).astype(np.int64)
     assert np.array_equal(rng[:, 1] - rng[:, 0], np.bincount((cul["keys"] >> np.uint64(32)).astype(np.int64),
                                                              minlength=rng.shape[0]))
+
+
+if int(os.environ.get("DGS_FUZZ_SWEEP", "0")) > 0:
+    # (defined only on request: an empty parameter set would show up as a skipped test in the default suite)
+    @pytest.mark.parametrize("P,W,H,K,seed,sigma,deg,kw", _fuzz_sweep(int(os.environ["DGS_FUZZ_SWEEP"]), seed0=7000))
+    def test_bit_exact_stages_sweep(gpu, P, W, H, K, seed, sigma, deg, kw):
+        """The integer / bit-exact statements of test_preprocess_bit_exact, test_binning_bit_exact and
+        test_tile_cull_lists_are_the_contributing_subset on seeded random scenes: preprocess bits, duplicate offsets, sort
+        keys, point lists and tile ranges equal to the oracle's; the tile-culled lists an order-preserving subset that drops
+        no contributing duplicate, with images / radii / transmittance unchanged by a bit."""
+        sc = synthetic.make_scene(P, W, H, K=K, seed=seed, sigma_px=sigma, sh_degree=deg)
+        hip = hip_forward_state(sc, K, **kw)
+        ora = [oracle_forward(sc, k, **kw) for k in range(K)]
+        _check_preprocess_bits(sc, hip, ora, min_visible=0, relu=not kw.get("use_sigmoid", False))
+        _check_binning_bits(sc, hip, ora)
+        if not kw:
+            _check_tile_cull_subset(sc, ratio=(0.0, 1.0 + 1e-9), shell=1.0)
 
 
 @pytest.mark.parametrize("depth", [False, True])
@@ -1023,23 +1069,6 @@ FUZZ = [
     (700, 31, 33, 16, 108, 2.0, 2, {}),                      # many subframes
     (500, 48, 32, 40, 109, 2.0, 2, {}),                      # more subframes than the reference ever uses (K <= 128)
 ]
-
-
-def _fuzz_sweep(n, seed0=9000):
-    """DGS_FUZZ_SWEEP=n appends n more cases drawn from a seeded generator (odd sizes, 1-12 subframes, splats from sub-pixel
-    to a dozen pixels, every SH degree, both colour activations): a one-off wider net, not part of the default suite."""
-    rng = np.random.default_rng(seed0)
-    out = []
-    for i in range(n):
-        deg = int(rng.integers(0, 4))
-        kw = {}
-        if rng.random() < 0.35:
-            kw["use_sigmoid"] = True
-        if rng.random() < 0.5:
-            kw["sh_degree"] = int(rng.integers(0, deg + 1))
-        out.append((int(rng.integers(200, 3000)), int(rng.integers(9, 200)), int(rng.integers(9, 140)),
-                    int(rng.integers(1, 13)), seed0 + i, float(np.exp(rng.uniform(np.log(0.3), np.log(12.0)))), deg, kw))
-    return out
 
 
 FUZZ = FUZZ + _fuzz_sweep(int(os.environ.get("DGS_FUZZ_SWEEP", "0")))
