@@ -457,6 +457,37 @@ if int(os.environ.get("DGS_FUZZ_SWEEP", "0")) > 0:
             _check_tile_cull_subset(sc, ratio=(0.0, 1.0 + 1e-9), shell=1.0)
 
 
+if int(os.environ.get("DGS_FUZZ_SWEEP", "0")) > 0:
+    @pytest.mark.parametrize("P,W,H,K,seed,sigma,deg,kw", _fuzz_sweep(int(os.environ["DGS_FUZZ_SWEEP"]), seed0=8000))
+    def test_execution_modes_agree_bitwise_sweep(gpu, P, W, H, K, seed, sigma, deg, kw):
+        """Statements that hold bit for bit whatever the scene, on seeded random ones: tile-culled lists against the
+        reference's lists (images and every gradient), the one-call capacity forward against the two-phase one, two runs
+        of the same call, K fused subframes against K single calls (per-subframe outputs), wide records against packed."""
+        sc = synthetic.make_scene(P, W, H, K=K, seed=seed, sigma_px=sigma, sh_degree=deg)
+        gC, gD = _grads(sc, K, seed=seed)
+        with tile_cull(False):
+            a = hip_forward_backward(sc, K, gC, gD, **kw)
+        with tile_cull(True):
+            b = hip_forward_backward(sc, K, gC, gD, **kw)
+            b2 = hip_forward_backward(sc, K, gC, gD, **kw)
+            s1 = hip_forward_backward(sc, K, gC, gD, fused=False, **kw) if K <= 6 else None
+            with wide_records(True):
+                w = hip_forward_backward(sc, K, gC, gD, **kw)
+        for key in GRAD_KEYS + ["color", "depth", "radii"]:
+            assert np.array_equal(a[key], b[key]), ("tile_cull", key)
+            assert np.array_equal(b[key], b2[key]), ("rerun", key)
+            assert np.array_equal(b[key], w[key]), ("wide_records", key)
+        if s1 is not None:
+            for key in ["color", "depth", "radii", "dL_dmeans2D", "dL_dviewmatrix", "dL_dprojmatrix"]:
+                assert np.array_equal(b[key], s1[key]), ("per-subframe calls", key)
+        st = hip_forward_state(sc, K, cull=True, **kw)
+        cap = hip_forward_state(sc, K, cull=True, capacity=st["R"] + 513, **kw)
+        assert cap["R"] == st["R"] and not cap["overflow"]
+        for key in ("radii", "ranges", "color", "depth", "n_contrib", "final_T"):
+            assert np.array_equal(st[key], cap[key]), ("capacity", key)
+        assert np.array_equal(st["keys"], cap["keys"][:st["R"]]) and np.array_equal(st["point_list"], cap["point_list"][:st["R"]])
+
+
 @pytest.mark.parametrize("depth", [False, True])
 def test_tile_cull_gradients_bitwise_equal(gpu, depth):
     sc = small_scene()
