@@ -372,23 +372,28 @@ def test_variants(gpu, variant):
 
 # ------------------------------------------------------------------------------------------------ edge cases
 # ------------------------------------------------------------------------------------------------ tile culling
-def _pair_can_contribute(sc, st, margin):
+def _pair_can_contribute(sc, st, margin, chunk=32768):
     """For every duplicate of the rectangle lists: does alpha reach margin/255 (with power <= 0) at some in-image
-    pixel of its tile?  float64 restatement of forward.cu:346-358."""
+    pixel of its tile?  float64 restatement of forward.cu:346-358.  Evaluated `chunk` duplicates at a time: the [R, 256]
+    temporaries of a one-shot evaluation are 2 KB per duplicate each -- host memory a large list does not have."""
     W, H, T = sc["W"], sc["H"], st["T"]
     gx = (W + 15) // 16
     kt = (st["keys"] >> np.uint64(32)).astype(np.int64)
-    k, tile = kt // T, kt % T
-    rows = st["rows"][k, st["point_list"].astype(np.int64)].astype(np.float64)
-    x, y, a, b, c, op = (rows[:, i][:, None] for i in range(6))
     lx, ly = np.meshgrid(np.arange(16), np.arange(16))
-    px = (tile % gx)[:, None] * 16 + lx.reshape(1, -1)
-    py = (tile // gx)[:, None] * 16 + ly.reshape(1, -1)
-    dx, dy = x - px, y - py
-    power = -0.5 * (a * dx * dx + c * dy * dy) - b * dx * dy
-    alpha = op * np.exp(np.minimum(power, 0.0))
-    ok = (power <= 0) & (alpha >= margin / 255.0) & (px < W) & (py < H)
-    return ok.any(axis=1)
+    lx, ly = lx.reshape(1, -1), ly.reshape(1, -1)
+    out = np.zeros(kt.size, bool)
+    for i0 in range(0, kt.size, chunk):
+        sl = slice(i0, min(i0 + chunk, kt.size))
+        k, tile = kt[sl] // T, kt[sl] % T
+        rows = st["rows"][k, st["point_list"][sl].astype(np.int64)].astype(np.float64)
+        x, y, a, b, c, op = (rows[:, i][:, None] for i in range(6))
+        px = (tile % gx)[:, None] * 16 + lx
+        py = (tile // gx)[:, None] * 16 + ly
+        dx, dy = x - px, y - py
+        power = -0.5 * (a * dx * dx + c * dy * dy) - b * dx * dy
+        alpha = op * np.exp(np.minimum(power, 0.0))
+        out[sl] = ((power <= 0) & (alpha >= margin / 255.0) & (px < W) & (py < H)).any(axis=1)
+    return out
 
 
 @pytest.mark.parametrize("seed,sigma", [(0, None), (31, 9.0)])
